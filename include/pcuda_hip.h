@@ -1,0 +1,260 @@
+/*
+ * libpcuda_hip.so -- C ABI of the MI355X (gfx950) kernels behind the PointCloudUDA
+ * adversarial train-step hot path.
+ *
+ * The reference (sulaimanvesal/PointCloudUDA) has no FFI: its "operators" are the ATen
+ * ops issued by the modules under src/networks, src/utils/loss.py and the body of train_epoch
+ * (src/train_mscmrseg.py:183-330).  Each entry point below names the reference call
+ * site(s) it replaces.  The Python host (pointcloududa_amd/) binds these with ctypes and
+ * keeps the reference's nn.Module / function signatures on top.
+ *
+ * Conventions
+ *   - all tensors are device pointers owned by the caller; fp32 unless stated otherwise;
+ *     image tensors are NCHW with dense HxW planes and explicit batch/channel strides
+ *     (in ELEMENTS), so channel slices of concatenated buffers can be passed without copies;
+ *   - every launch goes to the caller's hipStream_t (void* here); nothing allocates, frees
+ *     or synchronises; scratch memory is passed in (query the size with *_workspace_size);
+ *   - return value: 0 = ok, <0 = error (PCUDA_E_*); never throws;
+ *   - precision modes for the MFMA convolutions (operands are split on the fly from fp32):
+ *       PCUDA_PREC_BF16X3  a = a_hi + a_lo (two bf16), a*b ~= ah*bh + ah*bl + al*bh, fp32 accumulate
+ *                          (~2^-17 relative per product: the parity mode, default)
+ *       PCUDA_PREC_BF16    single bf16 MFMA per product, fp32 accumulate (throughput mode)
+ */
+#ifndef PCUDA_HIP_H
+#define PCUDA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCUDA_OK 0
+#define PCUDA_E_BADARG (-1)
+#define PCUDA_E_UNSUPPORTED (-2)
+#define PCUDA_E_LAUNCH (-3)
+#define PCUDA_E_WORKSPACE (-4)
+
+#define PCUDA_PREC_BF16X3 0
+#define PCUDA_PREC_BF16 1
+
+typedef void* pcuda_stream_t; /* hipStream_t */
+
+/* library / device ----------------------------------------------------------------- */
+int pcuda_version(void);                 /* ABI version of this header */
+int pcuda_device_count(void);            /* hipGetDeviceCount, 0 when no GPU */
+const char* pcuda_last_error(void);      /* text of the last failing call on this thread */
+
+/* kernel-family timing (HIP events recorded on the launch stream around every launch of
+ * a family while enabled; used by bench.py for the live roofline figure) */
+#define PCUDA_FAM_CONV_FWD 0   /* implicit-GEMM forward + dgrad launches */
+#define PCUDA_FAM_CONV_WGRAD 1
+#define PCUDA_FAM_POINTWISE 2
+#define PCUDA_FAM_COUNT 3
+int pcuda_prof_enable(int on);
+int pcuda_prof_reset(void);
+/* synchronises the recorded events; ms = summed kernel time, work = summed algorithmic
+ * FLOPs (conv families) or bytes (pointwise), launches = number of launches */
+int pcuda_prof_read(int family, double* ms, double* work, long long* launches);
+
+/* ------------------------------------------------------------------------------------
+ * 2-D convolution: replaces nn.Conv2d forward/backward at
+ *   unet.py:23,27,32 (encoder 3x3 / 1x1), :61 (dilated bottleneck), :85 (6x6 head),
+ *   :112,116,122 (decoder), :178 (classifier); GAN.py:97-107 (4x4 s2 p2, 3x3 s2 p1).
+ * cross-correlation, square kernel, symmetric padding, one dilation, groups = 1.
+ * ---------------------------------------------------------------------------------- */
+typedef struct pcuda_conv_geom {
+  int n;            /* batch */
+  int cin, cout;
+  int in_h, in_w;   /* LOGICAL input plane (after the optional x2 upsample) */
+  int out_h, out_w; /* = floor((in + 2*pad - dil*(k-1) - 1)/stride) + 1 */
+  int k, stride, pad, dil;
+  int in_up;        /* 1: the stored input is (in_h/2 x in_w/2) and is read through a nearest x2
+                       upsample (folds nn.UpsamplingNearest2d, unet.py:111, into the conv) */
+} pcuda_conv_geom;
+
+/* source / destination that may be split across two tensors along channels
+ * (zero-copy torch.cat(dim=1): unet.py:46,134).  c1 = channels taken from p1; the rest come
+ * from p2 (p2 may be NULL when c1 == total).  scale/shift: optional per-channel affine
+ * applied on load to in-bounds elements (fused BatchNorm apply), NULL = identity. */
+typedef struct pcuda_src {
+  const float* p1; long long sn1, sc1; const float* scale1; const float* shift1;
+  const float* p2; long long sn2, sc2; const float* scale2; const float* shift2;
+  int c1;
+} pcuda_src;
+typedef struct pcuda_dst {
+  float* p1; long long sn1, sc1;
+  float* p2; long long sn2, sc2;
+  int c1;
+} pcuda_dst;
+
+/* packed-weight sizes (bytes) for a given geometry / precision */
+size_t pcuda_conv2d_packed_fwd_bytes(const pcuda_conv_geom* g, int prec);
+size_t pcuda_conv2d_packed_dgrad_bytes(const pcuda_conv_geom* g, int prec);
+/* repack fp32 OIHW weights into the MFMA-fragment layout ([co-tile][ci-chunk][tap][row][32+8]
+ * bf16 hi (+lo)); call once per optimiser step */
+int pcuda_conv2d_pack_fwd(const pcuda_conv_geom* g, int prec, const float* w, void* packed, pcuda_stream_t s);
+int pcuda_conv2d_pack_dgrad(const pcuda_conv_geom* g, int prec, const float* w, void* packed, pcuda_stream_t s);
+
+/* y = lrelu(conv(x) + bias, slope)   (slope = 1 -> no activation; bias may be NULL)
+ * bn_partials (optional): per-tile partial sums [ntiles][cout][2] (sum, sum of squares) of the
+ * activated output, for the BatchNorm that follows (unet.py:26,30); ntiles from
+ * pcuda_conv2d_fwd_tiles().  Deterministic (no atomics). */
+int pcuda_conv2d_fwd_tiles(const pcuda_conv_geom* g, int prec);
+int pcuda_conv2d_forward(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const void* packed_w,
+                         const float* bias, float slope, const pcuda_dst* y, float* bn_partials,
+                         pcuda_stream_t s);
+/* dx (+)= conv_transpose(dy): the data gradient; for stride 2 this is the transposed
+ * convolution the adversarial gradient takes back through the discriminators.
+ * dy: [n][cout][out_h][out_w] given as a pcuda_src (c1 = cout); dx may be split like a cat.
+ * When g->in_up is set, dx is the gradient of the UPSAMPLED (logical) input. */
+int pcuda_conv2d_dgrad(const pcuda_conv_geom* g, int prec, const pcuda_src* dy, const void* packed_w_dgrad,
+                       const pcuda_dst* dx, int accumulate, pcuda_stream_t s);
+/* dw (+)= sum over batch and space of dy (x) x ; db (+)= sum dy (db may be NULL).
+ * workspace: pcuda_conv2d_wgrad_workspace_size() bytes. */
+size_t pcuda_conv2d_wgrad_workspace_size(const pcuda_conv_geom* g);
+int pcuda_conv2d_wgrad(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const float* dy,
+                       long long dy_sn, long long dy_sc, float* dw, float* db, int accumulate,
+                       void* workspace, size_t workspace_bytes, pcuda_stream_t s);
+
+/* ------------------------------------------------------------------------------------
+ * BatchNorm (training mode) around LeakyReLU: conv -> LeakyReLU -> BatchNorm2d
+ * (unet.py:23-30,116-125); also BatchNorm1d of PointNetCls.py (hw = points or 1).
+ * ---------------------------------------------------------------------------------- */
+/* reduce per-tile partials -> mean, invstd, scale = gamma*invstd, shift = beta - mean*scale;
+ * running stats updated with momentum (unbiased variance), torch semantics. count = n*h*w */
+int pcuda_bn_finalize(const float* partials, int ntiles, int c, long long count, const float* gamma,
+                      const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                      float* mean, float* invstd, float* scale, float* shift, pcuda_stream_t s);
+/* partial sums of a tensor a[n][c][hw] (for layers whose producer is not a conv epilogue);
+ * returns ntiles written through *ntiles (query with partials == NULL) */
+int pcuda_bn_stats(const float* a, long long sn, long long sc, int n, int c, long long hw,
+                   float* partials, int* ntiles, pcuda_stream_t s);
+/* y = a*scale[c] + shift[c]; optional relu (PointNetCls.py:41-43) */
+int pcuda_bn_apply(const float* a, long long a_sn, long long a_sc, const float* scale, const float* shift,
+                   int relu, float* y, long long y_sn, long long y_sc, int n, int c, long long hw,
+                   pcuda_stream_t s);
+/* backward of [z -> a = lrelu(z, slope) -> y = BN(a)] given dy (optionally dy + dy2):
+ * pass 1: per-tile partials of (sum dy, sum dy*xhat) -> red[ntiles][c][2]
+ * pass 2 (after pcuda_bn_bwd_finalize): dz = lrelu'(a) * scale*(dy - mean_dy - xhat*mean_dyxhat)
+ * post_relu: the block is BN -> ReLU instead (PointNetCls): dy is first masked by (y > 0) and
+ * `act_slope` applies to nothing (a is then the BN input). */
+int pcuda_bn_bwd_reduce(const float* dy, long long dy_sn, long long dy_sc, const float* dy2, long long dy2_sn,
+                        long long dy2_sc, const float* a, long long a_sn, long long a_sc, const float* mean,
+                        const float* invstd, const float* scale, const float* shift, int post_relu, int n, int c,
+                        long long hw, float* red, int* ntiles, pcuda_stream_t s);
+int pcuda_bn_bwd_finalize(const float* red, int ntiles, int c, long long count, const float* gamma,
+                          const float* invstd, const float* mean, float* dgamma, float* dbeta, int accumulate,
+                          float* coef /* [c][3]: dz = m*(c0*dy + c1*a + c2) */, pcuda_stream_t s);
+int pcuda_bn_bwd_apply(const float* dy, long long dy_sn, long long dy_sc, const float* dy2, long long dy2_sn,
+                       long long dy2_sc, const float* a, long long a_sn, long long a_sc, const float* coef,
+                       const float* scale, const float* shift, int post_relu, float act_slope, float* dz,
+                       long long dz_sn, long long dz_sc, int n, int c, long long hw, pcuda_stream_t s);
+/* dz = dy * (a > 0 ? 1 : slope)   (LeakyReLU backward from the saved OUTPUT, as the in-place
+ * nn.LeakyReLU of unet.py:24 / GAN.py:108 does); optional second addend dy2 */
+int pcuda_lrelu_bwd(const float* dy, long long dy_sn, long long dy_sc, const float* dy2, long long dy2_sn,
+                    long long dy2_sc, const float* a, long long a_sn, long long a_sc, float slope, float* dz,
+                    long long dz_sn, long long dz_sc, int n, int c, long long hw, pcuda_stream_t s);
+/* per-channel sum over batch and space (bias gradients) db (+)= sum dz */
+int pcuda_channel_sum(const float* dz, long long sn, long long sc, int n, int c, long long hw, float* db,
+                      int accumulate, float* workspace, size_t workspace_bytes, pcuda_stream_t s);
+
+/* ------------------------------------------------------------------------------------
+ * pooling / resampling / adds (unet.py:48 MaxPool2d(2,2); :111 UpsamplingNearest2d backward)
+ * ---------------------------------------------------------------------------------- */
+/* y = maxpool2x2(x*scale + shift) with argmax code (0..3) saved as uint8 */
+int pcuda_maxpool2_fwd(const float* x, long long x_sn, long long x_sc, const float* scale, const float* shift,
+                       float* y, long long y_sn, long long y_sc, uint8_t* idx, int n, int c, int h, int w,
+                       pcuda_stream_t s);
+/* dx (+)= scatter(dy (+ dy2)) through idx; positions not selected get 0 (or keep when accumulate) */
+int pcuda_maxpool2_bwd(const float* dy, long long dy_sn, long long dy_sc, const float* dy2, long long dy2_sn,
+                       long long dy2_sc, const uint8_t* idx, float* dx, long long dx_sn, long long dx_sc,
+                       int accumulate, int n, int c, int h, int w, pcuda_stream_t s);
+/* dx[h][w] (+)= sum of the 2x2 block of dy[2h][2w] (nearest-upsample backward) */
+int pcuda_upsample2_bwd(const float* dy, long long dy_sn, long long dy_sc, float* dx, long long dx_sn,
+                        long long dx_sc, int accumulate, int n, int c, int h, int w, pcuda_stream_t s);
+/* y = a + b (+ c) (+ d), flat fp32 (bottleneck running sum, unet.py:68-73; gradient joins) */
+int pcuda_add4(const float* a, const float* b, const float* c, const float* d, float* y, long long numel,
+               pcuda_stream_t s);
+/* y = a * b, flat fp32 (applies a precomputed nn.Dropout mask, PointNetCls.py:179,209) */
+int pcuda_mul(const float* a, const float* b, float* y, long long numel, pcuda_stream_t s);
+
+/* ------------------------------------------------------------------------------------
+ * losses / entropy (train_mscmrseg.py:202-203,222-226; train_mmwhs.py:212-224,242; loss.py)
+ * ---------------------------------------------------------------------------------- */
+#define PCUDA_ACT_SIGMOID 0
+#define PCUDA_ACT_SOFTMAX 1
+/* e = -p*log(p + 1e-7) * norm, p = sigmoid|softmax(logits); optionally also writes p */
+int pcuda_entropy_fwd(const float* logits, int mode, float norm, float* ent, float* prob, int n, int c,
+                      long long hw, pcuda_stream_t s);
+/* dlogits (+)= d(ent)/dlogits . dent  (+ dprob through p when dprob != NULL) */
+int pcuda_entropy_bwd(const float* logits, int mode, float norm, const float* dent, const float* dprob,
+                      float* dlogits, int accumulate, int n, int c, long long hw, pcuda_stream_t s);
+/* segmentation loss: mode SIGMOID: BCE(sigmoid(o), y) + jaccard(sigmoid(o), y)
+ *                    mode SOFTMAX: cross_entropy(softmax(o), argmax y) ("double softmax") + jaccard(softmax(o), y)
+ * y: one-hot uint8 [n][c][hw].  out[0] = bce|ce, out[1] = jaccard.  workspace from *_workspace_size.
+ * pass 1 (fwd) leaves the per-class sums in the workspace; bwd reuses them. */
+size_t pcuda_seg_loss_workspace_size(int n, int c, long long hw);
+int pcuda_seg_loss_fwd(const float* logits, const uint8_t* onehot, int mode, int n, int c, long long hw,
+                       float* out2, void* workspace, size_t workspace_bytes, pcuda_stream_t s);
+/* dlogits = g_main * d(bce|ce)/do + g_jac * d(jaccard)/do */
+int pcuda_seg_loss_bwd(const float* logits, const uint8_t* onehot, int mode, int n, int c, long long hw,
+                       const float* g_main, const float* g_jac, float* dlogits, const void* workspace,
+                       pcuda_stream_t s);
+/* mean BCE-with-logits against a constant label; acc (optional) = mean(sigmoid(x) >= .5)
+ * (train_mscmrseg.py:224-226,270-273) */
+int pcuda_bce_const_fwd(const float* x, long long numel, float label, float* loss, float* acc, pcuda_stream_t s);
+int pcuda_bce_const_bwd(const float* x, long long numel, float label, const float* gout, float gscale, float* dx,
+                        pcuda_stream_t s);
+/* batch_NN_loss (loss.py:40-76): x,y [b][npts][3]; loss scalar; idx workspaces int32 [2][b][npts] */
+int pcuda_nn_loss_fwd(const float* x, const float* y, int b, int npts, float* loss, int* idx_ws, float* val_ws,
+                      pcuda_stream_t s);
+int pcuda_nn_loss_bwd(const float* x, const float* y, int b, int npts, const int* idx_ws, const float* val_ws,
+                      const float* gout, float* dx, pcuda_stream_t s);
+/* per-step host metric moved on-device (utils.py:32-40 + metric.py:5-36): hard = (o == max_c o);
+ * dice = mean_{c>=1} (2*sum(y*hard)+1)/(sum y + sum hard + 1).  workspace: 3*c doubles. */
+int pcuda_dice_metric(const float* logits, const uint8_t* onehot, int n, int c, long long hw, float* dice,
+                      void* workspace, size_t workspace_bytes, pcuda_stream_t s);
+
+/* ------------------------------------------------------------------------------------
+ * small dense ops of PointNetCls / the point head (PointNetCls.py; unet.py:86,94-95)
+ * ---------------------------------------------------------------------------------- */
+/* y[m][n] = x[m][k] . w[n][k]^T + b[n]   (nn.Linear; also conv1d k=1 seen as [B*L][C]) */
+int pcuda_linear_fwd(const float* x, const float* w, const float* b, float* y, int m, int k, int n, pcuda_stream_t s);
+int pcuda_linear_bwd_x(const float* dy, const float* w, float* dx, int m, int k, int n, int accumulate, pcuda_stream_t s);
+int pcuda_linear_bwd_w(const float* dy, const float* x, float* dw, float* db, int m, int k, int n, int accumulate,
+                       pcuda_stream_t s);
+/* max over the last axis of x[b][c][l] with argmax (PointNetCls.py:44,162) */
+int pcuda_max_points_fwd(const float* x, int b, int c, int l, float* y, int* idx, pcuda_stream_t s);
+int pcuda_max_points_bwd(const float* dy, const int* idx, int b, int c, int l, float* dx, pcuda_stream_t s);
+/* batched small matmul C[b] = op(A[b]) . op(B[b]); A [m][k] (or [k][m] when ta), B [k][n] (or [n][k] when tb) */
+int pcuda_bmm(const float* a, const float* bmat, float* c, int batch, int m, int k, int n, int ta, int tb,
+              int accumulate, pcuda_stream_t s);
+
+/* ------------------------------------------------------------------------------------
+ * mask -> surface point cloud sampler (utils/npy2point.py:7-18,101-125)
+ * ---------------------------------------------------------------------------------- */
+/* canonical surface-vertex list of b binary masks [b][h][w] (uint8, >0 = foreground):
+ * verts int32 [b][max_verts][3] rows (z,y,x) in lexicographic order, z in {0,1,2}; counts[b].
+ * workspace: b*h*w*4 + 4096 bytes */
+int pcuda_surface_vertices(const uint8_t* mask, int b, int h, int w, int* verts, int max_verts, int* counts,
+                           void* workspace, size_t workspace_bytes, pcuda_stream_t s);
+/* farthest point sampling (graipher): pts float64 [b][npts_max][3] with counts[b] valid rows;
+ * first[b] = start index; out idx int32 [b][k].  Bit-exact with numpy float64 (no FMA contraction,
+ * first-occurrence argmax).  counts[b] == 0 -> idx all -1 */
+int pcuda_fps(const double* pts, const int* counts, const int* first, int b, int npts_max, int k, int* idx,
+              pcuda_stream_t s);
+
+/* ------------------------------------------------------------------------------------
+ * optimisers on flat fp32 buffers (train_mscmrseg.py:427-455: Adam(b=(.9,.99)); SGD(m, wd))
+ * ---------------------------------------------------------------------------------- */
+int pcuda_adam_step(float* p, const float* g, float* m, float* v, long long numel, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int step, float grad_scale, pcuda_stream_t s);
+int pcuda_sgd_step(float* p, const float* g, float* mom, long long numel, float lr, float momentum,
+                   float weight_decay, int first_step, float grad_scale, pcuda_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCUDA_HIP_H */

@@ -1,0 +1,111 @@
+"""ctypes binding of libpcuda_hip.so (the C ABI declared in include/pcuda_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a call
+returns an error code, a RuntimeError is raised with the library's own message.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpcuda_hip.so")
+
+PREC_BF16X3, PREC_BF16 = 0, 1
+ACT_SIGMOID, ACT_SOFTMAX = 0, 1
+FAM_CONV_FWD, FAM_CONV_WGRAD, FAM_POINTWISE = 0, 1, 2
+
+c_f32p = C.c_void_p      # all device pointers travel as integers
+i32, i64, f32, vp, sz = C.c_int, C.c_longlong, C.c_float, C.c_void_p, C.c_size_t
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [("n", i32), ("cin", i32), ("cout", i32), ("in_h", i32), ("in_w", i32), ("out_h", i32),
+                ("out_w", i32), ("k", i32), ("stride", i32), ("pad", i32), ("dil", i32), ("in_up", i32)]
+
+
+class Src(C.Structure):
+    _fields_ = [("p1", vp), ("sn1", i64), ("sc1", i64), ("scale1", vp), ("shift1", vp),
+                ("p2", vp), ("sn2", i64), ("sc2", i64), ("scale2", vp), ("shift2", vp), ("c1", i32)]
+
+
+class Dst(C.Structure):
+    _fields_ = [("p1", vp), ("sn1", i64), ("sc1", i64), ("p2", vp), ("sn2", i64), ("sc2", i64), ("c1", i32)]
+
+
+_PROTOS = {
+    "pcuda_version": (i32, []),
+    "pcuda_device_count": (i32, []),
+    "pcuda_last_error": (C.c_char_p, []),
+    "pcuda_prof_enable": (i32, [i32]),
+    "pcuda_prof_reset": (i32, []),
+    "pcuda_prof_read": (i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]),
+    "pcuda_conv2d_packed_fwd_bytes": (sz, [C.POINTER(ConvGeom), i32]),
+    "pcuda_conv2d_packed_dgrad_bytes": (sz, [C.POINTER(ConvGeom), i32]),
+    "pcuda_conv2d_pack_fwd": (i32, [C.POINTER(ConvGeom), i32, vp, vp, vp]),
+    "pcuda_conv2d_pack_dgrad": (i32, [C.POINTER(ConvGeom), i32, vp, vp, vp]),
+    "pcuda_conv2d_fwd_tiles": (i32, [C.POINTER(ConvGeom), i32]),
+    "pcuda_conv2d_forward": (i32, [C.POINTER(ConvGeom), i32, C.POINTER(Src), vp, vp, f32, C.POINTER(Dst), vp, vp]),
+    "pcuda_conv2d_dgrad": (i32, [C.POINTER(ConvGeom), i32, C.POINTER(Src), vp, C.POINTER(Dst), i32, vp]),
+    "pcuda_conv2d_wgrad_workspace_size": (sz, [C.POINTER(ConvGeom)]),
+    "pcuda_conv2d_wgrad": (i32, [C.POINTER(ConvGeom), i32, C.POINTER(Src), vp, i64, i64, vp, vp, i32, vp, sz, vp]),
+    "pcuda_bn_finalize": (i32, [vp, i32, i32, i64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp]),
+    "pcuda_bn_stats": (i32, [vp, i64, i64, i32, i32, i64, vp, C.POINTER(i32), vp]),
+    "pcuda_bn_apply": (i32, [vp, i64, i64, vp, vp, i32, vp, i64, i64, i32, i32, i64, vp]),
+    "pcuda_bn_bwd_reduce": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, vp, vp, i32, i32, i32, i64, vp,
+                                  C.POINTER(i32), vp]),
+    "pcuda_bn_bwd_finalize": (i32, [vp, i32, i32, i64, vp, vp, vp, vp, vp, i32, vp, vp]),
+    "pcuda_bn_bwd_apply": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, vp, i32, f32, vp, i64, i64, i32,
+                                 i32, i64, vp]),
+    "pcuda_lrelu_bwd": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, f32, vp, i64, i64, i32, i32, i64, vp]),
+    "pcuda_channel_sum": (i32, [vp, i64, i64, i32, i32, i64, vp, i32, vp, sz, vp]),
+    "pcuda_maxpool2_fwd": (i32, [vp, i64, i64, vp, vp, vp, i64, i64, vp, i32, i32, i32, i32, vp]),
+    "pcuda_maxpool2_bwd": (i32, [vp, i64, i64, vp, i64, i64, vp, vp, i64, i64, i32, i32, i32, i32, i32, vp]),
+    "pcuda_upsample2_bwd": (i32, [vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, i32, vp]),
+    "pcuda_add4": (i32, [vp, vp, vp, vp, vp, i64, vp]),
+    "pcuda_mul": (i32, [vp, vp, vp, i64, vp]),
+    "pcuda_entropy_fwd": (i32, [vp, i32, f32, vp, vp, i32, i32, i64, vp]),
+    "pcuda_entropy_bwd": (i32, [vp, i32, f32, vp, vp, vp, i32, i32, i32, i64, vp]),
+    "pcuda_seg_loss_workspace_size": (sz, [i32, i32, i64]),
+    "pcuda_seg_loss_fwd": (i32, [vp, vp, i32, i32, i32, i64, vp, vp, sz, vp]),
+    "pcuda_seg_loss_bwd": (i32, [vp, vp, i32, i32, i32, i64, vp, vp, vp, vp, vp]),
+    "pcuda_bce_const_fwd": (i32, [vp, i64, f32, vp, vp, vp]),
+    "pcuda_bce_const_bwd": (i32, [vp, i64, f32, vp, f32, vp, vp]),
+    "pcuda_nn_loss_fwd": (i32, [vp, vp, i32, i32, vp, vp, vp, vp]),
+    "pcuda_nn_loss_bwd": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp]),
+    "pcuda_dice_metric": (i32, [vp, vp, i32, i32, i64, vp, vp, sz, vp]),
+    "pcuda_linear_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "pcuda_linear_bwd_x": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "pcuda_linear_bwd_w": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "pcuda_max_points_fwd": (i32, [vp, i32, i32, i32, vp, vp, vp]),
+    "pcuda_max_points_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp]),
+    "pcuda_bmm": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "pcuda_surface_vertices": (i32, [vp, i32, i32, i32, vp, i32, vp, vp, sz, vp]),
+    "pcuda_fps": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
+    "pcuda_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
+    "pcuda_sgd_step": (i32, [vp, vp, vp, i64, f32, f32, f32, i32, f32, vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(_PROTOS.keys())
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if it has not been built (run `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libpcuda_hip.so is missing at %s: build it with pointcloududa_amd/csrc/Makefile "
+                               "(there is no CPU fallback)" % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(handle, name)      # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().pcuda_last_error()
+        raise RuntimeError("libpcuda_hip %s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))

@@ -1,0 +1,74 @@
+// Shared device/host helpers for libpcuda_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/pcuda_hip.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LDS_AS __attribute__((address_space(3)))
+
+// ---------------------------------------------------------------- error plumbing
+void pcuda_set_error(const char* fmt, ...);
+#define PCUDA_FAIL(code, ...)      \
+  do {                             \
+    pcuda_set_error(__VA_ARGS__);  \
+    return (code);                 \
+  } while (0)
+#define PCUDA_CHECK_LAUNCH(name)                                          \
+  do {                                                                    \
+    hipError_t e__ = hipGetLastError();                                   \
+    if (e__ != hipSuccess) PCUDA_FAIL(PCUDA_E_LAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
+  } while (0)
+
+// ---------------------------------------------------------------- profiling hooks (prof.hip)
+struct ProfScope {
+  int fam;
+  void* ev0;
+  ProfScope(int family, double work, hipStream_t s);
+  ~ProfScope();
+  hipStream_t stream;
+};
+
+// ---------------------------------------------------------------- bf16 split helpers
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  bf16x2 p = {(__bf16)a, (__bf16)b};  // v_cvt_pk_bf16_f32 (round to nearest even, NaN preserving)
+  return __builtin_bit_cast(uint32_t, p);
+}
+__device__ __forceinline__ float bf16_hi_as_float(float a) {
+  __bf16 h = (__bf16)a;
+  return (float)h;
+}
+// hi/lo packs of two floats: hi = bf16(a), lo = bf16(a - hi)
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  bf16x2 ph = {(__bf16)a, (__bf16)b};
+  hi = __builtin_bit_cast(uint32_t, ph);
+  float ra = a - (float)ph[0], rb = b - (float)ph[1];
+  lo = pack_bf16x2(ra, rb);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// sum over the 32 lanes that share (lane >> 5)
+__device__ __forceinline__ float half_wave_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,90 @@
+// Parameter blocks of the implicit-GEMM convolution kernels (host + device).
+#pragma once
+#include "common.h"
+
+#define IG_MAX_TAPS 36
+#define IG_REC 40          // bf16 per LDS record: 32 channels + 8 pad (80 B: conflict-free b128 reads)
+#define IG_REC_BYTES 80
+
+// One launch of the generic kernel computes, for every logical output pixel (oy,ox) and row r:
+//   D[r][oy,ox] = sum_{tap t, channel c} Wp[t][r][c] * X[c][oy*in_step + dy[t]][ox*in_step + dx[t]]
+// and stores act(D + bias) at physical (oy*oy_mul + oy_off, ox*ox_mul + ox_off).
+// forward:  r = cout, c = cin, in_step = stride, d = k*dil - pad
+// dgrad:    r = cin,  c = cout, in_step = 1, one launch per stride-parity class
+struct IgemmParams {
+  pcuda_src x;
+  int cin;                 // reduction channels
+  int in_h, in_w;          // logical input plane (bounds for zero padding)
+  int in_shift;            // 1: stored plane is (in_h>>1, in_w>>1), read through nearest x2
+  int in_row;              // stored row length
+  pcuda_dst y;
+  int cout;                // rows
+  int out_w;               // physical row length of the output planes
+  int lh, lw;              // logical output grid
+  int oy_mul, oy_off, ox_mul, ox_off;
+  int in_step;
+  int ntaps, tg;           // taps; taps staged per weight group
+  signed char dy[IG_MAX_TAPS], dx[IG_MAX_TAPS];
+  int dy_min, dx_min, ih_t, iw_t;   // unclamped LDS tile: origin offset and dims
+  const uint16_t* wpack;   // [co_tile][chunk][tap][CO_TILE][IG_REC] bf16 bits; lo plane at +w_lo_off
+  long long w_lo_off;
+  int nchunks;
+  const float* bias;
+  float slope;
+  int accumulate;
+  float* stats;            // [tile][cout][2] partial (sum, sumsq) of the stored values, or NULL
+  int twl;                 // log2(tile width); tile = 256 logical pixels
+  int tiles_x, tiles_y, n;
+  int n_co_tiles;
+  int clamp;               // 1: LDS tile = tile clipped to the image (+ one zero record)
+};
+
+// wgrad: dW[r][c][tap] = sum_{n,oy,ox} dZ[r][oy,ox] * X[c][oy*stride + dy[t]][ox*stride + dx[t]]
+struct WgradParams {
+  pcuda_src x;
+  int cin;
+  int in_h, in_w, in_shift, in_row;
+  const float* dz; long long dz_sn, dz_sc;
+  int cout, out_h, out_w;
+  int stride;
+  int ntaps;               // taps handled per block-group (<= 9)
+  int ntaps_total, tap_groups;
+  signed char dy[IG_MAX_TAPS], dx[IG_MAX_TAPS];
+  int ih_t, iw_t;          // LDS tile dims per tap group are computed from the FULL tap span
+  int dy_min, dx_min;
+  int twl;                 // tile = 128 logical pixels
+  int tiles_x, tiles_y, n;
+  int ksplit;              // gridDim.y
+  int n_co_tiles, n_chunks;
+  float* partial;          // [ksplit][cout][cin][ntaps_total] fp32
+  int aligned4;            // dz rows can be read with float4
+};
+
+struct PackParams {
+  const float* w;
+  uint16_t* out;
+  long long lo_off;        // 0 -> no lo plane (bf16 mode)
+  int rows, red;           // rows (M) and reduction (K) extents
+  long long s_row, s_red;  // element strides in w for row / reduction index (tap stride is 1)
+  int ntaps;
+  signed char tap_src[IG_MAX_TAPS];
+  int co_tile;             // 32 or 64
+  int nchunks, n_co_tiles;
+};
+
+static inline int ig_co_blks(int rows) { return rows > 32 ? 2 : 1; }
+// log2 of the tile width for tiles of `tile_px` logical pixels: minimise the padded area,
+// ties -> 32-wide rows (one MFMA column block = one 128-B output row segment)
+static inline int ig_twl(int lw, int lh, int tile_px) {
+  int best = 5;
+  long long best_cost = -1;
+  const int order[6] = {5, 6, 4, 7, 3, 8};
+  for (int oi = 0; oi < 6; ++oi) {
+    const int twl = order[oi];
+    const int tw = 1 << twl, th = tile_px >> twl;
+    if (th < 1) continue;
+    const long long cost = (long long)((lw + tw - 1) / tw) * tw * (long long)((lh + th - 1) / th) * th;
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = twl; }
+  }
+  return best;
+}

@@ -1,0 +1,874 @@
+// Implicit-GEMM (im2col-free) NCHW convolution on the CDNA4 matrix cores.
+//
+// Replaces nn.Conv2d forward / backward of the reference (unet.py:23,27,32,61,85,112,116,122,178;
+// GAN.py:97-107).  Activations stay fp32 NCHW in HBM; a block stages a haloed input tile of
+// 32 channels into LDS pixel-major ([pixel][32 ch + 8 pad] bf16, 80-B records -> conflict-free
+// ds_read_b128), splitting fp32 into bf16 hi (+ lo) on the way, and the four waves issue
+// v_mfma_f32_32x32x16_bf16 with D[row = output channel][col = pixel] so that the accumulator
+// registers store straight into NCHW rows (32 consecutive pixels = 128 B per register).
+//   forward / dgrad : igemm_kernel  (dgrad = the same kernel over role-swapped packed weights,
+//                     one launch per stride-parity class = transposed convolution)
+//   wgrad           : wgrad_kernel  (reduction over pixels; X read back through
+//                     ds_read_b64_tr_b16, split-K partial slabs + deterministic reduce)
+#include "conv_igemm.h"
+
+// ------------------------------------------------------------------------------------------
+// weight repack: fp32 [rows][red][taps] (any strides) -> bf16 [co_tile][chunk][tap][CO_TILE][40]
+// ------------------------------------------------------------------------------------------
+__global__ void pack_kernel(const PackParams p) {
+  const long long total = (long long)p.n_co_tiles * p.nchunks * p.ntaps * p.co_tile * IG_REC;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    int col = (int)(idx % IG_REC);
+    long long rest = idx / IG_REC;
+    int row = (int)(rest % p.co_tile); rest /= p.co_tile;
+    int t = (int)(rest % p.ntaps); rest /= p.ntaps;
+    int ch = (int)(rest % p.nchunks);
+    int cot = (int)(rest / p.nchunks);
+    int r = cot * p.co_tile + row, c = ch * 32 + col;
+    float v = 0.f;
+    if (col < 32 && r < p.rows && c < p.red) v = p.w[r * p.s_row + c * p.s_red + p.tap_src[t]];
+    __bf16 hi = (__bf16)v;
+    p.out[idx] = __builtin_bit_cast(uint16_t, hi);
+    if (p.lo_off) {
+      __bf16 lo = (__bf16)(v - (float)hi);
+      p.out[p.lo_off + idx] = __builtin_bit_cast(uint16_t, lo);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// stage one 32-channel chunk of a haloed input tile into LDS, pixel-major, bf16 hi (+ lo)
+// ------------------------------------------------------------------------------------------
+template <bool X3>
+__device__ __forceinline__ void stage_x_chunk(unsigned char* __restrict__ xhi, unsigned char* __restrict__ xlo,
+                                              const pcuda_src& x, int n, int cin, int chunk, int in_h, int in_w,
+                                              int in_shift, int in_row, int oy0, int ox0, int th, int tw,
+                                              int ngroups, int tid) {
+  const int npix = th * tw;
+  const int cbase = chunk * 32;
+  for (int pix = tid; pix < npix; pix += 256) {
+    const int iy = pix / tw, ix = pix - iy * tw;
+    const int gy = oy0 + iy, gx = ox0 + ix;
+    const bool inb = ((unsigned)gy < (unsigned)in_h) & ((unsigned)gx < (unsigned)in_w);
+    const long long off = (long long)(gy >> in_shift) * in_row + (gx >> in_shift);
+    for (int g = 0; g < ngroups; ++g) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = cbase + g * 8 + j;   // wave-uniform
+        float val = 0.f;
+        if (c < cin) {
+          if (c < x.c1) {
+            if (inb) {
+              val = x.p1[(long long)n * x.sn1 + (long long)c * x.sc1 + off];
+              if (x.scale1) val = val * x.scale1[c] + x.shift1[c];
+            }
+          } else {
+            const int cc = c - x.c1;
+            if (inb) {
+              val = x.p2[(long long)n * x.sn2 + (long long)cc * x.sc2 + off];
+              if (x.scale2) val = val * x.scale2[cc] + x.shift2[cc];
+            }
+          }
+        }
+        v[j] = val;
+      }
+      uint4 hi, lo;
+      if (X3) {
+        split2(v[0], v[1], hi.x, lo.x); split2(v[2], v[3], hi.y, lo.y);
+        split2(v[4], v[5], hi.z, lo.z); split2(v[6], v[7], hi.w, lo.w);
+        *(uint4*)(xlo + (size_t)pix * IG_REC_BYTES + g * 16) = lo;
+      } else {
+        hi.x = pack_bf16x2(v[0], v[1]); hi.y = pack_bf16x2(v[2], v[3]);
+        hi.z = pack_bf16x2(v[4], v[5]); hi.w = pack_bf16x2(v[6], v[7]);
+      }
+      *(uint4*)(xhi + (size_t)pix * IG_REC_BYTES + g * 16) = hi;
+    }
+  }
+}
+
+__device__ __forceinline__ bf16x8 lds_frag(const unsigned char* p) {
+  return __builtin_bit_cast(bf16x8, *(const uint4*)p);
+}
+
+// ------------------------------------------------------------------------------------------
+// forward / dgrad kernel.  256 threads = 4 waves; tile = CO_TILE rows x (128*NPB) logical pixels;
+// wave w owns pixels [32*NPB*w, +32*NPB) (NPB 32-pixel MFMA column blocks) for all CO_BLKS row blocks.
+// ------------------------------------------------------------------------------------------
+template <bool X3, int CO_BLKS, bool CLAMP, int NPB>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p, const int x_cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int CO_TILE = 32 * CO_BLKS;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+
+  // XCD-aware block order: blocks that share an XCD (bid % 8) walk adjacent tiles, and the
+  // co-tiles of one pixel tile are adjacent, so the haloed input tile is fetched once per L2.
+  const unsigned bid = blockIdx.x, nwg = gridDim.x;
+  const unsigned xcd = bid & 7, q = nwg >> 3, rem = nwg & 7;
+  const unsigned L = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+  const int cot = L % p.n_co_tiles;
+  const int pt = L / p.n_co_tiles;
+  const int txi = pt % p.tiles_x;
+  const int tmp = pt / p.tiles_x;
+  const int tyi = tmp % p.tiles_y;
+  const int n = tmp / p.tiles_y;
+  const int TW = 1 << p.twl, TH = (128 * NPB) >> p.twl;
+  const int y0 = tyi * TH, x0 = txi * TW;
+
+  int oy0 = y0 * p.in_step + p.dy_min, ox0 = x0 * p.in_step + p.dx_min;
+  int th = p.ih_t, tw = p.iw_t;
+  if (CLAMP) {
+    const int y1 = min(oy0 + th, p.in_h), x1 = min(ox0 + tw, p.in_w);
+    oy0 = max(oy0, 0); ox0 = max(ox0, 0);
+    th = max(y1 - oy0, 0); tw = max(x1 - ox0, 0);
+  }
+  const int npix = th * tw;
+
+  unsigned char* Xhi = smem;
+  unsigned char* Xlo = smem + (size_t)x_cap * IG_REC_BYTES;
+  unsigned char* Whi = smem + (size_t)(X3 ? 2 : 1) * x_cap * IG_REC_BYTES;
+  unsigned char* Wlo = Whi + (size_t)p.tg * CO_TILE * IG_REC_BYTES;
+
+  // per-lane pixel of each MFMA column block
+  int pty[NPB], ptx[NPB], bbase[NPB];
+#pragma unroll
+  for (int pb = 0; pb < NPB; ++pb) {
+    const int pl = w * (32 * NPB) + pb * 32 + r;
+    pty[pb] = pl >> p.twl;
+    ptx[pb] = pl & (TW - 1);
+    bbase[pb] = ((pty[pb] * p.in_step) * tw + ptx[pb] * p.in_step) * IG_REC_BYTES + h * 16;
+  }
+
+  f32x16 acc[CO_BLKS][NPB];
+#pragma unroll
+  for (int cb = 0; cb < CO_BLKS; ++cb)
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[cb][pb][i] = 0.f;
+
+  for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+    const int cvalid = min(32, p.cin - chunk * 32);
+    const int nks = cvalid > 16 ? 2 : 1;
+    __syncthreads();   // every wave is done reading the previous chunk's X / W
+    stage_x_chunk<X3>(Xhi, Xlo, p.x, n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row, oy0, ox0, th, tw,
+                      nks * 2, tid);
+    if (CLAMP && tid < 5) {   // the all-zero record that out-of-image taps read
+      *(uint4*)(Xhi + (size_t)npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
+      if (X3) *(uint4*)(Xlo + (size_t)npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
+    }
+    for (int t0 = 0; t0 < p.ntaps; t0 += p.tg) {
+      if (t0 > 0) __syncthreads();
+      const int tgc = min(p.tg, p.ntaps - t0);
+      {
+        const long long slab = (long long)CO_TILE * IG_REC;   // bf16 elements per tap
+        const uint16_t* src = p.wpack + (((long long)cot * p.nchunks + chunk) * p.ntaps + t0) * slab;
+        const int nvec = tgc * CO_TILE * 5;                  // 16-B vectors
+        const uint4* s4 = (const uint4*)src;
+        for (int i = tid; i < nvec; i += 256) ((uint4*)Whi)[i] = s4[i];
+        if (X3) {
+          const uint4* l4 = (const uint4*)(src + p.w_lo_off);
+          for (int i = tid; i < nvec; i += 256) ((uint4*)Wlo)[i] = l4[i];
+        }
+      }
+      __syncthreads();
+      for (int tl = 0; tl < tgc; ++tl) {
+        const int t = t0 + tl;
+        int baddr[NPB];
+        if (CLAMP) {
+#pragma unroll
+          for (int pb = 0; pb < NPB; ++pb) {
+            const int gy = (y0 + pty[pb]) * p.in_step + p.dy[t];
+            const int gx = (x0 + ptx[pb]) * p.in_step + p.dx[t];
+            const bool ok = ((unsigned)gy < (unsigned)p.in_h) & ((unsigned)gx < (unsigned)p.in_w);
+            const int idx = ok ? (gy - oy0) * tw + (gx - ox0) : npix;
+            baddr[pb] = idx * IG_REC_BYTES + h * 16;
+          }
+        } else {
+          const int toff = ((p.dy[t] - p.dy_min) * tw + (p.dx[t] - p.dx_min)) * IG_REC_BYTES;
+#pragma unroll
+          for (int pb = 0; pb < NPB; ++pb) baddr[pb] = bbase[pb] + toff;
+        }
+        const int abase = (tl * CO_TILE + r) * IG_REC_BYTES + h * 16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          if (ks < nks) {
+            bf16x8 ah[CO_BLKS], al[CO_BLKS], bh[NPB], bl[NPB];
+#pragma unroll
+            for (int cb = 0; cb < CO_BLKS; ++cb) {
+              ah[cb] = lds_frag(Whi + abase + cb * 32 * IG_REC_BYTES + ks * 32);
+              if (X3) al[cb] = lds_frag(Wlo + abase + cb * 32 * IG_REC_BYTES + ks * 32);
+            }
+#pragma unroll
+            for (int pb = 0; pb < NPB; ++pb) {
+              bh[pb] = lds_frag(Xhi + baddr[pb] + ks * 32);
+              if (X3) bl[pb] = lds_frag(Xlo + baddr[pb] + ks * 32);
+            }
+#pragma unroll
+            for (int cb = 0; cb < CO_BLKS; ++cb)
+#pragma unroll
+              for (int pb = 0; pb < NPB; ++pb) {
+                if (X3) {
+                  acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cb], bh[pb], acc[cb][pb], 0, 0, 0);
+                  acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb], bl[pb], acc[cb][pb], 0, 0, 0);
+                }
+                acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb], bh[pb], acc[cb][pb], 0, 0, 0);
+              }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: bias + LeakyReLU, NCHW store (register i = one output channel, the 32 lanes of
+  // a half-wave = 32 consecutive pixels), optional per-tile BatchNorm partial sums.
+  __syncthreads();
+  float* sred = (float*)smem;   // [4 waves][CO_TILE][2]
+#pragma unroll
+  for (int cb = 0; cb < CO_BLKS; ++cb) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      const int co = cot * CO_TILE + row;
+      const bool cok = co < p.cout;
+      const float b = (cok && p.bias) ? p.bias[co] : 0.f;
+      float* plane = nullptr;
+      if (cok) {
+        plane = (co < p.y.c1) ? p.y.p1 + (long long)n * p.y.sn1 + (long long)co * p.y.sc1
+                              : p.y.p2 + (long long)n * p.y.sn2 + (long long)(co - p.y.c1) * p.y.sc2;
+      }
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int pb = 0; pb < NPB; ++pb) {
+        const int ly = y0 + pty[pb], lx = x0 + ptx[pb];
+        if (cok && ly < p.lh && lx < p.lw) {
+          float v = acc[cb][pb][i] + b;
+          v = v > 0.f ? v : v * p.slope;
+          float* dst = plane + (long long)(ly * p.oy_mul + p.oy_off) * p.out_w + (lx * p.ox_mul + p.ox_off);
+          if (p.accumulate) v += *dst;
+          *dst = v;
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+      if (p.stats) {
+        s1 = half_wave_sum(s1);
+        s2 = half_wave_sum(s2);
+        if (r == 0) {
+          sred[(w * CO_TILE + row) * 2 + 0] = s1;
+          sred[(w * CO_TILE + row) * 2 + 1] = s2;
+        }
+      }
+    }
+  }
+  if (p.stats) {
+    __syncthreads();
+    if (tid < CO_TILE) {
+      const int co = cot * CO_TILE + tid;
+      if (co < p.cout) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {   // fixed order: deterministic
+          s1 += sred[(ww * CO_TILE + tid) * 2 + 0];
+          s2 += sred[(ww * CO_TILE + tid) * 2 + 1];
+        }
+        p.stats[((long long)pt * p.cout + co) * 2 + 0] = s1;
+        p.stats[((long long)pt * p.cout + co) * 2 + 1] = s2;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// wgrad kernel.  Block = (co-tile, 32-channel chunk, tap group) x split-K slice; loops over its
+// 128-pixel tiles, keeping dW tiles [32 rows][32 ci] per tap in the accumulators.
+// ------------------------------------------------------------------------------------------
+#define WG_ZROW 272   // bytes per dZ row in LDS: 128 px bf16 + 16 pad (17*16: conflict-free b128)
+
+__device__ __forceinline__ bf16x8 lds_tr_frag(const unsigned char* p0, const unsigned char* p1) {
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)p0);
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)p1);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <bool X3, int CO_BLKS>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const int x_cap, float* db_partial) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int CO_TILE = 32 * CO_BLKS;
+  constexpr int NWT = 4 / CO_BLKS;             // waves sharing one row block
+  constexpr int MAXT = CO_BLKS == 2 ? 5 : 3;   // taps per wave (block handles <= 9 taps)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+
+  const int bx = blockIdx.x;
+  const int tgidx = bx % p.tap_groups;
+  const int chunk = (bx / p.tap_groups) % p.n_chunks;
+  const int cot = bx / (p.tap_groups * p.n_chunks);
+  const int kslice = blockIdx.y;
+  const int t_begin = tgidx * p.ntaps;
+  const int tcount = min(p.ntaps, p.ntaps_total - t_begin);
+  const int cb = w % CO_BLKS, wsub = w / CO_BLKS;
+  const int share = (tcount + NWT - 1) / NWT;
+  const int my_t0 = t_begin + wsub * share;
+  const int my_cnt = max(0, min(share, tcount - wsub * share));
+
+  unsigned char* Xhi = smem;
+  unsigned char* Xlo = smem + (size_t)x_cap * IG_REC_BYTES;
+  unsigned char* Zhi = smem + (size_t)(X3 ? 2 : 1) * x_cap * IG_REC_BYTES;
+  unsigned char* Zlo = Zhi + (size_t)CO_TILE * WG_ZROW;
+
+  const int TW = 1 << p.twl, TH = 128 >> p.twl;
+  const int ntiles = p.n * p.tiles_y * p.tiles_x;
+  const int tile_lo = (int)((long long)kslice * ntiles / p.ksplit);
+  const int tile_hi = (int)((long long)(kslice + 1) * ntiles / p.ksplit);
+  const bool do_db = (db_partial != nullptr) && chunk == 0 && tgidx == 0;
+
+  f32x16 acc[MAXT];
+#pragma unroll
+  for (int ti = 0; ti < MAXT; ++ti)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[ti][i] = 0.f;
+  float dbacc[CO_TILE / 16];
+#pragma unroll
+  for (int j = 0; j < CO_TILE / 16; ++j) dbacc[j] = 0.f;
+
+  // transposed-read lane roles: 16-lane group g -> k half (g>>1), column block (g&1)
+  const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  const int cvalid = min(32, p.cin - chunk * 32);
+  (void)cvalid;
+
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    const int txi = tile % p.tiles_x;
+    const int tmp = tile / p.tiles_x;
+    const int tyi = tmp % p.tiles_y;
+    const int n = tmp / p.tiles_y;
+    const int y0 = tyi * TH, x0 = txi * TW;
+    __syncthreads();
+    stage_x_chunk<X3>(Xhi, Xlo, p.x, n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row,
+                      y0 * p.stride + p.dy_min, x0 * p.stride + p.dx_min, p.ih_t, p.iw_t, 4, tid);
+    // dZ tile [CO_TILE][128 px] in natural (pixel-contiguous) order
+#pragma unroll
+    for (int j = 0; j < CO_TILE / 16; ++j) {
+      const int item = tid + 256 * j;
+      const int row = item >> 4, oct = item & 15;
+      const int co = cot * CO_TILE + row;
+      const int pl = oct * 8;
+      const int ty = pl >> p.twl, tx = pl & (TW - 1);
+      const int oy = y0 + ty, ox = x0 + tx;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      if (co < p.cout && oy < p.out_h) {
+        const float* src = p.dz + (long long)n * p.dz_sn + (long long)co * p.dz_sc + (long long)oy * p.out_w + ox;
+        if (p.aligned4 && ox + 8 <= p.out_w) {
+          const float4 a = *(const float4*)src, b = *(const float4*)(src + 4);
+          v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (ox + e < p.out_w) v[e] = src[e];
+        }
+      }
+      if (do_db) dbacc[j] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+      uint4 hi, lo;
+      if (X3) {
+        split2(v[0], v[1], hi.x, lo.x); split2(v[2], v[3], hi.y, lo.y);
+        split2(v[4], v[5], hi.z, lo.z); split2(v[6], v[7], hi.w, lo.w);
+        *(uint4*)(Zlo + row * WG_ZROW + oct * 16) = lo;
+      } else {
+        hi.x = pack_bf16x2(v[0], v[1]); hi.y = pack_bf16x2(v[2], v[3]);
+        hi.z = pack_bf16x2(v[4], v[5]); hi.w = pack_bf16x2(v[6], v[7]);
+      }
+      *(uint4*)(Zhi + row * WG_ZROW + oct * 16) = hi;
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int ks = 0; ks < 8; ++ks) {
+      const int aoff = (cb * 32 + r) * WG_ZROW + ks * 32 + h * 16;
+      const bf16x8 ah = lds_frag(Zhi + aoff);
+      bf16x8 al;
+      if (X3) al = lds_frag(Zlo + aoff);
+      int rowb[2];
+#pragma unroll
+      for (int sel = 0; sel < 2; ++sel) {
+        const int pl = ks * 16 + 8 * (g >> 1) + 4 * sel + tq;
+        const int ty = pl >> p.twl, tx = pl & (TW - 1);
+        rowb[sel] = ((ty * p.stride) * p.iw_t + tx * p.stride) * IG_REC_BYTES + ((g & 1) * 16 + 4 * tp) * 2;
+      }
+#pragma unroll
+      for (int ti = 0; ti < MAXT; ++ti) {
+        if (ti < my_cnt) {   // wave-uniform: EXEC stays all ones for the transposed reads
+          const int t = my_t0 + ti;
+          const int toff = ((p.dy[t] - p.dy_min) * p.iw_t + (p.dx[t] - p.dx_min)) * IG_REC_BYTES;
+          const bf16x8 bh = lds_tr_frag(Xhi + rowb[0] + toff, Xhi + rowb[1] + toff);
+          if (X3) {
+            const bf16x8 bl = lds_tr_frag(Xlo + rowb[0] + toff, Xlo + rowb[1] + toff);
+            acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[ti], 0, 0, 0);
+            acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[ti], 0, 0, 0);
+          }
+          acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[ti], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // partial slabs: partial[kslice][co][ci][tap]
+#pragma unroll
+  for (int ti = 0; ti < MAXT; ++ti) {
+    if (ti < my_cnt) {
+      const int t = my_t0 + ti;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int co = cot * CO_TILE + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        const int ci = chunk * 32 + r;
+        if (co < p.cout && ci < p.cin)
+          p.partial[(((long long)kslice * p.cout + co) * p.cin + ci) * p.ntaps_total + t] = acc[ti][i];
+      }
+    }
+  }
+  if (do_db) {
+#pragma unroll
+    for (int j = 0; j < CO_TILE / 16; ++j) {
+      float s = dbacc[j];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      const int row = (tid + 256 * j) >> 4;
+      const int co = cot * CO_TILE + row;
+      if ((tid & 15) == 0 && co < p.cout) db_partial[(long long)kslice * p.cout + co] = s;
+    }
+  }
+}
+
+// dw[i] (+)= sum_k partial[k][i]  (fixed order)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, long long numel, int ksplit,
+                                    float* __restrict__ dw, int accumulate) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < numel;
+       i += (long long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < ksplit; ++k) s += partial[(long long)k * numel + i];
+    dw[i] = accumulate ? dw[i] + s : s;
+  }
+}
+
+// ==========================================================================================
+// host side
+// ==========================================================================================
+namespace {
+
+const int LDS_HARD = 160 * 1024;
+
+bool geom_ok(const pcuda_conv_geom* g) {
+  if (!g || g->n <= 0 || g->cin <= 0 || g->cout <= 0 || g->k <= 0 || g->stride <= 0 || g->dil <= 0 || g->pad < 0)
+    return false;
+  if (g->k * g->k > IG_MAX_TAPS) return false;
+  const int oh = (g->in_h + 2 * g->pad - g->dil * (g->k - 1) - 1) / g->stride + 1;
+  const int ow = (g->in_w + 2 * g->pad - g->dil * (g->k - 1) - 1) / g->stride + 1;
+  if (oh != g->out_h || ow != g->out_w || oh <= 0 || ow <= 0) return false;
+  if (g->in_up && ((g->in_h & 1) || (g->in_w & 1))) return false;
+  return true;
+}
+
+bool src_ok(const pcuda_src* s, int c) {
+  if (!s || !s->p1 || s->c1 <= 0 || s->c1 > c) return false;
+  if (s->c1 < c && !s->p2) return false;
+  return true;
+}
+bool dst_ok(const pcuda_dst* d, int c) {
+  if (!d || !d->p1 || d->c1 <= 0 || d->c1 > c) return false;
+  if (d->c1 < c && !d->p2) return false;
+  return true;
+}
+
+struct TapSet {
+  int n;
+  signed char dy[IG_MAX_TAPS], dx[IG_MAX_TAPS], src[IG_MAX_TAPS];
+  int dy_min, dy_max, dx_min, dx_max;
+  void finish() {
+    dy_min = dx_min = 127; dy_max = dx_max = -127;
+    for (int i = 0; i < n; ++i) {
+      if (dy[i] < dy_min) dy_min = dy[i];
+      if (dy[i] > dy_max) dy_max = dy[i];
+      if (dx[i] < dx_min) dx_min = dx[i];
+      if (dx[i] > dx_max) dx_max = dx[i];
+    }
+    if (n == 0) dy_min = dy_max = dx_min = dx_max = 0;
+  }
+};
+
+TapSet fwd_taps(const pcuda_conv_geom* g) {
+  TapSet t; t.n = 0;
+  for (int ky = 0; ky < g->k; ++ky)
+    for (int kx = 0; kx < g->k; ++kx) {
+      t.dy[t.n] = (signed char)(ky * g->dil - g->pad);
+      t.dx[t.n] = (signed char)(kx * g->dil - g->pad);
+      t.src[t.n] = (signed char)(ky * g->k + kx);
+      ++t.n;
+    }
+  t.finish();
+  return t;
+}
+
+inline int posmod(int a, int m) { return ((a % m) + m) % m; }
+
+// taps of the dgrad parity class (ry, rx): dX[s*m + ry] = sum_ky dY[m + (ry + pad - ky*dil)/s] w[ky]
+TapSet dgrad_taps(const pcuda_conv_geom* g, int ry, int rx) {
+  TapSet t; t.n = 0;
+  const int s = g->stride;
+  for (int ky = 0; ky < g->k; ++ky) {
+    const int vy = ry + g->pad - ky * g->dil;
+    if (posmod(vy, s) != 0) continue;
+    for (int kx = 0; kx < g->k; ++kx) {
+      const int vx = rx + g->pad - kx * g->dil;
+      if (posmod(vx, s) != 0) continue;
+      t.dy[t.n] = (signed char)(vy / s);
+      t.dx[t.n] = (signed char)(vx / s);
+      t.src[t.n] = (signed char)(ky * g->k + kx);
+      ++t.n;
+    }
+  }
+  t.finish();
+  return t;
+}
+
+size_t packed_elems(int rows, int red, int ntaps) {   // bf16 elements of ONE plane (hi)
+  const int co_tile = 32 * ig_co_blks(rows);
+  const int n_co_tiles = cdiv(rows, co_tile), nchunks = cdiv(red, 32);
+  return (size_t)n_co_tiles * nchunks * ntaps * co_tile * IG_REC;
+}
+
+int launch_pack(const float* w, uint16_t* out, int prec, int rows, int red, long long s_row, long long s_red,
+                const TapSet& taps, hipStream_t s) {
+  if (taps.n == 0) return PCUDA_OK;
+  PackParams p;
+  p.w = w; p.out = out;
+  p.rows = rows; p.red = red; p.s_row = s_row; p.s_red = s_red;
+  p.ntaps = taps.n;
+  memcpy(p.tap_src, taps.src, sizeof(p.tap_src));
+  p.co_tile = 32 * ig_co_blks(rows);
+  p.n_co_tiles = cdiv(rows, p.co_tile);
+  p.nchunks = cdiv(red, 32);
+  const size_t plane = packed_elems(rows, red, taps.n);
+  p.lo_off = prec == PCUDA_PREC_BF16X3 ? (long long)plane : 0;
+  const int blocks = (int)((plane + 255) / 256 > 4096 ? 4096 : (plane + 255) / 256);
+  hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, s, p);
+  PCUDA_CHECK_LAUNCH("pack_kernel");
+  return PCUDA_OK;
+}
+
+// pick taps-per-group and LDS size; returns <0 when nothing fits
+int plan_lds(bool x3, int co_tile, int x_cap, int ntaps, int* tg_out, size_t* lds_out) {
+  const size_t mul = x3 ? 2 : 1;
+  const size_t xb = (size_t)x_cap * IG_REC_BYTES * mul;
+  const size_t wtap = (size_t)co_tile * IG_REC_BYTES * mul;
+  const size_t epi = 4 * (size_t)co_tile * 2 * sizeof(float);
+  if (ntaps < 1) ntaps = 1;
+  // budgets: 3, 2, 1 workgroups per CU (160 KiB LDS)
+  const size_t budgets[3] = {54528, 81920, 163840};
+  for (int b = 0; b < 3; ++b) {
+    if (xb >= budgets[b]) continue;
+    const int fit = (int)((budgets[b] - xb) / wtap);
+    const int need = b == 0 ? (ntaps < 3 ? ntaps : 3) : 1;
+    if (fit < need) continue;
+    const int tg = fit > ntaps ? ntaps : fit;
+    size_t total = xb + (size_t)tg * wtap;
+    if (total < epi) total = epi;
+    *tg_out = tg; *lds_out = total;
+    return 0;
+  }
+  return -1;
+}
+
+struct IgemmPlan {
+  int npb, twl, tiles_x, tiles_y, ih_t, iw_t, clamp, x_cap, tg;
+  size_t lds;
+};
+
+// tile shape / LDS plan of one generic launch: depends only on geometry, taps and precision
+int plan_igemm(int rows, int lh, int lw, int in_h, int in_w, int in_step, const TapSet& taps, bool x3,
+               IgemmPlan* pl) {
+  const int co_tile = 32 * ig_co_blks(rows);
+  for (int npb = 2; npb >= 1; --npb) {
+    pl->twl = ig_twl(lw, lh, 128 * npb);
+    const int TW = 1 << pl->twl;
+    const int TH = (128 * npb) >> pl->twl;
+    if (TH < 1) continue;
+    pl->npb = npb;
+    pl->tiles_x = cdiv(lw, TW);
+    pl->tiles_y = cdiv(lh, TH);
+    pl->ih_t = (TH - 1) * in_step + (taps.dy_max - taps.dy_min) + 1;
+    pl->iw_t = (TW - 1) * in_step + (taps.dx_max - taps.dx_min) + 1;
+    const int full = pl->ih_t * pl->iw_t;
+    const int clipped = (pl->ih_t < in_h ? pl->ih_t : in_h) * (pl->iw_t < in_w ? pl->iw_t : in_w) + 1;
+    // clamp mode pays ~10 VALU per tap and lane; use it when the halo is mostly padding
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      pl->clamp = attempt == 0 ? ((clipped * 2 <= full) ? 1 : 0) : 1;
+      pl->x_cap = pl->clamp ? clipped : full;
+      if (plan_lds(x3, co_tile, pl->x_cap, taps.n, &pl->tg, &pl->lds) == 0) return 0;
+      if (pl->clamp) break;
+    }
+  }
+  return -1;
+}
+
+template <bool X3, int CO_BLKS, bool CLAMP, int NPB>
+int launch_igemm_t(const IgemmParams& p, int x_cap, size_t lds, hipStream_t s) {
+  auto kern = igemm_kernel<X3, CO_BLKS, CLAMP, NPB>;
+  static size_t lds_set = 0;
+  if (lds > 32 * 1024 && lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HARD);
+    if (e != hipSuccess) PCUDA_FAIL(PCUDA_E_LAUNCH, "igemm: cannot raise dynamic LDS to %d: %s", LDS_HARD, hipGetErrorString(e));
+    lds_set = LDS_HARD;
+  }
+  const int grid = p.n_co_tiles * p.n * p.tiles_x * p.tiles_y;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, p, x_cap);
+  PCUDA_CHECK_LAUNCH("igemm_kernel");
+  return PCUDA_OK;
+}
+
+template <bool X3, int CO_BLKS>
+int launch_igemm_c(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
+  if (pl.clamp) return pl.npb == 2 ? launch_igemm_t<X3, CO_BLKS, true, 2>(p, pl.x_cap, pl.lds, s)
+                                   : launch_igemm_t<X3, CO_BLKS, true, 1>(p, pl.x_cap, pl.lds, s);
+  return pl.npb == 2 ? launch_igemm_t<X3, CO_BLKS, false, 2>(p, pl.x_cap, pl.lds, s)
+                     : launch_igemm_t<X3, CO_BLKS, false, 1>(p, pl.x_cap, pl.lds, s);
+}
+
+int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
+  const bool x3 = prec == PCUDA_PREC_BF16X3;
+  const int co_blks = ig_co_blks(p.cout);
+  const int co_tile = 32 * co_blks;
+  IgemmPlan pl;
+  if (plan_igemm(p.cout, p.lh, p.lw, p.in_h, p.in_w, p.in_step, taps, x3, &pl) < 0)
+    PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "igemm: no tile of this convolution fits LDS (in_step %d, tap span %d)",
+               p.in_step, taps.dy_max - taps.dy_min);
+  p.n_co_tiles = cdiv(p.cout, co_tile);
+  p.nchunks = cdiv(p.cin, 32);
+  p.twl = pl.twl; p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y;
+  p.ntaps = taps.n;
+  memcpy(p.dy, taps.dy, sizeof(p.dy));
+  memcpy(p.dx, taps.dx, sizeof(p.dx));
+  p.dy_min = taps.dy_min; p.dx_min = taps.dx_min;
+  p.ih_t = pl.ih_t; p.iw_t = pl.iw_t; p.clamp = pl.clamp; p.tg = pl.tg;
+  const double flops = 2.0 * p.n * (double)p.lh * p.lw * p.cout * (double)p.cin * taps.n;
+  ProfScope prof(PCUDA_FAM_CONV_FWD, flops, s);
+  if (x3) return co_blks == 2 ? launch_igemm_c<true, 2>(p, pl, s) : launch_igemm_c<true, 1>(p, pl, s);
+  return co_blks == 2 ? launch_igemm_c<false, 2>(p, pl, s) : launch_igemm_c<false, 1>(p, pl, s);
+}
+
+struct WgradPlan {
+  int co_blks, co_tile, n_co_tiles, n_chunks, tap_groups, taps_per_group, twl, tiles_x, tiles_y, ksplit;
+  int ih_t, iw_t;
+};
+
+WgradPlan plan_wgrad(const pcuda_conv_geom* g) {
+  WgradPlan w;
+  w.co_blks = ig_co_blks(g->cout);
+  w.co_tile = 32 * w.co_blks;
+  w.n_co_tiles = cdiv(g->cout, w.co_tile);
+  w.n_chunks = cdiv(g->cin, 32);
+  const int ntaps = g->k * g->k;
+  w.tap_groups = cdiv(ntaps, 9);
+  w.taps_per_group = cdiv(ntaps, w.tap_groups);
+  w.twl = ig_twl(g->out_w, g->out_h, 128);
+  const int TW = 1 << w.twl, TH = 128 >> w.twl;
+  w.tiles_x = cdiv(g->out_w, TW);
+  w.tiles_y = cdiv(g->out_h, TH);
+  const int span = (g->k - 1) * g->dil;
+  w.ih_t = (TH - 1) * g->stride + span + 1;
+  w.iw_t = (TW - 1) * g->stride + span + 1;
+  const long long ntiles = (long long)g->n * w.tiles_x * w.tiles_y;
+  const int base = w.n_co_tiles * w.n_chunks * w.tap_groups;
+  long long ks = 1024 / base;
+  if (ks < 1) ks = 1;
+  if (ks > ntiles) ks = ntiles;
+  // keep the partial slabs below ~64 MB
+  const long long welems = (long long)g->cout * g->cin * ntaps;
+  while (ks > 1 && ks * welems * 4 > (64ll << 20)) ks >>= 1;
+  w.ksplit = (int)ks;
+  return w;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+extern "C" size_t pcuda_conv2d_packed_fwd_bytes(const pcuda_conv_geom* g, int prec) {
+  if (!geom_ok(g)) return 0;
+  return packed_elems(g->cout, g->cin, g->k * g->k) * 2 * (prec == PCUDA_PREC_BF16X3 ? 2 : 1);
+}
+
+extern "C" size_t pcuda_conv2d_packed_dgrad_bytes(const pcuda_conv_geom* g, int prec) {
+  if (!geom_ok(g)) return 0;
+  size_t tot = 0;
+  for (int ry = 0; ry < g->stride; ++ry)
+    for (int rx = 0; rx < g->stride; ++rx) {
+      TapSet t = dgrad_taps(g, ry, rx);
+      tot += packed_elems(g->cin, g->cout, t.n) * 2 * (prec == PCUDA_PREC_BF16X3 ? 2 : 1);
+    }
+  return tot;
+}
+
+extern "C" int pcuda_conv2d_pack_fwd(const pcuda_conv_geom* g, int prec, const float* w, void* packed,
+                                     pcuda_stream_t s) {
+  if (!geom_ok(g) || !w || !packed) PCUDA_FAIL(PCUDA_E_BADARG, "pack_fwd: bad geometry or null pointer");
+  const int kk = g->k * g->k;
+  TapSet t = fwd_taps(g);
+  return launch_pack(w, (uint16_t*)packed, prec, g->cout, g->cin, (long long)g->cin * kk, kk, t, (hipStream_t)s);
+}
+
+extern "C" int pcuda_conv2d_pack_dgrad(const pcuda_conv_geom* g, int prec, const float* w, void* packed,
+                                       pcuda_stream_t s) {
+  if (!geom_ok(g) || !w || !packed) PCUDA_FAIL(PCUDA_E_BADARG, "pack_dgrad: bad geometry or null pointer");
+  const int kk = g->k * g->k;
+  uint16_t* out = (uint16_t*)packed;
+  for (int ry = 0; ry < g->stride; ++ry)
+    for (int rx = 0; rx < g->stride; ++rx) {
+      TapSet t = dgrad_taps(g, ry, rx);
+      int rc = launch_pack(w, out, prec, g->cin, g->cout, kk, (long long)g->cin * kk, t, (hipStream_t)s);
+      if (rc) return rc;
+      out += packed_elems(g->cin, g->cout, t.n) * (prec == PCUDA_PREC_BF16X3 ? 2 : 1);
+    }
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_conv2d_fwd_tiles(const pcuda_conv_geom* g, int prec) {
+  if (!geom_ok(g)) return 0;
+  TapSet t = fwd_taps(g);
+  IgemmPlan pl;
+  if (plan_igemm(g->cout, g->out_h, g->out_w, g->in_h, g->in_w, g->stride, t, prec == PCUDA_PREC_BF16X3, &pl) < 0)
+    return 0;
+  return g->n * pl.tiles_x * pl.tiles_y;
+}
+
+extern "C" int pcuda_conv2d_forward(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const void* packed_w,
+                                    const float* bias, float slope, const pcuda_dst* y, float* bn_partials,
+                                    pcuda_stream_t s) {
+  if (!geom_ok(g)) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_forward: inconsistent geometry");
+  if (!src_ok(x, g->cin) || !dst_ok(y, g->cout) || !packed_w) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_forward: bad tensors");
+  if (prec != PCUDA_PREC_BF16X3 && prec != PCUDA_PREC_BF16) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_forward: bad precision");
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = *x; p.cin = g->cin;
+  p.in_h = g->in_h; p.in_w = g->in_w; p.in_shift = g->in_up ? 1 : 0; p.in_row = g->in_w >> p.in_shift;
+  p.y = *y; p.cout = g->cout; p.out_w = g->out_w;
+  p.lh = g->out_h; p.lw = g->out_w;
+  p.oy_mul = p.ox_mul = 1; p.oy_off = p.ox_off = 0;
+  p.in_step = g->stride;
+  p.wpack = (const uint16_t*)packed_w;
+  p.w_lo_off = (long long)packed_elems(g->cout, g->cin, g->k * g->k);
+  p.bias = bias; p.slope = slope; p.accumulate = 0; p.stats = bn_partials;
+  p.n = g->n;
+  TapSet t = fwd_taps(g);
+  return launch_igemm(p, prec, t, (hipStream_t)s);
+}
+
+extern "C" int pcuda_conv2d_dgrad(const pcuda_conv_geom* g, int prec, const pcuda_src* dy, const void* packed_w_dgrad,
+                                  const pcuda_dst* dx, int accumulate, pcuda_stream_t s) {
+  if (!geom_ok(g)) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_dgrad: inconsistent geometry");
+  if (!src_ok(dy, g->cout) || !dst_ok(dx, g->cin) || !packed_w_dgrad) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_dgrad: bad tensors");
+  if (prec != PCUDA_PREC_BF16X3 && prec != PCUDA_PREC_BF16) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_dgrad: bad precision");
+  const uint16_t* wp = (const uint16_t*)packed_w_dgrad;
+  const int st = g->stride;
+  for (int ry = 0; ry < st; ++ry)
+    for (int rx = 0; rx < st; ++rx) {
+      TapSet t = dgrad_taps(g, ry, rx);
+      const size_t plane = packed_elems(g->cin, g->cout, t.n);
+      const int lh = (g->in_h - ry + st - 1) / st, lw = (g->in_w - rx + st - 1) / st;
+      if (lh > 0 && lw > 0) {
+        IgemmParams p;
+        memset(&p, 0, sizeof(p));
+        p.x = *dy; p.cin = g->cout;
+        p.in_h = g->out_h; p.in_w = g->out_w; p.in_shift = 0; p.in_row = g->out_w;
+        p.y = *dx; p.cout = g->cin; p.out_w = g->in_w;
+        p.lh = lh; p.lw = lw;
+        p.oy_mul = p.ox_mul = st; p.oy_off = ry; p.ox_off = rx;
+        p.in_step = 1;
+        p.wpack = wp; p.w_lo_off = (long long)plane;
+        p.bias = nullptr; p.slope = 1.f; p.accumulate = accumulate; p.stats = nullptr;
+        p.n = g->n;
+        int rc = launch_igemm(p, prec, t, (hipStream_t)s);
+        if (rc) return rc;
+      }
+      wp += plane * (prec == PCUDA_PREC_BF16X3 ? 2 : 1);
+    }
+  return PCUDA_OK;
+}
+
+extern "C" size_t pcuda_conv2d_wgrad_workspace_size(const pcuda_conv_geom* g) {
+  if (!geom_ok(g)) return 0;
+  WgradPlan w = plan_wgrad(g);
+  return ((size_t)w.ksplit * g->cout * g->cin * g->k * g->k + (size_t)w.ksplit * g->cout) * sizeof(float) + 256;
+}
+
+template <bool X3, int CO_BLKS>
+static int launch_wgrad_t(const WgradParams& p, int x_cap, size_t lds, float* dbp, dim3 grid, hipStream_t s) {
+  auto kern = wgrad_kernel<X3, CO_BLKS>;
+  static size_t lds_set = 0;
+  if (lds > 32 * 1024 && lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HARD);
+    if (e != hipSuccess) PCUDA_FAIL(PCUDA_E_LAUNCH, "wgrad: cannot raise dynamic LDS: %s", hipGetErrorString(e));
+    lds_set = LDS_HARD;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p, x_cap, dbp);
+  PCUDA_CHECK_LAUNCH("wgrad_kernel");
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_conv2d_wgrad(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const float* dy,
+                                  long long dy_sn, long long dy_sc, float* dw, float* db, int accumulate,
+                                  void* workspace, size_t workspace_bytes, pcuda_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (!geom_ok(g)) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_wgrad: inconsistent geometry");
+  if (!src_ok(x, g->cin) || !dy || !dw) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_wgrad: bad tensors");
+  if (prec != PCUDA_PREC_BF16X3 && prec != PCUDA_PREC_BF16) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_wgrad: bad precision");
+  if (!workspace || workspace_bytes < pcuda_conv2d_wgrad_workspace_size(g))
+    PCUDA_FAIL(PCUDA_E_WORKSPACE, "conv2d_wgrad: workspace too small (%zu < %zu)", workspace_bytes,
+               pcuda_conv2d_wgrad_workspace_size(g));
+  const bool x3 = prec == PCUDA_PREC_BF16X3;
+  WgradPlan w = plan_wgrad(g);
+  TapSet t = fwd_taps(g);
+  WgradParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = *x; p.cin = g->cin;
+  p.in_h = g->in_h; p.in_w = g->in_w; p.in_shift = g->in_up ? 1 : 0; p.in_row = g->in_w >> p.in_shift;
+  p.dz = dy; p.dz_sn = dy_sn; p.dz_sc = dy_sc;
+  p.cout = g->cout; p.out_h = g->out_h; p.out_w = g->out_w;
+  p.stride = g->stride;
+  p.ntaps = w.taps_per_group; p.ntaps_total = t.n; p.tap_groups = w.tap_groups;
+  memcpy(p.dy, t.dy, sizeof(p.dy));
+  memcpy(p.dx, t.dx, sizeof(p.dx));
+  p.dy_min = t.dy_min; p.dx_min = t.dx_min;
+  p.ih_t = w.ih_t; p.iw_t = w.iw_t;
+  p.twl = w.twl; p.tiles_x = w.tiles_x; p.tiles_y = w.tiles_y; p.n = g->n;
+  p.ksplit = w.ksplit; p.n_co_tiles = w.n_co_tiles; p.n_chunks = w.n_chunks;
+  p.partial = (float*)workspace;
+  p.aligned4 = ((g->out_w & 3) == 0 && (dy_sn & 3) == 0 && (dy_sc & 3) == 0 && (((uintptr_t)dy) & 15) == 0) ? 1 : 0;
+  const long long welems = (long long)g->cout * g->cin * t.n;
+  float* dbp = db ? (float*)workspace + (size_t)w.ksplit * welems : nullptr;
+
+  const int x_cap = w.ih_t * w.iw_t;
+  const size_t mul = x3 ? 2 : 1;
+  const size_t lds = (size_t)x_cap * IG_REC_BYTES * mul + (size_t)w.co_tile * WG_ZROW * mul;
+  if (lds > (size_t)LDS_HARD) PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv2d_wgrad: tile %dx%d does not fit LDS", w.ih_t, w.iw_t);
+  const dim3 grid(w.n_co_tiles * w.n_chunks * w.tap_groups, w.ksplit);
+  {
+    const double flops = 2.0 * g->n * (double)g->out_h * g->out_w * g->cout * (double)g->cin * t.n;
+    ProfScope prof(PCUDA_FAM_CONV_WGRAD, flops, s);
+    int rc;
+    if (x3) rc = w.co_blks == 2 ? launch_wgrad_t<true, 2>(p, x_cap, lds, dbp, grid, s) : launch_wgrad_t<true, 1>(p, x_cap, lds, dbp, grid, s);
+    else rc = w.co_blks == 2 ? launch_wgrad_t<false, 2>(p, x_cap, lds, dbp, grid, s) : launch_wgrad_t<false, 1>(p, x_cap, lds, dbp, grid, s);
+    if (rc) return rc;
+  }
+  {
+    const int blocks = (int)((welems + 255) / 256 > 2048 ? 2048 : (welems + 255) / 256);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, welems,
+                       w.ksplit, dw, accumulate);
+    PCUDA_CHECK_LAUNCH("wgrad_reduce_kernel");
+    if (db) {
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(g->cout, 256)), dim3(256), 0, s, (const float*)dbp,
+                         (long long)g->cout, w.ksplit, db, accumulate);
+      PCUDA_CHECK_LAUNCH("wgrad_reduce_kernel(db)");
+    }
+  }
+  return PCUDA_OK;
+}

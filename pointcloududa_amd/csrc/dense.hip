@@ -1,0 +1,165 @@
+// Small dense ops of the point-cloud discriminator and the point head (PointNetCls.py:38-63,
+// 135-168, 204-214; unet.py:86,94-95): nn.Linear forward/backward, the 3x3 / 64x64 bmm's and the
+// max over points.  These are launch-latency bound (<= 0.6 GFLOP per sample in total), so one
+// generic fp32 LDS-tiled strided GEMM serves all of them; the k=1 Conv1d layers go through the
+// MFMA convolution kernels instead (a [B,C,L] tensor is an NCHW image with H = 1).
+#include "common.h"
+
+// C[b][i][j] (+)= sum_l A[b](i,l) * B[b](l,j) + bias[j]   with arbitrary element strides
+struct GemmParams {
+  const float* a; long long a_sb, a_si, a_sl;
+  const float* b; long long b_sb, b_sl, b_sj;
+  float* c; long long c_sb, c_si, c_sj;
+  const float* bias;   // per j, may be NULL
+  int m, n, k, accumulate;
+};
+
+#define GT 32
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+  __shared__ float As[GT][GT + 1], Bs[GT][GT + 1];
+  const int bz = blockIdx.z;
+  const float* A = p.a + bz * p.a_sb;
+  const float* B = p.b + bz * p.b_sb;
+  float* C = p.c + bz * p.c_sb;
+  const int i0 = blockIdx.y * GT, j0 = blockIdx.x * GT;
+  const int tj = threadIdx.x & 31, ti = threadIdx.x >> 5;   // 32 x 8 threads, 4 rows each
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int l0 = 0; l0 < p.k; l0 += GT) {
+    for (int e = threadIdx.x; e < GT * GT; e += 256) {
+      const int r = e >> 5, cc = e & 31;
+      // A tile [i][l]; pick the faster-varying index along the unit-stride axis of A
+      int ia, la;
+      if (p.a_sl == 1) { ia = r; la = cc; } else { ia = cc; la = r; }
+      As[ia][la] = (i0 + ia < p.m && l0 + la < p.k) ? A[(i0 + ia) * p.a_si + (l0 + la) * p.a_sl] : 0.f;
+      int lb, jb;
+      if (p.b_sj == 1) { lb = r; jb = cc; } else { lb = cc; jb = r; }
+      Bs[lb][jb] = (l0 + lb < p.k && j0 + jb < p.n) ? B[(l0 + lb) * p.b_sl + (j0 + jb) * p.b_sj] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int l = 0; l < GT; ++l) {
+      const float bv = Bs[l][tj];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] += As[ti * 4 + q][l] * bv;
+    }
+    __syncthreads();
+  }
+  const int j = j0 + tj;
+  if (j < p.n) {
+    const float bj = p.bias ? p.bias[j] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = i0 + ti * 4 + q;
+      if (i < p.m) {
+        float* dst = C + i * p.c_si + j * p.c_sj;
+        const float v = acc[q] + bj;
+        *dst = p.accumulate ? *dst + v : v;
+      }
+    }
+  }
+}
+
+// column sums: db[j] (+)= sum_i dy[i][j]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dy, int m, int n, float* db,
+                                                     int accumulate) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  float s = 0.f;
+  for (int i = 0; i < m; ++i) s += dy[(long long)i * n + j];
+  db[j] = accumulate ? db[j] + s : s;
+}
+
+// one wave per (b, c) row of x[b][c][l]
+__global__ __launch_bounds__(256) void max_points_fwd_kernel(const float* __restrict__ x, int rows, int l,
+                                                             float* __restrict__ y, int* __restrict__ idx) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* p = x + (long long)row * l;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = lane; i < l; i += 64) {
+    const float v = p[i];
+    if (v > best) { best = v; bi = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) { y[row] = best; idx[row] = bi; }
+}
+
+__global__ __launch_bounds__(256) void max_points_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ idx,
+                                                             int rows, int l, float* __restrict__ dx) {
+  const long long total = (long long)rows * l;
+  for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += 256ll * gridDim.x) {
+    const int row = (int)(e / l), i = (int)(e - (long long)row * l);
+    dx[e] = (idx[row] == i) ? dy[row] : 0.f;
+  }
+}
+
+namespace {
+int launch_gemm(const GemmParams& p, int batch, hipStream_t s) {
+  if (p.m <= 0 || p.n <= 0 || p.k <= 0 || batch <= 0) PCUDA_FAIL(PCUDA_E_BADARG, "gemm: bad dims");
+  dim3 grid(cdiv(p.n, GT), cdiv(p.m, GT), batch);
+  hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, s, p);
+  PCUDA_CHECK_LAUNCH("gemm_kernel");
+  return PCUDA_OK;
+}
+}  // namespace
+
+extern "C" int pcuda_linear_fwd(const float* x, const float* w, const float* b, float* y, int m, int k, int n,
+                                pcuda_stream_t s) {
+  if (!x || !w || !y) PCUDA_FAIL(PCUDA_E_BADARG, "linear_fwd: null pointer");
+  GemmParams p = {x, 0, k, 1, w, 0, 1, k, y, 0, n, 1, b, m, n, k, 0};   // y[i][j] = sum_l x[i][l] w[j][l]
+  return launch_gemm(p, 1, (hipStream_t)s);
+}
+
+extern "C" int pcuda_linear_bwd_x(const float* dy, const float* w, float* dx, int m, int k, int n, int accumulate,
+                                  pcuda_stream_t s) {
+  if (!dy || !w || !dx) PCUDA_FAIL(PCUDA_E_BADARG, "linear_bwd_x: null pointer");
+  GemmParams p = {dy, 0, n, 1, w, 0, k, 1, dx, 0, k, 1, nullptr, m, k, n, accumulate};   // dx[i][c] = sum_j dy[i][j] w[j][c]
+  return launch_gemm(p, 1, (hipStream_t)s);
+}
+
+extern "C" int pcuda_linear_bwd_w(const float* dy, const float* x, float* dw, float* db, int m, int k, int n,
+                                  int accumulate, pcuda_stream_t s) {
+  if (!dy || !x || !dw) PCUDA_FAIL(PCUDA_E_BADARG, "linear_bwd_w: null pointer");
+  GemmParams p = {dy, 0, 1, n, x, 0, k, 1, dw, 0, k, 1, nullptr, n, k, m, accumulate};   // dw[j][c] = sum_i dy[i][j] x[i][c]
+  int rc = launch_gemm(p, 1, (hipStream_t)s);
+  if (rc) return rc;
+  if (db) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, dy, m, n, db, accumulate);
+    PCUDA_CHECK_LAUNCH("colsum_kernel");
+  }
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_bmm(const float* a, const float* bmat, float* c, int batch, int m, int k, int n, int ta, int tb,
+                         int accumulate, pcuda_stream_t s) {
+  if (!a || !bmat || !c) PCUDA_FAIL(PCUDA_E_BADARG, "bmm: null pointer");
+  GemmParams p;
+  p.a = a; p.a_sb = (long long)m * k; p.a_si = ta ? 1 : k; p.a_sl = ta ? m : 1;
+  p.b = bmat; p.b_sb = (long long)k * n; p.b_sl = tb ? 1 : n; p.b_sj = tb ? k : 1;
+  p.c = c; p.c_sb = (long long)m * n; p.c_si = n; p.c_sj = 1;
+  p.bias = nullptr; p.m = m; p.n = n; p.k = k; p.accumulate = accumulate;
+  return launch_gemm(p, batch, (hipStream_t)s);
+}
+
+extern "C" int pcuda_max_points_fwd(const float* x, int b, int c, int l, float* y, int* idx, pcuda_stream_t s) {
+  if (!x || !y || !idx || b <= 0 || c <= 0 || l <= 0) PCUDA_FAIL(PCUDA_E_BADARG, "max_points_fwd: bad arguments");
+  const int rows = b * c;
+  hipLaunchKernelGGL(max_points_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)s, x, rows, l, y, idx);
+  PCUDA_CHECK_LAUNCH("max_points_fwd_kernel");
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_max_points_bwd(const float* dy, const int* idx, int b, int c, int l, float* dx, pcuda_stream_t s) {
+  if (!dy || !idx || !dx || b <= 0 || c <= 0 || l <= 0) PCUDA_FAIL(PCUDA_E_BADARG, "max_points_bwd: bad arguments");
+  const long long total = (long long)b * c * l;
+  const int blocks = (int)(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256));
+  hipLaunchKernelGGL(max_points_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, dy, idx, b * c, l, dx);
+  PCUDA_CHECK_LAUNCH("max_points_bwd_kernel");
+  return PCUDA_OK;
+}

@@ -1,0 +1,496 @@
+// HBM-bound kernels around the convolutions: BatchNorm (train) statistics / apply / backward fused
+// with the LeakyReLU that precedes it in the reference (unet.py:23-30: conv -> LeakyReLU -> BN),
+// 2x2 max pooling (unet.py:48), nearest-upsample backward (unet.py:111), running sums.
+// Tensors are [n][c][hw] with dense planes and explicit batch / channel strides.
+#include "common.h"
+
+#define PCH 2048   // plane elements per workgroup (256 threads x 8)
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];   // blockDim = 256
+}
+
+// ---------------------------------------------------------------------------- statistics
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ a, long long sn, long long sc,
+                                                       long long hw, int c, float* __restrict__ partials) {
+  __shared__ float sh[4];
+  const int ch = blockIdx.y, n = blockIdx.z;
+  const float* pl = a + n * sn + ch * sc;
+  const long long i0 = (long long)blockIdx.x * PCH, i1 = min(hw, i0 + PCH);
+  float s1 = 0.f, s2 = 0.f;
+  for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
+    const float v = pl[i];
+    s1 += v;
+    s2 += v * v;
+  }
+  s1 = block_sum(s1, sh);
+  s2 = block_sum(s2, sh);
+  if (threadIdx.x == 0) {
+    const long long tile = (long long)n * gridDim.x + blockIdx.x;
+    partials[(tile * c + ch) * 2 + 0] = s1;
+    partials[(tile * c + ch) * 2 + 1] = s2;
+  }
+}
+
+// one workgroup per channel; fp64 finalisation in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int ntiles, int c,
+                                                          double count, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, float momentum,
+                                                          float* running_mean, float* running_var, float* mean,
+                                                          float* invstd, float* scale, float* shift) {
+  __shared__ double sh[2][256];
+  const int ch = blockIdx.x;
+  double s1 = 0, s2 = 0;
+  for (int t = threadIdx.x; t < ntiles; t += 256) {
+    s1 += (double)partials[((long long)t * c + ch) * 2 + 0];
+    s2 += (double)partials[((long long)t * c + ch) * 2 + 1];
+  }
+  sh[0][threadIdx.x] = s1;
+  sh[1][threadIdx.x] = s2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double m = sh[0][0] / count;
+    double var = sh[1][0] / count - m * m;
+    if (var < 0) var = 0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[ch] : 1.f, b = beta ? beta[ch] : 0.f;
+    mean[ch] = (float)m;
+    invstd[ch] = is;
+    const float sc = g * is;
+    scale[ch] = sc;
+    shift[ch] = b - (float)m * sc;
+    if (running_mean) {
+      const double unb = count > 1 ? var * count / (count - 1.0) : var;
+      running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)m;
+      running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unb;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ a, long long a_sn, long long a_sc,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       int relu, float* __restrict__ y, long long y_sn, long long y_sc,
+                                                       long long hw) {
+  const int ch = blockIdx.y, n = blockIdx.z;
+  const float* pa = a + n * a_sn + ch * a_sc;
+  float* py = y + n * y_sn + ch * y_sc;
+  const float sc = scale[ch], sf = shift[ch];
+  const long long i0 = (long long)blockIdx.x * PCH, i1 = min(hw, i0 + PCH);
+  for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
+    float v = pa[i] * sc + sf;
+    if (relu) v = v > 0.f ? v : 0.f;
+    py[i] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------- backward
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    const float* __restrict__ dy, long long dy_sn, long long dy_sc, const float* __restrict__ dy2, long long dy2_sn,
+    long long dy2_sc, const float* __restrict__ a, long long a_sn, long long a_sc, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ scale, const float* __restrict__ shift, int post_relu,
+    long long hw, int c, float* __restrict__ red) {
+  __shared__ float sh[4];
+  const int ch = blockIdx.y, n = blockIdx.z;
+  const float* pd = dy + n * dy_sn + ch * dy_sc;
+  const float* pd2 = dy2 ? dy2 + n * dy2_sn + ch * dy2_sc : nullptr;
+  const float* pa = a + n * a_sn + ch * a_sc;
+  const float m = mean[ch], is = invstd[ch];
+  const float sc = post_relu ? scale[ch] : 0.f, sf = post_relu ? shift[ch] : 0.f;
+  const long long i0 = (long long)blockIdx.x * PCH, i1 = min(hw, i0 + PCH);
+  float s1 = 0.f, s2 = 0.f;
+  for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
+    const float av = pa[i];
+    float g = pd[i];
+    if (pd2) g += pd2[i];
+    if (post_relu && !(av * sc + sf > 0.f)) g = 0.f;
+    s1 += g;
+    s2 += g * ((av - m) * is);
+  }
+  s1 = block_sum(s1, sh);
+  s2 = block_sum(s2, sh);
+  if (threadIdx.x == 0) {
+    const long long tile = (long long)n * gridDim.x + blockIdx.x;
+    red[(tile * c + ch) * 2 + 0] = s1;
+    red[(tile * c + ch) * 2 + 1] = s2;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ red, int ntiles, int c,
+                                                              double count, const float* __restrict__ gamma,
+                                                              const float* __restrict__ invstd,
+                                                              const float* __restrict__ mean, float* dgamma,
+                                                              float* dbeta, int accumulate, float* coef) {
+  __shared__ double sh[2][256];
+  const int ch = blockIdx.x;
+  double s1 = 0, s2 = 0;
+  for (int t = threadIdx.x; t < ntiles; t += 256) {
+    s1 += (double)red[((long long)t * c + ch) * 2 + 0];
+    s2 += (double)red[((long long)t * c + ch) * 2 + 1];
+  }
+  sh[0][threadIdx.x] = s1;
+  sh[1][threadIdx.x] = s2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double S1 = sh[0][0], S2 = sh[1][0];
+    if (dgamma) dgamma[ch] = accumulate ? dgamma[ch] + (float)S2 : (float)S2;
+    if (dbeta) dbeta[ch] = accumulate ? dbeta[ch] + (float)S1 : (float)S1;
+    const double g = gamma ? (double)gamma[ch] : 1.0, is = invstd[ch], m = mean[ch];
+    const double sc = g * is;
+    coef[ch * 3 + 0] = (float)sc;
+    coef[ch * 3 + 1] = (float)(-sc * is * S2 / count);
+    coef[ch * 3 + 2] = (float)(-sc * S1 / count + sc * is * (S2 / count) * m);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const float* __restrict__ dy, long long dy_sn, long long dy_sc, const float* __restrict__ dy2, long long dy2_sn,
+    long long dy2_sc, const float* __restrict__ a, long long a_sn, long long a_sc, const float* __restrict__ coef,
+    const float* __restrict__ scale, const float* __restrict__ shift, int post_relu, float act_slope,
+    float* __restrict__ dz, long long dz_sn, long long dz_sc, long long hw) {
+  const int ch = blockIdx.y, n = blockIdx.z;
+  const float* pd = dy + n * dy_sn + ch * dy_sc;
+  const float* pd2 = dy2 ? dy2 + n * dy2_sn + ch * dy2_sc : nullptr;
+  const float* pa = a + n * a_sn + ch * a_sc;
+  float* pz = dz + n * dz_sn + ch * dz_sc;
+  const float c0 = coef[ch * 3 + 0], c1 = coef[ch * 3 + 1], c2 = coef[ch * 3 + 2];
+  const float sc = post_relu ? scale[ch] : 0.f, sf = post_relu ? shift[ch] : 0.f;
+  const long long i0 = (long long)blockIdx.x * PCH, i1 = min(hw, i0 + PCH);
+  for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
+    const float av = pa[i];
+    float g = pd[i];
+    if (pd2) g += pd2[i];
+    float out;
+    if (post_relu) {
+      if (!(av * sc + sf > 0.f)) g = 0.f;
+      out = c0 * g + c1 * av + c2;
+    } else {
+      out = (c0 * g + c1 * av + c2) * (av > 0.f ? 1.f : act_slope);
+    }
+    pz[i] = out;
+  }
+}
+
+__global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* __restrict__ dy, long long dy_sn, long long dy_sc,
+                                                        const float* __restrict__ dy2, long long dy2_sn,
+                                                        long long dy2_sc, const float* __restrict__ a, long long a_sn,
+                                                        long long a_sc, float slope, float* __restrict__ dz,
+                                                        long long dz_sn, long long dz_sc, long long hw) {
+  const int ch = blockIdx.y, n = blockIdx.z;
+  const float* pd = dy + n * dy_sn + ch * dy_sc;
+  const float* pd2 = dy2 ? dy2 + n * dy2_sn + ch * dy2_sc : nullptr;
+  const float* pa = a + n * a_sn + ch * a_sc;
+  float* pz = dz + n * dz_sn + ch * dz_sc;
+  const long long i0 = (long long)blockIdx.x * PCH, i1 = min(hw, i0 + PCH);
+  for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
+    float g = pd[i];
+    if (pd2) g += pd2[i];
+    pz[i] = pa[i] > 0.f ? g : g * slope;
+  }
+}
+
+__global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float* __restrict__ dz, long long sn,
+                                                                  long long sc, long long hw, int c,
+                                                                  float* __restrict__ part) {
+  __shared__ float sh[4];
+  const int ch = blockIdx.y, n = blockIdx.z;
+  const float* pl = dz + n * sn + ch * sc;
+  const long long i0 = (long long)blockIdx.x * PCH, i1 = min(hw, i0 + PCH);
+  float s = 0.f;
+  for (long long i = i0 + threadIdx.x; i < i1; i += 256) s += pl[i];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) part[((long long)n * gridDim.x + blockIdx.x) * c + ch] = s;
+}
+
+__global__ __launch_bounds__(256) void channel_sum_final_kernel(const float* __restrict__ part, int ntiles, int c,
+                                                                float* db, int accumulate) {
+  __shared__ double sh[256];
+  const int ch = blockIdx.x;
+  double s = 0;
+  for (int t = threadIdx.x; t < ntiles; t += 256) s += (double)part[(long long)t * c + ch];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) db[ch] = accumulate ? db[ch] + (float)sh[0] : (float)sh[0];
+}
+
+// ---------------------------------------------------------------------------- pooling / resampling
+// one thread per pooled element; first maximum in row-major window order wins (ATen semantics)
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, long long x_sn, long long x_sc,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, float* __restrict__ y,
+                                                           long long y_sn, long long y_sc, uint8_t* __restrict__ idx,
+                                                           int c, int h, int w) {
+  const int ch = blockIdx.y, n = blockIdx.z;
+  const int oh = h >> 1, ow = w >> 1;
+  const float sc = scale ? scale[ch] : 1.f, sf = shift ? shift[ch] : 0.f;
+  const float* px = x + n * x_sn + ch * x_sc;
+  float* py = y + n * y_sn + ch * y_sc;
+  uint8_t* pi = idx + ((long long)n * c + ch) * oh * ow;
+  const int total = oh * ow;
+  for (int o = blockIdx.x * PCH + threadIdx.x; o < min(total, (int)(blockIdx.x + 1) * PCH); o += 256) {
+    const int oy = o / ow, ox = o - oy * ow;
+    const float* r0 = px + (long long)(2 * oy) * w + 2 * ox;
+    const float2 t0 = *(const float2*)r0;
+    const float2 t1 = *(const float2*)(r0 + w);
+    const float v0 = t0.x * sc + sf, v1 = t0.y * sc + sf, v2 = t1.x * sc + sf, v3 = t1.y * sc + sf;
+    float m = v0;
+    int k = 0;
+    if (v1 > m) { m = v1; k = 1; }
+    if (v2 > m) { m = v2; k = 2; }
+    if (v3 > m) { m = v3; k = 3; }
+    py[o] = m;
+    pi[o] = (uint8_t)k;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ dy, long long dy_sn,
+                                                           long long dy_sc, const float* __restrict__ dy2,
+                                                           long long dy2_sn, long long dy2_sc,
+                                                           const uint8_t* __restrict__ idx, float* __restrict__ dx,
+                                                           long long dx_sn, long long dx_sc, int accumulate, int c,
+                                                           int h, int w) {
+  const int ch = blockIdx.y, n = blockIdx.z;
+  const int oh = h >> 1, ow = w >> 1;
+  const float* pd = dy + n * dy_sn + ch * dy_sc;
+  const float* pd2 = dy2 ? dy2 + n * dy2_sn + ch * dy2_sc : nullptr;
+  const uint8_t* pi = idx + ((long long)n * c + ch) * oh * ow;
+  float* px = dx + n * dx_sn + ch * dx_sc;
+  const int total = oh * ow;
+  for (int o = blockIdx.x * PCH + threadIdx.x; o < min(total, (int)(blockIdx.x + 1) * PCH); o += 256) {
+    const int oy = o / ow, ox = o - oy * ow;
+    float g = pd[o];
+    if (pd2) g += pd2[o];
+    const int k = pi[o];
+    float* r0 = px + (long long)(2 * oy) * w + 2 * ox;
+    float2 t0 = make_float2(k == 0 ? g : 0.f, k == 1 ? g : 0.f);
+    float2 t1 = make_float2(k == 2 ? g : 0.f, k == 3 ? g : 0.f);
+    if (accumulate) {
+      const float2 a0 = *(float2*)r0, a1 = *(float2*)(r0 + w);
+      t0.x += a0.x; t0.y += a0.y; t1.x += a1.x; t1.y += a1.y;
+    }
+    *(float2*)r0 = t0;
+    *(float2*)(r0 + w) = t1;
+  }
+}
+
+__global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restrict__ dy, long long dy_sn,
+                                                            long long dy_sc, float* __restrict__ dx, long long dx_sn,
+                                                            long long dx_sc, int accumulate, int h, int w) {
+  const int ch = blockIdx.y, n = blockIdx.z;
+  const float* pd = dy + n * dy_sn + ch * dy_sc;
+  float* px = dx + n * dx_sn + ch * dx_sc;
+  const int total = h * w;
+  for (int o = blockIdx.x * PCH + threadIdx.x; o < min(total, (int)(blockIdx.x + 1) * PCH); o += 256) {
+    const int oy = o / w, ox = o - oy * w;
+    const float* r0 = pd + (long long)(2 * oy) * (2 * w) + 2 * ox;
+    const float2 t0 = *(const float2*)r0;
+    const float2 t1 = *(const float2*)(r0 + 2 * w);
+    const float s = (t0.x + t0.y) + (t1.x + t1.y);
+    px[o] = accumulate ? px[o] + s : s;
+  }
+}
+
+__global__ __launch_bounds__(256) void add4_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                   const float* __restrict__ c, const float* __restrict__ d,
+                                                   float* __restrict__ y, long long numel) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < numel; i += 256ll * gridDim.x) {
+    float v = a[i] + b[i];
+    if (c) v += c[i];
+    if (d) v += d[i];
+    y[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ y, long long numel) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < numel; i += 256ll * gridDim.x) y[i] = a[i] * b[i];
+}
+
+// ============================================================================ host wrappers
+namespace {
+inline bool dims_ok(int n, int c, long long hw) { return n > 0 && c > 0 && hw > 0 && n <= 65535 && c <= 65535; }
+inline dim3 plane_grid(int n, int c, long long hw) { return dim3((unsigned)cdiv(hw, PCH), (unsigned)c, (unsigned)n); }
+}  // namespace
+
+extern "C" int pcuda_bn_stats(const float* a, long long sn, long long sc, int n, int c, long long hw,
+                              float* partials, int* ntiles, pcuda_stream_t s) {
+  if (!dims_ok(n, c, hw)) PCUDA_FAIL(PCUDA_E_BADARG, "bn_stats: bad dims");
+  const int nt = n * cdiv(hw, PCH);
+  if (ntiles) *ntiles = nt;
+  if (!partials) return PCUDA_OK;
+  if (!a) PCUDA_FAIL(PCUDA_E_BADARG, "bn_stats: null input");
+  ProfScope prof(PCUDA_FAM_POINTWISE, 4.0 * n * c * (double)hw, (hipStream_t)s);
+  hipLaunchKernelGGL(bn_stats_kernel, plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, a, sn, sc, hw, c, partials);
+  PCUDA_CHECK_LAUNCH("bn_stats_kernel");
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_bn_finalize(const float* partials, int ntiles, int c, long long count, const float* gamma,
+                                 const float* beta, float eps, float momentum, float* running_mean,
+                                 float* running_var, float* mean, float* invstd, float* scale, float* shift,
+                                 pcuda_stream_t s) {
+  if (!partials || ntiles <= 0 || c <= 0 || count <= 0 || !mean || !invstd || !scale || !shift)
+    PCUDA_FAIL(PCUDA_E_BADARG, "bn_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(c), dim3(256), 0, (hipStream_t)s, partials, ntiles, c, (double)count,
+                     gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+  PCUDA_CHECK_LAUNCH("bn_finalize_kernel");
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_bn_apply(const float* a, long long a_sn, long long a_sc, const float* scale, const float* shift,
+                              int relu, float* y, long long y_sn, long long y_sc, int n, int c, long long hw,
+                              pcuda_stream_t s) {
+  if (!dims_ok(n, c, hw) || !a || !y || !scale || !shift) PCUDA_FAIL(PCUDA_E_BADARG, "bn_apply: bad arguments");
+  ProfScope prof(PCUDA_FAM_POINTWISE, 8.0 * n * c * (double)hw, (hipStream_t)s);
+  hipLaunchKernelGGL(bn_apply_kernel, plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, a, a_sn, a_sc, scale, shift,
+                     relu, y, y_sn, y_sc, hw);
+  PCUDA_CHECK_LAUNCH("bn_apply_kernel");
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_bn_bwd_reduce(const float* dy, long long dy_sn, long long dy_sc, const float* dy2,
+                                   long long dy2_sn, long long dy2_sc, const float* a, long long a_sn, long long a_sc,
+                                   const float* mean, const float* invstd, const float* scale, const float* shift,
+                                   int post_relu, int n, int c, long long hw, float* red, int* ntiles,
+                                   pcuda_stream_t s) {
+  if (!dims_ok(n, c, hw)) PCUDA_FAIL(PCUDA_E_BADARG, "bn_bwd_reduce: bad dims");
+  const int nt = n * cdiv(hw, PCH);
+  if (ntiles) *ntiles = nt;
+  if (!red) return PCUDA_OK;
+  if (!dy || !a || !mean || !invstd || (post_relu && (!scale || !shift)))
+    PCUDA_FAIL(PCUDA_E_BADARG, "bn_bwd_reduce: null pointer");
+  ProfScope prof(PCUDA_FAM_POINTWISE, (dy2 ? 12.0 : 8.0) * n * c * (double)hw, (hipStream_t)s);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, dy, dy_sn, dy_sc, dy2,
+                     dy2_sn, dy2_sc, a, a_sn, a_sc, mean, invstd, scale, shift, post_relu, hw, c, red);
+  PCUDA_CHECK_LAUNCH("bn_bwd_reduce_kernel");
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_bn_bwd_finalize(const float* red, int ntiles, int c, long long count, const float* gamma,
+                                     const float* invstd, const float* mean, float* dgamma, float* dbeta,
+                                     int accumulate, float* coef, pcuda_stream_t s) {
+  if (!red || ntiles <= 0 || c <= 0 || count <= 0 || !invstd || !mean || !coef)
+    PCUDA_FAIL(PCUDA_E_BADARG, "bn_bwd_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(256), 0, (hipStream_t)s, red, ntiles, c, (double)count,
+                     gamma, invstd, mean, dgamma, dbeta, accumulate, coef);
+  PCUDA_CHECK_LAUNCH("bn_bwd_finalize_kernel");
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_bn_bwd_apply(const float* dy, long long dy_sn, long long dy_sc, const float* dy2,
+                                  long long dy2_sn, long long dy2_sc, const float* a, long long a_sn, long long a_sc,
+                                  const float* coef, const float* scale, const float* shift, int post_relu,
+                                  float act_slope, float* dz, long long dz_sn, long long dz_sc, int n, int c,
+                                  long long hw, pcuda_stream_t s) {
+  if (!dims_ok(n, c, hw) || !dy || !a || !coef || !dz || (post_relu && (!scale || !shift)))
+    PCUDA_FAIL(PCUDA_E_BADARG, "bn_bwd_apply: bad arguments");
+  ProfScope prof(PCUDA_FAM_POINTWISE, (dy2 ? 16.0 : 12.0) * n * c * (double)hw, (hipStream_t)s);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, dy, dy_sn, dy_sc, dy2,
+                     dy2_sn, dy2_sc, a, a_sn, a_sc, coef, scale, shift, post_relu, act_slope, dz, dz_sn, dz_sc, hw);
+  PCUDA_CHECK_LAUNCH("bn_bwd_apply_kernel");
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_lrelu_bwd(const float* dy, long long dy_sn, long long dy_sc, const float* dy2, long long dy2_sn,
+                               long long dy2_sc, const float* a, long long a_sn, long long a_sc, float slope,
+                               float* dz, long long dz_sn, long long dz_sc, int n, int c, long long hw,
+                               pcuda_stream_t s) {
+  if (!dims_ok(n, c, hw) || !dy || !a || !dz) PCUDA_FAIL(PCUDA_E_BADARG, "lrelu_bwd: bad arguments");
+  ProfScope prof(PCUDA_FAM_POINTWISE, (dy2 ? 16.0 : 12.0) * n * c * (double)hw, (hipStream_t)s);
+  hipLaunchKernelGGL(lrelu_bwd_kernel, plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, dy, dy_sn, dy_sc, dy2,
+                     dy2_sn, dy2_sc, a, a_sn, a_sc, slope, dz, dz_sn, dz_sc, hw);
+  PCUDA_CHECK_LAUNCH("lrelu_bwd_kernel");
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_channel_sum(const float* dz, long long sn, long long sc, int n, int c, long long hw, float* db,
+                                 int accumulate, float* workspace, size_t workspace_bytes, pcuda_stream_t s) {
+  if (!dims_ok(n, c, hw) || !dz || !db) PCUDA_FAIL(PCUDA_E_BADARG, "channel_sum: bad arguments");
+  const int nt = n * cdiv(hw, PCH);
+  if (!workspace || workspace_bytes < (size_t)nt * c * sizeof(float))
+    PCUDA_FAIL(PCUDA_E_WORKSPACE, "channel_sum: workspace too small (need %zu)", (size_t)nt * c * sizeof(float));
+  hipLaunchKernelGGL(channel_sum_partial_kernel, plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, dz, sn, sc, hw, c,
+                     workspace);
+  PCUDA_CHECK_LAUNCH("channel_sum_partial_kernel");
+  hipLaunchKernelGGL(channel_sum_final_kernel, dim3(c), dim3(256), 0, (hipStream_t)s, (const float*)workspace, nt, c,
+                     db, accumulate);
+  PCUDA_CHECK_LAUNCH("channel_sum_final_kernel");
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_maxpool2_fwd(const float* x, long long x_sn, long long x_sc, const float* scale,
+                                  const float* shift, float* y, long long y_sn, long long y_sc, uint8_t* idx, int n,
+                                  int c, int h, int w, pcuda_stream_t s) {
+  if (!dims_ok(n, c, (long long)h * w) || (h & 1) || (w & 1) || !x || !y || !idx || ((x_sn | x_sc) & 1) ||
+      (((uintptr_t)x) & 7))
+    PCUDA_FAIL(PCUDA_E_BADARG, "maxpool2_fwd: bad arguments (even dims, 8-byte aligned planes required)");
+  const long long ohw = (long long)(h / 2) * (w / 2);
+  ProfScope prof(PCUDA_FAM_POINTWISE, 21.0 * n * c * (double)ohw, (hipStream_t)s);
+  hipLaunchKernelGGL(maxpool2_fwd_kernel, plane_grid(n, c, ohw), dim3(256), 0, (hipStream_t)s, x, x_sn, x_sc, scale,
+                     shift, y, y_sn, y_sc, idx, c, h, w);
+  PCUDA_CHECK_LAUNCH("maxpool2_fwd_kernel");
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_maxpool2_bwd(const float* dy, long long dy_sn, long long dy_sc, const float* dy2,
+                                  long long dy2_sn, long long dy2_sc, const uint8_t* idx, float* dx, long long dx_sn,
+                                  long long dx_sc, int accumulate, int n, int c, int h, int w, pcuda_stream_t s) {
+  if (!dims_ok(n, c, (long long)h * w) || (h & 1) || (w & 1) || !dy || !dx || !idx || ((dx_sn | dx_sc) & 1) ||
+      (((uintptr_t)dx) & 7))
+    PCUDA_FAIL(PCUDA_E_BADARG, "maxpool2_bwd: bad arguments");
+  const long long ohw = (long long)(h / 2) * (w / 2);
+  ProfScope prof(PCUDA_FAM_POINTWISE, 21.0 * n * c * (double)ohw, (hipStream_t)s);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, plane_grid(n, c, ohw), dim3(256), 0, (hipStream_t)s, dy, dy_sn, dy_sc, dy2,
+                     dy2_sn, dy2_sc, idx, dx, dx_sn, dx_sc, accumulate, c, h, w);
+  PCUDA_CHECK_LAUNCH("maxpool2_bwd_kernel");
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_upsample2_bwd(const float* dy, long long dy_sn, long long dy_sc, float* dx, long long dx_sn,
+                                   long long dx_sc, int accumulate, int n, int c, int h, int w, pcuda_stream_t s) {
+  if (!dims_ok(n, c, (long long)h * w) || !dy || !dx || ((dy_sn | dy_sc) & 1) || (((uintptr_t)dy) & 7))
+    PCUDA_FAIL(PCUDA_E_BADARG, "upsample2_bwd: bad arguments");
+  ProfScope prof(PCUDA_FAM_POINTWISE, 20.0 * n * c * (double)h * w, (hipStream_t)s);
+  hipLaunchKernelGGL(upsample2_bwd_kernel, plane_grid(n, c, (long long)h * w), dim3(256), 0, (hipStream_t)s, dy, dy_sn,
+                     dy_sc, dx, dx_sn, dx_sc, accumulate, h, w);
+  PCUDA_CHECK_LAUNCH("upsample2_bwd_kernel");
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_add4(const float* a, const float* b, const float* c, const float* d, float* y, long long numel,
+                          pcuda_stream_t s) {
+  if (!a || !b || !y || numel <= 0) PCUDA_FAIL(PCUDA_E_BADARG, "add4: bad arguments");
+  const int blocks = (int)(cdiv(numel, 256) > 4096 ? 4096 : cdiv(numel, 256));
+  hipLaunchKernelGGL(add4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, a, b, c, d, y, numel);
+  PCUDA_CHECK_LAUNCH("add4_kernel");
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_mul(const float* a, const float* b, float* y, long long numel, pcuda_stream_t s) {
+  if (!a || !b || !y || numel <= 0) PCUDA_FAIL(PCUDA_E_BADARG, "mul: bad arguments");
+  const int blocks = (int)(cdiv(numel, 256) > 4096 ? 4096 : cdiv(numel, 256));
+  hipLaunchKernelGGL(mul_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, a, b, y, numel);
+  PCUDA_CHECK_LAUNCH("mul_kernel");
+  return PCUDA_OK;
+}

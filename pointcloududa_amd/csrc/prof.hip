@@ -1,0 +1,105 @@
+// Error text + per-family kernel timing with HIP events on the launch stream.
+#include <stdarg.h>
+
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void pcuda_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* pcuda_last_error(void) { return g_err; }
+extern "C" int pcuda_version(void) { return 1; }
+extern "C" int pcuda_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+namespace {
+struct Rec {
+  hipEvent_t e0, e1;
+  int fam;
+  double work;
+};
+std::mutex g_mu;
+bool g_on = false;
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_free;
+
+hipEvent_t get_event() {
+  if (!g_free.empty()) {
+    hipEvent_t e = g_free.back();
+    g_free.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+}  // namespace
+
+ProfScope::ProfScope(int family, double work, hipStream_t s) : fam(family), ev0(nullptr), stream(s) {
+  if (!g_on) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  Rec r;
+  r.e0 = get_event();
+  r.e1 = get_event();
+  r.fam = family;
+  r.work = work;
+  if (!r.e0 || !r.e1) return;
+  (void)hipEventRecord(r.e0, s);
+  g_recs.push_back(r);
+  ev0 = (void*)r.e1;
+}
+
+ProfScope::~ProfScope() {
+  if (ev0) (void)hipEventRecord((hipEvent_t)ev0, stream);
+}
+
+extern "C" int pcuda_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_on = on != 0;
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_prof_reset(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& r : g_recs) {
+    (void)hipEventSynchronize(r.e1);
+    g_free.push_back(r.e0);
+    g_free.push_back(r.e1);
+  }
+  g_recs.clear();
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_prof_read(int family, double* ms, double* work, long long* launches) {
+  if (family < 0 || family >= PCUDA_FAM_COUNT) PCUDA_FAIL(PCUDA_E_BADARG, "prof_read: bad family %d", family);
+  std::lock_guard<std::mutex> lk(g_mu);
+  double t = 0, w = 0;
+  long long n = 0;
+  for (auto& r : g_recs) {
+    if (r.fam != family) continue;
+    if (hipEventSynchronize(r.e1) != hipSuccess) PCUDA_FAIL(PCUDA_E_LAUNCH, "prof_read: event sync failed");
+    float dt = 0.f;
+    if (hipEventElapsedTime(&dt, r.e0, r.e1) != hipSuccess) PCUDA_FAIL(PCUDA_E_LAUNCH, "prof_read: elapsed failed");
+    t += dt;
+    w += r.work;
+    ++n;
+  }
+  if (ms) *ms = t;
+  if (work) *work = w;
+  if (launches) *launches = n;
+  return PCUDA_OK;
+}

@@ -1,0 +1,540 @@
+"""torch-tensor front end of the C ABI (ctypes calls on torch's current HIP stream).
+
+torch is used here for device memory (``torch.empty``) and the stream handle only; every
+arithmetic step is a kernel of libpcuda_hip.so.  There is no fallback: a tensor that is not
+on a HIP device, or a missing library, raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from ._lib import ACT_SIGMOID, ACT_SOFTMAX, PREC_BF16, PREC_BF16X3, ConvGeom, Dst, Src, check
+
+_PREC = {"bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
+_precision = _PREC.get(os.environ.get("PCUDA_PRECISION", "bf16x3").lower(), PREC_BF16X3)
+
+
+def set_precision(name: str) -> None:
+    """'bf16x3' (parity mode: split-bf16 MFMA, ~fp32 accuracy) or 'bf16' (throughput mode)."""
+    global _precision
+    _precision = _PREC[name.lower()]
+
+
+def get_precision() -> str:
+    return "bf16x3" if _precision == PREC_BF16X3 else "bf16"
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t: torch.Tensor, dtype=torch.float32):
+    if not t.is_cuda:
+        raise RuntimeError("pointcloududa_amd kernels need HIP device tensors (no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError("expected %s, got %s" % (dtype, t.dtype))
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _planes(t: torch.Tensor) -> Tuple[int, int, int, int, int]:
+    """(n, c, hw, sn, sc) of a [N,C,...] tensor whose trailing dims form a dense plane."""
+    _req(t)
+    n, c = t.shape[0], t.shape[1]
+    hw = 1
+    for d in t.shape[2:]:
+        hw *= d
+    exp = 1
+    for d in range(t.dim() - 1, 1, -1):
+        if t.shape[d] != 1 and t.stride(d) != exp:
+            raise ValueError("tensor planes must be dense (shape %s strides %s)" % (tuple(t.shape), t.stride()))
+        exp *= t.shape[d]
+    return n, c, hw, t.stride(0), t.stride(1)
+
+
+class TA:
+    """A tensor with an optional per-channel affine still to be applied on load
+    (= a BatchNorm output that was never materialised)."""
+    __slots__ = ("t", "scale", "shift")
+
+    def __init__(self, t, scale=None, shift=None):
+        self.t, self.scale, self.shift = t, scale, shift
+
+
+def _as_ta(x) -> TA:
+    return x if isinstance(x, TA) else TA(x)
+
+
+def make_src(a, b=None) -> Src:
+    a = _as_ta(a)
+    _, c1, _, sn1, sc1 = _planes(a.t)
+    s = Src()
+    s.p1, s.sn1, s.sc1, s.scale1, s.shift1, s.c1 = a.t.data_ptr(), sn1, sc1, _ptr(a.scale), _ptr(a.shift), c1
+    if b is not None:
+        b = _as_ta(b)
+        _, _, _, sn2, sc2 = _planes(b.t)
+        s.p2, s.sn2, s.sc2, s.scale2, s.shift2 = b.t.data_ptr(), sn2, sc2, _ptr(b.scale), _ptr(b.shift)
+    return s
+
+
+def make_dst(a: torch.Tensor, b: Optional[torch.Tensor] = None) -> Dst:
+    _, c1, _, sn1, sc1 = _planes(a)
+    d = Dst()
+    d.p1, d.sn1, d.sc1, d.c1 = a.data_ptr(), sn1, sc1, c1
+    if b is not None:
+        _, _, _, sn2, sc2 = _planes(b)
+        d.p2, d.sn2, d.sc2 = b.data_ptr(), sn2, sc2
+    return d
+
+
+# ------------------------------------------------------------------------------------------
+# convolution
+# ------------------------------------------------------------------------------------------
+class ConvOp:
+    """Geometry + packed-weight cache of one nn.Conv2d (square kernel, groups=1)."""
+
+    def __init__(self, cin, cout, k, stride=1, pad=0, dil=1, in_up=False):
+        self.cin, self.cout, self.k, self.stride, self.pad, self.dil, self.in_up = cin, cout, k, stride, pad, dil, in_up
+        self._pk = {}     # (kind, prec) -> (weight ptr, version, generation, packed tensor)
+        self.owner = None  # object whose ``_wgen`` counter is bumped when weights change behind torch's back
+
+    def out_hw(self, in_h, in_w):
+        f = lambda v: (v + 2 * self.pad - self.dil * (self.k - 1) - 1) // self.stride + 1
+        return f(in_h), f(in_w)
+
+    def geom(self, n, in_h, in_w) -> ConvGeom:
+        """in_h/in_w: LOGICAL input size (already doubled when in_up)."""
+        oh, ow = self.out_hw(in_h, in_w)
+        return ConvGeom(n, self.cin, self.cout, in_h, in_w, oh, ow, self.k, self.stride, self.pad, self.dil,
+                        1 if self.in_up else 0)
+
+    def _packed(self, kind: str, w: torch.Tensor, g: ConvGeom):
+        key = (kind, _precision)
+        hit = self._pk.get(key)
+        gen = getattr(self.owner, "_wgen", 0)
+        if hit is not None and hit[0] == w.data_ptr() and hit[1] == w._version and hit[2] == gen:
+            return hit[3]
+        _req(w)
+        if not w.is_contiguous():
+            raise ValueError("conv weight must be contiguous OIHW")
+        lib = L.lib()
+        if kind == "fwd":
+            nbytes = lib.pcuda_conv2d_packed_fwd_bytes(C.byref(g), _precision)
+        else:
+            nbytes = lib.pcuda_conv2d_packed_dgrad_bytes(C.byref(g), _precision)
+        if nbytes == 0:
+            raise RuntimeError("conv geometry rejected by libpcuda_hip")
+        buf = hit[3] if (hit is not None and hit[3].numel() == nbytes) else torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        fn = lib.pcuda_conv2d_pack_fwd if kind == "fwd" else lib.pcuda_conv2d_pack_dgrad
+        check(fn(C.byref(g), _precision, w.data_ptr(), buf.data_ptr(), _stream()), "pack_" + kind)
+        self._pk[key] = (w.data_ptr(), w._version, gen, buf)
+        return buf
+
+    def forward(self, x, w, b, slope, in_h, in_w, x2=None, out=None, want_stats=False):
+        """x (and x2 for a channel concat): tensors or TA.  Returns (y, partials|None, ntiles)."""
+        xa = _as_ta(x)
+        n = xa.t.shape[0]
+        g = self.geom(n, in_h, in_w)
+        if out is None:
+            out = torch.empty((n, self.cout, g.out_h, g.out_w), dtype=torch.float32, device=w.device)
+        pk = self._packed("fwd", w, g)
+        lib = L.lib()
+        partials, nt = None, 0
+        if want_stats:
+            nt = lib.pcuda_conv2d_fwd_tiles(C.byref(g), _precision)
+            partials = torch.empty((nt, self.cout, 2), dtype=torch.float32, device=w.device)
+        src, dst = make_src(xa, x2), make_dst(out)
+        check(lib.pcuda_conv2d_forward(C.byref(g), _precision, C.byref(src), pk.data_ptr(), _ptr(b), float(slope),
+                                       C.byref(dst), _ptr(partials), _stream()), "conv2d_forward")
+        return out, partials, nt
+
+    def dgrad(self, dy, w, in_h, in_w, dx=None, dx2=None, accumulate=False):
+        """dy: [n,cout,oh,ow].  dx (+dx2 split along channels) = gradient of the logical input."""
+        n = dy.shape[0]
+        g = self.geom(n, in_h, in_w)
+        if dx is None:
+            dx = torch.empty((n, self.cin, in_h, in_w), dtype=torch.float32, device=dy.device)
+        pk = self._packed("dgrad", w, g)
+        src, dst = make_src(dy), make_dst(dx, dx2)
+        check(L.lib().pcuda_conv2d_dgrad(C.byref(g), _precision, C.byref(src), pk.data_ptr(), C.byref(dst),
+                                         1 if accumulate else 0, _stream()), "conv2d_dgrad")
+        return dx
+
+    def wgrad(self, x, dy, dw, db, in_h, in_w, x2=None, accumulate=True):
+        xa = _as_ta(x)
+        n = xa.t.shape[0]
+        g = self.geom(n, in_h, in_w)
+        lib = L.lib()
+        ws_bytes = lib.pcuda_conv2d_wgrad_workspace_size(C.byref(g))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
+        _, _, _, sn, sc = _planes(dy)
+        src = make_src(xa, x2)
+        check(lib.pcuda_conv2d_wgrad(C.byref(g), _precision, C.byref(src), dy.data_ptr(), sn, sc, dw.data_ptr(),
+                                     _ptr(db), 1 if accumulate else 0, ws.data_ptr(), ws_bytes, _stream()),
+              "conv2d_wgrad")
+
+
+# ------------------------------------------------------------------------------------------
+# BatchNorm pieces
+# ------------------------------------------------------------------------------------------
+class BNState:
+    """per-forward statistics of one BatchNorm layer"""
+    __slots__ = ("mean", "invstd", "scale", "shift", "count")
+
+
+def bn_finalize(partials, ntiles, count, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1) -> BNState:
+    c = partials.shape[1]
+    st = BNState()
+    buf = torch.empty((4, c), dtype=torch.float32, device=partials.device)
+    st.mean, st.invstd, st.scale, st.shift, st.count = buf[0], buf[1], buf[2], buf[3], count
+    check(L.lib().pcuda_bn_finalize(partials.data_ptr(), ntiles, c, count, _ptr(gamma), _ptr(beta), eps, momentum,
+                                    _ptr(running_mean), _ptr(running_var), st.mean.data_ptr(), st.invstd.data_ptr(),
+                                    st.scale.data_ptr(), st.shift.data_ptr(), _stream()), "bn_finalize")
+    return st
+
+
+def bn_stats(a: torch.Tensor):
+    n, c, hw, sn, sc = _planes(a)
+    nt = C.c_int(0)
+    lib = L.lib()
+    check(lib.pcuda_bn_stats(None, sn, sc, n, c, hw, None, C.byref(nt), _stream()), "bn_stats(query)")
+    partials = torch.empty((nt.value, c, 2), dtype=torch.float32, device=a.device)
+    check(lib.pcuda_bn_stats(a.data_ptr(), sn, sc, n, c, hw, partials.data_ptr(), C.byref(nt), _stream()), "bn_stats")
+    return partials, nt.value, n * hw
+
+
+def bn_apply(a: torch.Tensor, st: BNState, relu=False, out=None):
+    n, c, hw, sn, sc = _planes(a)
+    if out is None:
+        out = torch.empty_like(a, memory_format=torch.contiguous_format)
+    _, _, _, osn, osc = _planes(out)
+    check(L.lib().pcuda_bn_apply(a.data_ptr(), sn, sc, st.scale.data_ptr(), st.shift.data_ptr(), 1 if relu else 0,
+                                 out.data_ptr(), osn, osc, n, c, hw, _stream()), "bn_apply")
+    return out
+
+
+def bn_backward(dy, a, st: BNState, gamma, dgamma, dbeta, dy2=None, post_relu=False, act_slope=1.0,
+                accumulate=True):
+    """Backward of [a = lrelu(z, act_slope)] -> BN (post_relu=False) or a -> BN -> ReLU (post_relu=True).
+    Returns dz (gradient w.r.t. the pre-activation conv output, or w.r.t. a when post_relu)."""
+    n, c, hw, asn, asc = _planes(a)
+    _, _, _, dsn, dsc = _planes(dy)
+    d2p, d2sn, d2sc = None, 0, 0
+    if dy2 is not None:
+        _, _, _, d2sn, d2sc = _planes(dy2)
+        d2p = dy2.data_ptr()
+    lib = L.lib()
+    nt = C.c_int(0)
+    check(lib.pcuda_bn_bwd_reduce(None, 0, 0, None, 0, 0, None, 0, 0, None, None, None, None, 0, n, c, hw, None,
+                                  C.byref(nt), _stream()), "bn_bwd_reduce(query)")
+    red = torch.empty((nt.value, c, 2), dtype=torch.float32, device=a.device)
+    pr = 1 if post_relu else 0
+    check(lib.pcuda_bn_bwd_reduce(dy.data_ptr(), dsn, dsc, d2p, d2sn, d2sc, a.data_ptr(), asn, asc,
+                                  st.mean.data_ptr(), st.invstd.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(),
+                                  pr, n, c, hw, red.data_ptr(), C.byref(nt), _stream()), "bn_bwd_reduce")
+    coef = torch.empty((c, 3), dtype=torch.float32, device=a.device)
+    check(lib.pcuda_bn_bwd_finalize(red.data_ptr(), nt.value, c, n * hw, _ptr(gamma), st.invstd.data_ptr(),
+                                    st.mean.data_ptr(), _ptr(dgamma), _ptr(dbeta), 1 if accumulate else 0,
+                                    coef.data_ptr(), _stream()), "bn_bwd_finalize")
+    dz = torch.empty(a.shape, dtype=torch.float32, device=a.device)
+    _, _, _, zsn, zsc = _planes(dz)
+    check(lib.pcuda_bn_bwd_apply(dy.data_ptr(), dsn, dsc, d2p, d2sn, d2sc, a.data_ptr(), asn, asc, coef.data_ptr(),
+                                 st.scale.data_ptr(), st.shift.data_ptr(), pr, float(act_slope), dz.data_ptr(), zsn,
+                                 zsc, n, c, hw, _stream()), "bn_bwd_apply")
+    return dz
+
+
+def lrelu_bwd(dy, a, slope, dy2=None):
+    n, c, hw, asn, asc = _planes(a)
+    _, _, _, dsn, dsc = _planes(dy)
+    d2p, d2sn, d2sc = None, 0, 0
+    if dy2 is not None:
+        _, _, _, d2sn, d2sc = _planes(dy2)
+        d2p = dy2.data_ptr()
+    dz = torch.empty(a.shape, dtype=torch.float32, device=a.device)
+    _, _, _, zsn, zsc = _planes(dz)
+    check(L.lib().pcuda_lrelu_bwd(dy.data_ptr(), dsn, dsc, d2p, d2sn, d2sc, a.data_ptr(), asn, asc, float(slope),
+                                  dz.data_ptr(), zsn, zsc, n, c, hw, _stream()), "lrelu_bwd")
+    return dz
+
+
+def channel_sum(dz, db, accumulate=True):
+    n, c, hw, sn, sc = _planes(dz)
+    ws = torch.empty((n * ((hw + 2047) // 2048), c), dtype=torch.float32, device=dz.device)
+    check(L.lib().pcuda_channel_sum(dz.data_ptr(), sn, sc, n, c, hw, db.data_ptr(), 1 if accumulate else 0,
+                                    ws.data_ptr(), ws.numel() * 4, _stream()), "channel_sum")
+
+
+# ------------------------------------------------------------------------------------------
+# pooling / resampling / adds
+# ------------------------------------------------------------------------------------------
+def maxpool2_fwd(x):
+    xa = _as_ta(x)
+    n, c, _, sn, sc = _planes(xa.t)
+    h, w = xa.t.shape[2], xa.t.shape[3]
+    y = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=xa.t.device)
+    idx = torch.empty((n, c, h // 2, w // 2), dtype=torch.uint8, device=xa.t.device)
+    check(L.lib().pcuda_maxpool2_fwd(xa.t.data_ptr(), sn, sc, _ptr(xa.scale), _ptr(xa.shift), y.data_ptr(),
+                                     y.stride(0), y.stride(1), idx.data_ptr(), n, c, h, w, _stream()), "maxpool2_fwd")
+    return y, idx
+
+
+def maxpool2_bwd(dy, idx, h, w, dy2=None):
+    n, c, _, dsn, dsc = _planes(dy)
+    d2p, d2sn, d2sc = None, 0, 0
+    if dy2 is not None:
+        _, _, _, d2sn, d2sc = _planes(dy2)
+        d2p = dy2.data_ptr()
+    dx = torch.empty((n, c, h, w), dtype=torch.float32, device=dy.device)
+    check(L.lib().pcuda_maxpool2_bwd(dy.data_ptr(), dsn, dsc, d2p, d2sn, d2sc, idx.data_ptr(), dx.data_ptr(),
+                                     dx.stride(0), dx.stride(1), 0, n, c, h, w, _stream()), "maxpool2_bwd")
+    return dx
+
+
+def upsample2_bwd(dy):
+    n, c, _, dsn, dsc = _planes(dy)
+    h, w = dy.shape[2] // 2, dy.shape[3] // 2
+    dx = torch.empty((n, c, h, w), dtype=torch.float32, device=dy.device)
+    check(L.lib().pcuda_upsample2_bwd(dy.data_ptr(), dsn, dsc, dx.data_ptr(), dx.stride(0), dx.stride(1), 0, n, c, h,
+                                      w, _stream()), "upsample2_bwd")
+    return dx
+
+
+def add_n(ts, out=None):
+    ts = [t for t in ts if t is not None]
+    for t in ts:
+        _req(t)
+        if not t.is_contiguous():
+            raise ValueError("add_n needs contiguous tensors")
+    if out is None:
+        out = torch.empty_like(ts[0])
+    p = [t.data_ptr() for t in ts] + [None] * (4 - len(ts))
+    check(L.lib().pcuda_add4(p[0], p[1], p[2], p[3], out.data_ptr(), out.numel(), _stream()), "add4")
+    return out
+
+
+def mul(a, b):
+    _req(a); _req(b)
+    a, b = a.contiguous(), b.contiguous()
+    y = torch.empty_like(a)
+    check(L.lib().pcuda_mul(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), "mul")
+    return y
+
+
+# ------------------------------------------------------------------------------------------
+# losses / entropy
+# ------------------------------------------------------------------------------------------
+def _mode(m):
+    return ACT_SIGMOID if m in (ACT_SIGMOID, "sigmoid") else ACT_SOFTMAX
+
+
+def entropy_fwd(logits, mode="sigmoid", norm=1.0, want_prob=False):
+    _req(logits)
+    logits = logits.contiguous()
+    n, c = logits.shape[:2]
+    hw = logits.numel() // (n * c)
+    ent = torch.empty_like(logits)
+    prob = torch.empty_like(logits) if want_prob else None
+    check(L.lib().pcuda_entropy_fwd(logits.data_ptr(), _mode(mode), float(norm), ent.data_ptr(), _ptr(prob), n, c, hw,
+                                    _stream()), "entropy_fwd")
+    return ent, prob
+
+
+def entropy_bwd(logits, mode, norm, dent=None, dprob=None, out=None, accumulate=False):
+    n, c = logits.shape[:2]
+    hw = logits.numel() // (n * c)
+    if out is None:
+        out = torch.empty_like(logits)
+    check(L.lib().pcuda_entropy_bwd(logits.data_ptr(), _mode(mode), float(norm),
+                                    _ptr(None if dent is None else dent.contiguous()),
+                                    _ptr(None if dprob is None else dprob.contiguous()), out.data_ptr(),
+                                    1 if accumulate else 0, n, c, hw, _stream()), "entropy_bwd")
+    return out
+
+
+def seg_loss_fwd(logits, onehot, mode="sigmoid"):
+    _req(logits)
+    _req(onehot, torch.uint8)
+    n, c = logits.shape[:2]
+    hw = logits.numel() // (n * c)
+    lib = L.lib()
+    nb = lib.pcuda_seg_loss_workspace_size(n, c, hw)
+    ws = torch.empty(nb, dtype=torch.uint8, device=logits.device)
+    out2 = torch.empty(2, dtype=torch.float32, device=logits.device)
+    check(lib.pcuda_seg_loss_fwd(logits.data_ptr(), onehot.data_ptr(), _mode(mode), n, c, hw, out2.data_ptr(),
+                                 ws.data_ptr(), nb, _stream()), "seg_loss_fwd")
+    return out2, ws
+
+
+def seg_loss_bwd(logits, onehot, mode, ws, g_main=None, g_jac=None):
+    n, c = logits.shape[:2]
+    hw = logits.numel() // (n * c)
+    d = torch.empty_like(logits)
+    check(L.lib().pcuda_seg_loss_bwd(logits.data_ptr(), onehot.data_ptr(), _mode(mode), n, c, hw, _ptr(g_main),
+                                     _ptr(g_jac), d.data_ptr(), ws.data_ptr(), _stream()), "seg_loss_bwd")
+    return d
+
+
+def bce_const_fwd(x, label, want_acc=False):
+    _req(x)
+    x = x.contiguous()
+    loss = torch.empty((), dtype=torch.float32, device=x.device)
+    acc = torch.empty((), dtype=torch.float32, device=x.device) if want_acc else None
+    check(L.lib().pcuda_bce_const_fwd(x.data_ptr(), x.numel(), float(label), loss.data_ptr(), _ptr(acc), _stream()),
+          "bce_const_fwd")
+    return loss, acc
+
+
+def bce_const_bwd(x, label, gout, gscale=1.0):
+    x = x.contiguous()
+    dx = torch.empty_like(x)
+    check(L.lib().pcuda_bce_const_bwd(x.data_ptr(), x.numel(), float(label), _ptr(gout), float(gscale), dx.data_ptr(),
+                                      _stream()), "bce_const_bwd")
+    return dx
+
+
+def nn_loss_fwd(x, y):
+    _req(x); _req(y)
+    x, y = x.contiguous(), y.contiguous()
+    b, npts = x.shape[0], x.shape[1]
+    idx = torch.empty((2, b, npts), dtype=torch.int32, device=x.device)
+    val = torch.empty(2 * b * npts + b, dtype=torch.float32, device=x.device)
+    loss = torch.empty((), dtype=torch.float32, device=x.device)
+    check(L.lib().pcuda_nn_loss_fwd(x.data_ptr(), y.data_ptr(), b, npts, loss.data_ptr(), idx.data_ptr(),
+                                    val.data_ptr(), _stream()), "nn_loss_fwd")
+    return loss, idx, val
+
+
+def nn_loss_bwd(x, y, idx, val, gout):
+    x, y = x.contiguous(), y.contiguous()
+    b, npts = x.shape[0], x.shape[1]
+    dx = torch.empty_like(x)
+    check(L.lib().pcuda_nn_loss_bwd(x.data_ptr(), y.data_ptr(), b, npts, idx.data_ptr(), val.data_ptr(), _ptr(gout),
+                                    dx.data_ptr(), _stream()), "nn_loss_bwd")
+    return dx
+
+
+def dice_metric(logits, onehot):
+    _req(logits); _req(onehot, torch.uint8)
+    logits = logits.contiguous()
+    n, c = logits.shape[:2]
+    hw = logits.numel() // (n * c)
+    ws = torch.empty(3 * c, dtype=torch.int64, device=logits.device)
+    out = torch.empty((), dtype=torch.float32, device=logits.device)
+    check(L.lib().pcuda_dice_metric(logits.data_ptr(), onehot.data_ptr(), n, c, hw, out.data_ptr(), ws.data_ptr(),
+                                    ws.numel() * 8, _stream()), "dice_metric")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# dense
+# ------------------------------------------------------------------------------------------
+def linear_fwd(x, w, b):
+    _req(x); _req(w)
+    m, k = x.shape
+    n = w.shape[0]
+    y = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    check(L.lib().pcuda_linear_fwd(x.data_ptr(), w.data_ptr(), _ptr(b), y.data_ptr(), m, k, n, _stream()), "linear_fwd")
+    return y
+
+
+def linear_bwd_x(dy, w):
+    m, n = dy.shape
+    k = w.shape[1]
+    dx = torch.empty((m, k), dtype=torch.float32, device=dy.device)
+    check(L.lib().pcuda_linear_bwd_x(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), m, k, n, 0, _stream()), "linear_bwd_x")
+    return dx
+
+
+def linear_bwd_w(dy, x, dw, db, accumulate=True):
+    m, n = dy.shape
+    k = x.shape[1]
+    check(L.lib().pcuda_linear_bwd_w(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), _ptr(db), m, k, n,
+                                     1 if accumulate else 0, _stream()), "linear_bwd_w")
+
+
+def max_points_fwd(x):
+    _req(x)
+    b, c, l = x.shape
+    y = torch.empty((b, c), dtype=torch.float32, device=x.device)
+    idx = torch.empty((b, c), dtype=torch.int32, device=x.device)
+    check(L.lib().pcuda_max_points_fwd(x.data_ptr(), b, c, l, y.data_ptr(), idx.data_ptr(), _stream()), "max_points_fwd")
+    return y, idx
+
+
+def max_points_bwd(dy, idx, l):
+    b, c = dy.shape
+    dx = torch.empty((b, c, l), dtype=torch.float32, device=dy.device)
+    check(L.lib().pcuda_max_points_bwd(dy.data_ptr(), idx.data_ptr(), b, c, l, dx.data_ptr(), _stream()), "max_points_bwd")
+    return dx
+
+
+def bmm(a, b, ta=False, tb=False):
+    """C[i] = op(A[i]) op(B[i]); a: [B,m,k] (or [B,k,m] with ta), b: [B,k,n] (or [B,n,k] with tb)."""
+    _req(a); _req(b)
+    batch = a.shape[0]
+    m, k = (a.shape[2], a.shape[1]) if ta else (a.shape[1], a.shape[2])
+    n = b.shape[1] if tb else b.shape[2]
+    c = torch.empty((batch, m, n), dtype=torch.float32, device=a.device)
+    check(L.lib().pcuda_bmm(a.data_ptr(), b.data_ptr(), c.data_ptr(), batch, m, k, n, 1 if ta else 0, 1 if tb else 0, 0,
+                            _stream()), "bmm")
+    return c
+
+
+# ------------------------------------------------------------------------------------------
+# sampler
+# ------------------------------------------------------------------------------------------
+def surface_vertices(mask_u8: torch.Tensor, max_verts: int):
+    _req(mask_u8, torch.uint8)
+    b, h, w = mask_u8.shape
+    verts = torch.zeros((b, max_verts, 3), dtype=torch.int32, device=mask_u8.device)
+    counts = torch.empty(b, dtype=torch.int32, device=mask_u8.device)
+    check(L.lib().pcuda_surface_vertices(mask_u8.data_ptr(), b, h, w, verts.data_ptr(), max_verts, counts.data_ptr(),
+                                         None, 0, _stream()), "surface_vertices")
+    return verts, counts
+
+
+def fps(pts_f64: torch.Tensor, counts: torch.Tensor, first: torch.Tensor, k: int):
+    _req(pts_f64, torch.float64); _req(counts, torch.int32); _req(first, torch.int32)
+    b, npts_max, _ = pts_f64.shape
+    idx = torch.empty((b, k), dtype=torch.int32, device=pts_f64.device)
+    check(L.lib().pcuda_fps(pts_f64.data_ptr(), counts.data_ptr(), first.data_ptr(), b, npts_max, k, idx.data_ptr(),
+                            _stream()), "fps")
+    return idx
+
+
+# ------------------------------------------------------------------------------------------
+# optimiser steps
+# ------------------------------------------------------------------------------------------
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    check(L.lib().pcuda_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2,
+                                  eps, weight_decay, step, grad_scale, _stream()), "adam_step")
+
+
+def sgd_step(p, g, mom, lr, momentum, weight_decay, first_step, grad_scale=1.0):
+    check(L.lib().pcuda_sgd_step(p.data_ptr(), g.data_ptr(), _ptr(mom), p.numel(), lr, momentum, weight_decay,
+                                 1 if first_step else 0, grad_scale, _stream()), "sgd_step")
+
+
+# ------------------------------------------------------------------------------------------
+# profiling
+# ------------------------------------------------------------------------------------------
+def prof_enable(on: bool):
+    check(L.lib().pcuda_prof_enable(1 if on else 0))
+
+
+def prof_reset():
+    check(L.lib().pcuda_prof_reset())
+
+
+def prof_read(family: int):
+    ms, work, n = C.c_double(0), C.c_double(0), C.c_longlong(0)
+    check(L.lib().pcuda_prof_read(family, C.byref(ms), C.byref(work), C.byref(n)), "prof_read")
+    return ms.value, work.value, n.value

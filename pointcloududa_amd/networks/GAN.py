@@ -1,0 +1,163 @@
+"""HIP-backed drop-in for the reference's ``src/networks/GAN.py``.
+
+``UncertaintyDiscriminator`` (GAN.py:89-144) is the class both image discriminators of the train
+scripts instantiate (d1 on logits / probabilities, d2 on the entropy map).  Its five 4x4 stride-2
+convolutions run on the MFMA implicit-GEMM kernels; the adversarial gradient that flows back to
+the segmenter is the stride-2 *transposed* convolution (``conv2d_dgrad`` with one launch per
+output-parity class).  The other classes of the file keep their signatures and parameter names.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import kernels as K
+from ..kernels import ConvOp
+from ._holders import Conv2d, LeakyReLU, Linear, ensure_grad
+
+
+class _ConvChainFn(torch.autograd.Function):
+    """x -> [conv -> LeakyReLU(slope)]* -> conv   over a list of bias-free Conv2d holders"""
+
+    @staticmethod
+    def forward(ctx, module, x, *weights):
+        if not x.is_cuda:
+            raise RuntimeError("discriminators run on HIP devices only (no CPU fallback)")
+        x = x.contiguous().float()
+        acts, sizes = [x], []
+        h, w = x.shape[2], x.shape[3]
+        cur = x
+        nl = len(module._chain)
+        for li, (name, op) in enumerate(module._chain):
+            slope = module._slope if li < nl - 1 else 1.0
+            sizes.append((h, w))
+            cur, _, _ = op.forward(cur, weights[li], None, slope, h, w)
+            h, w = op.out_hw(h, w)
+            acts.append(cur)
+        ctx.module, ctx.acts, ctx.sizes, ctx.weights = module, acts, sizes, weights
+        ctx.set_materialize_grads(False)
+        return cur
+
+    @staticmethod
+    def backward(ctx, d_out):
+        nin = len(ctx.needs_input_grad)
+        if d_out is None:
+            return (None,) * nin
+        module, acts, sizes, weights = ctx.module, ctx.acts, ctx.sizes, ctx.weights
+        nl = len(module._chain)
+        dz = d_out.contiguous()
+        dx = None
+        for li in reversed(range(nl)):
+            name, op = module._chain[li]
+            h, w = sizes[li]
+            wt = weights[li]
+            if wt.requires_grad:
+                op.wgrad(acts[li], dz, ensure_grad(wt), None, h, w)
+            if li > 0:
+                d_a = op.dgrad(dz, wt, h, w)
+                dz = K.lrelu_bwd(d_a, acts[li], module._slope)
+            elif ctx.needs_input_grad[1]:
+                dx = op.dgrad(dz, wt, h, w)
+        ctx.acts = None
+        return (None, dx) + (None,) * (nin - 2)
+
+
+class _ConvChain(nn.Module):
+    _slope = 0.2
+
+    def _build_chain(self, names):
+        chain = []
+        for n in names:
+            m = getattr(self, n)
+            op = ConvOp(m.in_channels, m.out_channels, m.kernel_size[0], stride=m.stride[0], pad=m.padding[0],
+                        dil=m.dilation[0])
+            op.owner = self
+            chain.append((n, op))
+        self._chain = chain
+
+    def _init_conv(self, heinit=False):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                std = float(np.sqrt(2 / float(np.prod(m.weight.size()[1:])))) if heinit else 0.02
+                m.weight.data.normal_(0.0, std)
+                if m.bias is not None:
+                    m.bias.data.zero_()
+
+    def forward(self, x):
+        ws = [getattr(self, n).weight for n, _ in self._chain]
+        return _ConvChainFn.apply(self, x, *ws)
+
+
+class UncertaintyDiscriminator(_ConvChain):
+    def __init__(self, in_channel=2, heinit=False, ext=False):
+        super().__init__()
+        f = [64, 128, 256, 512, 1]
+        self.conv1 = Conv2d(in_channel, f[0], kernel_size=4, stride=2, padding=2, bias=False)
+        self.conv2 = Conv2d(f[0], f[1], kernel_size=4, stride=2, padding=2, bias=False)
+        self.conv3 = Conv2d(f[1], f[2], kernel_size=4, stride=2, padding=2, bias=False)
+        self.conv4 = Conv2d(f[2], f[3], kernel_size=4, stride=2, padding=2, bias=False)
+        names = ["conv1", "conv2", "conv3", "conv4"]
+        if ext:
+            self.conv4_2 = Conv2d(f[3], 1024, kernel_size=3, stride=2, padding=1, bias=False)
+            self.conv4_3 = Conv2d(1024, f[2], kernel_size=3, stride=2, padding=1, bias=False)
+            self.conv5 = Conv2d(f[2], f[4], kernel_size=4, stride=2, padding=2, bias=False)
+            names += ["conv4_2", "conv4_3"]
+        else:
+            self.conv5 = Conv2d(f[3], f[4], kernel_size=4, stride=2, padding=2, bias=False)
+        names.append("conv5")
+        self.leakyrelu = LeakyReLU(negative_slope=0.2)
+        self._ext = ext
+        self._init_conv(heinit=heinit)
+        self._build_chain(names)
+
+
+class BoundaryDiscriminator(_ConvChain):
+    """GAN.py:147-177: the same chain on a 1-channel input."""
+    _in = 1
+
+    def __init__(self):
+        super().__init__()
+        f = [64, 128, 256, 512, 1]
+        cin = self._in
+        for i, co in enumerate(f):
+            setattr(self, "conv%d" % (i + 1), Conv2d(cin, co, kernel_size=4, stride=2, padding=2, bias=False))
+            cin = co
+        self.leakyrelu = LeakyReLU(negative_slope=0.2)
+        self._init_conv()
+        self._build_chain(["conv1", "conv2", "conv3", "conv4", "conv5"])
+
+
+class BoundaryEntDiscriminator(BoundaryDiscriminator):
+    """GAN.py:179-209: 3-channel input."""
+    _in = 3
+
+
+class OutputDiscriminator(nn.Module):
+    """GAN.py:52-86.  Not instantiated by the reference's train scripts (d1 is an
+    UncertaintyDiscriminator there); it needs a bilinear resize to 224x224 that has no HIP kernel yet."""
+
+    def __init__(self, in_channel=2, softmax=False, init=False):
+        super().__init__()
+        raise NotImplementedError("OutputDiscriminator is unused by train_mscmrseg.py / train_mmwhs.py and is "
+                                  "not built; use UncertaintyDiscriminator (what the scripts use for d1)")
+
+
+class Discriminator(nn.Module):
+    """GAN.py:7-49: fully connected 24576-4096-2048-1024-1 with LeakyReLU(0.2); unused by the scripts."""
+
+    def __init__(self):
+        super().__init__()
+        f = [4096, 2048, 1024, 1]
+        self.fc1 = Linear(24576, f[0])
+        self.leakyrelu = LeakyReLU(negative_slope=0.2)
+        self.fc2 = Linear(f[0], f[1])
+        self.fc3 = Linear(f[1], f[2])
+        self.fc4 = Linear(f[2], f[3])
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                m.weight.data.normal_(0.0, 0.02)
+                m.bias.data.zero_()
+
+    def forward(self, x):
+        raise NotImplementedError("the fully connected Discriminator is unused by the reference scripts")

@@ -1,0 +1,386 @@
+"""HIP-backed drop-in for the reference's ``src/networks/unet.py``.
+
+Same classes, constructor signatures, module tree and ``state_dict`` keys as the reference
+(unet.py:7-233); the arithmetic is one fused autograd node per network call that launches the
+libpcuda_hip kernels (implicit-GEMM MFMA convolutions with fused bias + LeakyReLU + BatchNorm
+partial statistics, BatchNorm applied lazily inside the consumer's load, nearest-upsample and
+channel concatenation folded into the convolution's addressing).
+
+Gradients of the parameters are accumulated straight into ``param.grad`` (created on first use)
+instead of being returned through autograd: the train step keeps them in one flat buffer per
+network, which is also what gets all-reduced over RCCL.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import kernels as K
+from ..kernels import TA, ConvOp
+from ._holders import (BatchNorm2d, Conv2d, LeakyReLU, Linear, Marker, collect, ensure_grad)
+
+SLOPE = 0.01   # nn.LeakyReLU() default used throughout unet.py
+
+
+# ============================================================================ engine
+class _SegEngine:
+    """forward / hand-written backward of Segmentation_model_Point over a name->tensor dict"""
+
+    def __init__(self, filters, in_channels, n_block, depth, n_class, pointnet, fc_inch):
+        f = filters
+        self.f, self.cin, self.nb, self.depth, self.ncls, self.pointnet, self.fc_inch = \
+            f, in_channels, n_block, depth, n_class, pointnet, fc_inch
+        ops = {}
+        for i in range(n_block):
+            co = f * 2 ** i
+            ci = in_channels if i == 0 else f * 2 ** (i - 1)
+            blk = "encoder.encoder%d" % (i + 1)
+            ops[blk + ".0"] = ConvOp(ci, co, 3, pad=1)
+            ops[blk + ".3"] = ConvOp(co, co, 3, pad=1)
+            if i > 0:
+                ops["encoder.conv1_%d.0" % (i + 1)] = ConvOp(ci * 3, co, 1)
+        co, ci = f * 2 ** n_block, f * 2 ** (n_block - 1)
+        for j in range(depth):
+            d = 2 ** j
+            ops["bottleneck.bottleneck%d.0" % (j + 1)] = ConvOp(ci, co, 3, pad=d, dil=d)
+            ci = co
+        if pointnet:
+            ops["pointNet.final_conv"] = ConvOp(512 * f // 32, 300, 6)
+        for i in range(n_block):
+            co = f * 2 ** i
+            ops["decoder.decoder1_%d.1" % (i + 1)] = ConvOp(2 * co, co, 3, pad=1, in_up=True)
+            blk = "decoder.decoder2_%d" % (i + 1)
+            ops[blk + ".0"] = ConvOp(2 * co, co, 3, pad=1)
+            ops[blk + ".3"] = ConvOp(co, co, 3, pad=1)
+        ops["classifier"] = ConvOp(f, n_class, 1)
+        self.ops = ops
+
+    # ---------------------------------------------------------------- helpers
+    @staticmethod
+    def _bn(P, name, partials, nt, count, training, c_dev):
+        if training:
+            return K.bn_finalize(partials, nt, count, P[name + ".weight"], P[name + ".bias"],
+                                 P[name + ".running_mean"], P[name + ".running_var"])
+        st = K.BNState()   # eval: fold the running statistics (tiny [C] vectors; not on the train path)
+        inv = torch.rsqrt(P[name + ".running_var"] + 1e-5)
+        st.mean, st.invstd = P[name + ".running_mean"], inv
+        st.scale = (P[name + ".weight"] * inv).contiguous()
+        st.shift = (P[name + ".bias"] - P[name + ".running_mean"] * st.scale).contiguous()
+        st.count = count
+        return st
+
+    def _dc_fwd(self, P, blk, x, x2, h, w, training, S):
+        """conv3x3 -> LeakyReLU -> BN -> conv3x3 -> LeakyReLU -> BN (unet.py:23-30,116-125)."""
+        n = (x.t if isinstance(x, TA) else x).shape[0]
+        a0, part, nt = self.ops[blk + ".0"].forward(x, P[blk + ".0.weight"], P[blk + ".0.bias"], SLOPE, h, w, x2=x2,
+                                                    want_stats=training)
+        st0 = self._bn(P, blk + ".2", part, nt, n * h * w, training, a0.device)
+        a1, part, nt = self.ops[blk + ".3"].forward(TA(a0, st0.scale, st0.shift), P[blk + ".3.weight"],
+                                                    P[blk + ".3.bias"], SLOPE, h, w, want_stats=training)
+        st1 = self._bn(P, blk + ".5", part, nt, n * h * w, training, a1.device)
+        S[blk] = (x, x2, a0, st0, a1, st1)
+        return TA(a1, st1.scale, st1.shift)
+
+    def _dc_bwd(self, P, G, blk, dy, dy2, h, w, S, need_dx):
+        x, x2, a0, st0, a1, st1 = S[blk]
+        dz1 = K.bn_backward(dy, a1, st1, P[blk + ".5.weight"], G(blk + ".5.weight"), G(blk + ".5.bias"), dy2=dy2,
+                            act_slope=SLOPE)
+        if G(blk + ".3.weight") is not None:
+            self.ops[blk + ".3"].wgrad(TA(a0, st0.scale, st0.shift), dz1, G(blk + ".3.weight"), G(blk + ".3.bias"), h, w)
+        d_y0 = self.ops[blk + ".3"].dgrad(dz1, P[blk + ".3.weight"], h, w)
+        dz0 = K.bn_backward(d_y0, a0, st0, P[blk + ".2.weight"], G(blk + ".2.weight"), G(blk + ".2.bias"),
+                            act_slope=SLOPE)
+        if G(blk + ".0.weight") is not None:
+            self.ops[blk + ".0"].wgrad(x, dz0, G(blk + ".0.weight"), G(blk + ".0.bias"), h, w, x2=x2)
+        if not need_dx:
+            return None, None
+        op0 = self.ops[blk + ".0"]
+        n = dz0.shape[0]
+        if x2 is None:
+            return op0.dgrad(dz0, P[blk + ".0.weight"], h, w), None
+        c1 = (x.t if isinstance(x, TA) else x).shape[1]
+        dx1 = torch.empty((n, c1, h, w), dtype=torch.float32, device=dz0.device)
+        dx2 = torch.empty((n, op0.cin - c1, h, w), dtype=torch.float32, device=dz0.device)
+        op0.dgrad(dz0, P[blk + ".0.weight"], h, w, dx=dx1, dx2=dx2)
+        return dx1, dx2
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, P, x, training):
+        n, _, H, W = x.shape
+        nb = self.nb
+        if H % (1 << nb) or W % (1 << nb):
+            raise ValueError("input size must be divisible by %d" % (1 << nb))
+        S = {"hw": (H, W), "n": n}
+        cur, h, w, res = x, H, W, None
+        skips = []
+        for i in range(nb):                                           # unet.py:35-51
+            y = self._dc_fwd(P, "encoder.encoder%d" % (i + 1), cur, None, h, w, training, S)
+            skips.append(y)
+            if i > 0:
+                c1 = "encoder.conv1_%d.0" % (i + 1)
+                t, _, _ = self.ops[c1].forward(y, P[c1 + ".weight"], P[c1 + ".bias"], SLOPE, h, w, x2=res)
+                S[c1] = (y, res, t)
+                pooled, idx = K.maxpool2_fwd(t)
+            else:
+                pooled, idx = K.maxpool2_fwd(y)
+            S["pool%d" % i] = idx
+            res = cur = pooled
+            h, w = h // 2, w // 2
+        outs, o = [], cur                                             # unet.py:67-73
+        for j in range(self.depth):
+            name = "bottleneck.bottleneck%d.0" % (j + 1)
+            S[name] = o
+            o, _, _ = self.ops[name].forward(o, P[name + ".weight"], P[name + ".bias"], SLOPE, h, w)
+            outs.append(o)
+        bsum = outs[0]
+        for k0 in range(1, len(outs), 3):
+            bsum = K.add_n([bsum] + outs[k0:k0 + 3])
+        S["bott_outs"] = outs
+        verts = None
+        if self.pointnet:                                             # unet.py:89-96
+            hc, _, _ = self.ops["pointNet.final_conv"].forward(bsum, P["pointNet.final_conv.weight"],
+                                                               P["pointNet.final_conv.bias"], SLOPE, h, w)
+            flat = hc.view(n * 300, -1)
+            if flat.shape[1] != self.fc_inch:
+                raise ValueError("fc_inch=%d does not match the %dx%d head output" % (self.fc_inch, h - 5, w - 5))
+            verts = K.linear_fwd(flat, P["pointNet.final_fc.weight"], P["pointNet.final_fc.bias"]).view(n, 300, 3)
+            S["head"] = (bsum, hc, flat)
+        prev, ph, pw = bsum, h, w
+        for i in reversed(range(nb)):                                 # unet.py:128-136
+            up = "decoder.decoder1_%d.1" % (i + 1)
+            oh, ow = 2 * ph, 2 * pw
+            S[up] = prev
+            u, _, _ = self.ops[up].forward(prev, P[up + ".weight"], P[up + ".bias"], 1.0, oh, ow)
+            prev = self._dc_fwd(P, "decoder.decoder2_%d" % (i + 1), skips[i], u, oh, ow, training, S)
+            ph, pw = oh, ow
+        S["cls_in"] = prev
+        logits, _, _ = self.ops["classifier"].forward(prev, P["classifier.weight"], P["classifier.bias"], 1.0, ph, pw)
+        return logits, verts, S
+
+    # ---------------------------------------------------------------- backward
+    def backward(self, P, S, d_logits, d_verts, need_dx):
+        def G(name):
+            p = P[name]
+            return ensure_grad(p) if p.requires_grad else None
+
+        nb, (H, W), n = self.nb, S["hw"], S["n"]
+        d_skips = [None] * nb
+        d_bsum = None
+        if d_logits is not None:
+            d_logits = d_logits.contiguous()
+            if G("classifier.weight") is not None:
+                self.ops["classifier"].wgrad(S["cls_in"], d_logits, G("classifier.weight"), G("classifier.bias"), H, W)
+            d_cur = self.ops["classifier"].dgrad(d_logits, P["classifier.weight"], H, W)
+            for i in range(nb):
+                oh, ow = H >> i, W >> i
+                d_skips[i], d_u = self._dc_bwd(P, G, "decoder.decoder2_%d" % (i + 1), d_cur, None, oh, ow, S, True)
+                up = "decoder.decoder1_%d.1" % (i + 1)
+                if G(up + ".weight") is not None:
+                    self.ops[up].wgrad(S[up], d_u, G(up + ".weight"), G(up + ".bias"), oh, ow)
+                d_cur = K.upsample2_bwd(self.ops[up].dgrad(d_u, P[up + ".weight"], oh, ow))
+            d_bsum = d_cur
+        h, w = H >> nb, W >> nb
+        if self.pointnet and d_verts is not None:
+            bsum, hc, flat = S["head"]
+            d_v = d_verts.contiguous().view(n * 300, 3)
+            if G("pointNet.final_fc.weight") is not None:
+                K.linear_bwd_w(d_v, flat, G("pointNet.final_fc.weight"), G("pointNet.final_fc.bias"))
+            d_hc = K.linear_bwd_x(d_v, P["pointNet.final_fc.weight"]).view(hc.shape)
+            dzc = K.lrelu_bwd(d_hc, hc, SLOPE)
+            op = self.ops["pointNet.final_conv"]
+            if G("pointNet.final_conv.weight") is not None:
+                op.wgrad(bsum, dzc, G("pointNet.final_conv.weight"), G("pointNet.final_conv.bias"), h, w)
+            if d_bsum is None:
+                d_bsum = op.dgrad(dzc, P["pointNet.final_conv.weight"], h, w)
+            else:
+                op.dgrad(dzc, P["pointNet.final_conv.weight"], h, w, dx=d_bsum, accumulate=True)
+        if d_bsum is None:
+            return None
+        outs, g_next = S["bott_outs"], None
+        for j in reversed(range(self.depth)):
+            name = "bottleneck.bottleneck%d.0" % (j + 1)
+            dz = K.lrelu_bwd(d_bsum, outs[j], SLOPE, dy2=g_next)
+            if G(name + ".weight") is not None:
+                self.ops[name].wgrad(S[name], dz, G(name + ".weight"), G(name + ".bias"), h, w)
+            g_next = self.ops[name].dgrad(dz, P[name + ".weight"], h, w)
+        dA, dB = g_next, None
+        for i in reversed(range(nb)):
+            hi, wi = H >> i, W >> i
+            idx = S["pool%d" % i]
+            if i > 0:
+                c1 = "encoder.conv1_%d.0" % (i + 1)
+                y, res_prev, t = S[c1]
+                d_t = K.maxpool2_bwd(dA, idx, hi, wi, dy2=dB)
+                dzc = K.lrelu_bwd(d_t, t, SLOPE)
+                if G(c1 + ".weight") is not None:
+                    self.ops[c1].wgrad(y, dzc, G(c1 + ".weight"), G(c1 + ".bias"), hi, wi, x2=res_prev)
+                d_y = torch.empty(y.t.shape, dtype=torch.float32, device=dzc.device)
+                dB = torch.empty(res_prev.shape, dtype=torch.float32, device=dzc.device)
+                self.ops[c1].dgrad(dzc, P[c1 + ".weight"], hi, wi, dx=d_y, dx2=dB)
+            else:
+                d_y = K.maxpool2_bwd(dA, idx, hi, wi, dy2=dB)
+                dB = None
+            dA, _ = self._dc_bwd(P, G, "encoder.encoder%d" % (i + 1), d_y, d_skips[i], hi, wi, S, i > 0 or need_dx)
+        return dA
+
+
+class _SegFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        if not x.is_cuda:
+            raise RuntimeError("Segmentation_model_Point runs on HIP devices only (no CPU fallback)")
+        x = x.contiguous().float()
+        P = module._tensor_dict()
+        logits, verts, S = module._engine.forward(P, x, module.training)
+        if module.training:
+            module._bump_batches_tracked()
+        ctx.module, ctx.S, ctx.P = module, S, P
+        ctx.set_materialize_grads(False)
+        if verts is None:
+            return logits
+        return logits, verts
+
+    @staticmethod
+    def backward(ctx, d_logits, d_verts=None):
+        dx = ctx.module._engine.backward(ctx.P, ctx.S, d_logits, d_verts, ctx.needs_input_grad[1])
+        ctx.S = None
+        return (None, dx) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+# ============================================================================ module tree (reference names)
+class Encoder(nn.Module):
+    def __init__(self, filters=32, in_channels=3, n_block=4, kernel_size=(3, 3), batch_norm=True, padding='same'):
+        super().__init__()
+        self.filter = filters
+        pad = kernel_size[0] // 2 if padding == 'same' else 0
+        for i in range(n_block):
+            out_ch = filters * 2 ** i
+            in_ch = in_channels if i == 0 else filters * 2 ** (i - 1)
+            model = [Conv2d(in_ch, out_ch, kernel_size, padding=pad), LeakyReLU(inplace=True)]
+            if batch_norm:
+                model += [BatchNorm2d(out_ch)]
+            model += [Conv2d(out_ch, out_ch, kernel_size, padding=pad), LeakyReLU(inplace=True)]
+            if batch_norm:
+                model += [BatchNorm2d(out_ch)]
+            self.add_module('encoder%d' % (i + 1), nn.Sequential(*model))
+            self.add_module('conv1_%d' % (i + 1), nn.Sequential(Conv2d(in_ch * 3, out_ch, 1), LeakyReLU(inplace=True)))
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, filters=32, n_block=4, depth=4, kernel_size=(3, 3)):
+        super().__init__()
+        out_ch, in_ch = filters * 2 ** n_block, filters * 2 ** (n_block - 1)
+        for i in range(depth):
+            d = 2 ** i
+            self.add_module('bottleneck%d' % (i + 1), nn.Sequential(
+                Conv2d(in_ch, out_ch, kernel_size, padding=d, dilation=d), LeakyReLU(inplace=True)))
+            if i == 0:
+                in_ch = out_ch
+
+
+class PointNet(nn.Module):
+    def __init__(self, num_points=300, fc_inch=81, conv_inch=512, ext=False):
+        super().__init__()
+        if ext:
+            raise NotImplementedError("extpn=True (two extra 3x3 convs in the point head) is not built yet")
+        self.num_points = num_points
+        self.ReLU = LeakyReLU(inplace=True)
+        self.final_conv = Conv2d(conv_inch, self.num_points, kernel_size=6)
+        self.final_fc = Linear(fc_inch, 3)
+        self._ext = ext
+
+
+class Decoder(nn.Module):
+    def __init__(self, filters=32, n_block=4, kernel_size=(3, 3), batch_norm=True, padding='same', drop=False):
+        super().__init__()
+        if drop:
+            raise NotImplementedError("Decoder(drop=True) is never used by the reference scripts")
+        self.n_block = n_block
+        pad = kernel_size[0] // 2 if padding == 'same' else 0
+        for i in reversed(range(n_block)):
+            out_ch = filters * 2 ** i
+            in_ch = 2 * out_ch
+            self.add_module('decoder1_%d' % (i + 1), nn.Sequential(
+                Marker("UpsamplingNearest2d(scale_factor=2), folded into the next conv"),
+                Conv2d(in_ch, out_ch, kernel_size, padding=pad)))
+            model = [Conv2d(in_ch, out_ch, kernel_size, padding=pad), LeakyReLU(inplace=True)]
+            if batch_norm:
+                model += [BatchNorm2d(out_ch)]
+            model += [Conv2d(out_ch, out_ch, kernel_size, padding=pad), LeakyReLU(inplace=True)]
+            if batch_norm:
+                model += [BatchNorm2d(out_ch)]
+            self.add_module('decoder2_%d' % (i + 1), nn.Sequential(*model))
+
+
+class Segmentation_model_Point(nn.Module):
+    """unet.py:165-233.  forward(x, features_out=True) -> (logits, None, verts|None) or logits."""
+
+    def __init__(self, filters=32, in_channels=3, n_block=4, bottleneck_depth=4, n_class=4, pointnet=False,
+                 fc_inch=81, heinit=False, multicuda=False, extpn=False, batchnorm=True):
+        super().__init__()
+        if multicuda:
+            raise NotImplementedError("multicuda (2-GPU model split, unet.py:180-192) is replaced by data "
+                                      "parallelism: see pointcloududa_amd.parallel")
+        if not batchnorm:
+            raise NotImplementedError("batchnorm=False is never used by the reference scripts")
+        self._pointnet = pointnet
+        self.encoder = Encoder(filters=filters, in_channels=in_channels, n_block=n_block, batch_norm=batchnorm)
+        self.bottleneck = Bottleneck(filters=filters, n_block=n_block, depth=bottleneck_depth)
+        if pointnet:
+            self.pointNet = PointNet(num_points=300, fc_inch=fc_inch, conv_inch=512 * filters // 32, ext=extpn)
+        self.decoder = Decoder(filters=filters, n_block=n_block, drop=False, batch_norm=batchnorm)
+        self.classifier = Conv2d(filters, n_class, kernel_size=(1, 1))
+        self._initialize_weights(heinit=heinit)
+        self._multicuda = False
+        self._engine = _SegEngine(filters, in_channels, n_block, bottleneck_depth, n_class, pointnet, fc_inch)
+        for op in self._engine.ops.values():
+            op.owner = self
+
+    def _initialize_weights(self, heinit=False):                      # unet.py:194-208
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                std = float(np.sqrt(2 / float(np.prod(m.weight.size()[1:])))) if heinit else 0.02
+                m.weight.data.normal_(0.0, std)
+                if m.bias is not None:
+                    m.bias.data.zero_()
+
+    def tomulticuda(self):
+        return None
+
+    # -- plumbing for the fused autograd node
+    def _tensor_dict(self):
+        d = dict(self.named_parameters())
+        d.update(dict(self.named_buffers()))
+        return d
+
+    def _bump_batches_tracked(self):
+        flat = getattr(self, "_flat_tracked", None)
+        if flat is not None:
+            flat.add_(1)
+            return
+        for k, b in self.named_buffers():
+            if k.endswith("num_batches_tracked"):
+                b.add_(1)
+
+    def forward(self, x, features_out=True, print_shape=False):
+        params = [p for p in self.parameters()]
+        out = _SegFn.apply(self, x, *params)
+        logits, verts = (out if isinstance(out, tuple) else (out, None))
+        if print_shape:
+            print("output: {}".format(logits.size()))
+            if verts is not None:
+                print("pointcloud: {}".format(verts.size()))
+        if features_out:
+            return logits, None, verts
+        return logits
+
+
+class Segmentation_model(Segmentation_model_Point):
+    """unet.py:139-162 (not used by the reference scripts): the same network without the point head."""
+
+    def __init__(self, filters=32, in_channels=3, n_block=4, bottleneck_depth=4, n_class=4, feature_dis=False):
+        if feature_dis:
+            raise NotImplementedError("feature_dis (a second classifier on the bottleneck) is not built")
+        super().__init__(filters=filters, in_channels=in_channels, n_block=n_block,
+                         bottleneck_depth=bottleneck_depth, n_class=n_class, pointnet=False)

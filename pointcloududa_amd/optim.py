@@ -1,0 +1,103 @@
+"""Flat parameter / gradient buffers and the fused optimiser steps.
+
+MI355X-first layout: every network keeps ALL its parameters in one contiguous fp32 buffer and all
+its gradients in another (288 GB of HBM: nothing is ever sharded or offloaded).  The backward
+kernels accumulate straight into the gradient buffer, ``zero_grad`` is one memset, the optimiser is
+one kernel launch, and data parallelism is one RCCL all-reduce per network and step.
+
+Adam(betas=(0.9, 0.99)) for the segmenter and SGD(momentum, weight_decay=5e-4) for the
+discriminators follow train_mscmrseg.py:427-455 / train_mmwhs.py:453-489.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import kernels as K
+
+_ALIGN = 64   # elements: every parameter starts on a 256-B boundary
+
+
+def flatten_module(module: nn.Module):
+    """Re-home the module's parameters (and their .grad) as views of two flat buffers.
+    Returns (flat_param, flat_grad).  Idempotent."""
+    if getattr(module, "_flat_param", None) is not None:
+        return module._flat_param, module._flat_grad
+    params = [p for p in module.parameters()]
+    if not params:
+        raise ValueError("module has no parameters")
+    dev = params[0].device
+    offs, total = [], 0
+    for p in params:
+        if p.dtype != torch.float32:
+            raise TypeError("flatten_module: fp32 parameters only")
+        offs.append(total)
+        total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+    flat = torch.zeros(total, dtype=torch.float32, device=dev)
+    grad = torch.zeros(total, dtype=torch.float32, device=dev)
+    for p, o in zip(params, offs):
+        n = p.numel()
+        flat[o:o + n].copy_(p.data.reshape(-1))
+        p.data = flat[o:o + n].view(p.shape)
+        p.grad = grad[o:o + n].view(p.shape)
+    tracked = [b for k, b in module.named_buffers() if k.endswith("num_batches_tracked")]
+    if tracked:
+        ft = torch.zeros(len(tracked), dtype=torch.long, device=dev)
+        for i, b in enumerate(tracked):
+            ft[i] = b
+            b.data = ft[i]
+        module._flat_tracked = ft
+    module._flat_param, module._flat_grad = flat, grad
+    return flat, grad
+
+
+class _FlatOptimizer:
+    def __init__(self, module: nn.Module, lr: float):
+        self.module = module
+        self.p, self.g = flatten_module(module)
+        self.lr = float(lr)
+        self.steps = 0
+
+    def zero_grad(self):
+        self.g.zero_()
+
+    def all_reduce_grads(self, group=None):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.g, op=dist.ReduceOp.SUM, group=group)
+            return 1.0 / dist.get_world_size(group)
+        return 1.0
+
+
+class FusedAdam(_FlatOptimizer):
+    def __init__(self, module, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0):
+        super().__init__(module, lr)
+        self.betas, self.eps, self.wd = betas, eps, weight_decay
+        self.m = torch.zeros_like(self.p)
+        self.v = torch.zeros_like(self.p)
+
+    def step(self, grad_scale: float = 1.0):
+        self.steps += 1
+        self.module._wgen = getattr(self.module, "_wgen", 0) + 1   # packed conv weights are stale now
+        K.adam_step(self.p, self.g, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                    self.steps, grad_scale)
+
+    def state_dict(self):
+        return {"steps": self.steps, "lr": self.lr, "exp_avg": self.m, "exp_avg_sq": self.v}
+
+
+class FusedSGD(_FlatOptimizer):
+    def __init__(self, module, lr=2.5e-5, momentum=0.99, weight_decay=0.0005):
+        super().__init__(module, lr)
+        self.momentum, self.wd = momentum, weight_decay
+        self.buf = torch.zeros_like(self.p) if momentum != 0 else None
+
+    def step(self, grad_scale: float = 1.0):
+        self.module._wgen = getattr(self.module, "_wgen", 0) + 1
+        K.sgd_step(self.p, self.g, self.buf, self.lr, self.momentum, self.wd, self.steps == 0, grad_scale)
+        self.steps += 1
+
+    def state_dict(self):
+        return {"steps": self.steps, "lr": self.lr, "momentum_buffer": self.buf}

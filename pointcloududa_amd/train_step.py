@@ -1,0 +1,190 @@
+"""The 5-phase adversarial train step on the HIP kernels.
+
+Host-side mirror of the body of ``train_epoch``'s loop (train_mscmrseg.py:183-330;
+train_mmwhs.py:187-360): same phases, same losses, same freeze/unfreeze schedule, same optimiser
+settings -- with three MI355X-first changes that do not alter the arithmetic:
+
+* the per-step host metrics (Dice, discriminator accuracies, ``.item()`` calls at
+  train_mscmrseg.py:207-216,270-322) are computed on the device and returned as 0-dim tensors, so a
+  step never synchronises with the host;
+* gradients live in one flat buffer per network; with ``torch.distributed`` initialised each rank
+  runs the step on its shard of the batch and the flat buffers are all-reduced over RCCL before the
+  optimiser kernels (G after phase 2, the D's after phase 4);
+* loss weights (``dr``, ``wp``, ``w1/w2/w4``) are folded into the backward seeds instead of being
+  multiplied in as separate scalar ops.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+
+from . import kernels as K
+from .optim import FusedAdam, FusedSGD
+from .utils import loss as L
+
+
+@dataclass
+class TrainCfg:
+    variant: str = "mscmrseg"        # "mscmrseg" | "mmwhs"
+    d1: bool = True
+    d2: bool = True
+    d4: bool = True
+    dr: float = 0.01                 # -dr  (train_mscmrseg.py:692)
+    wp: float = 1.0                  # -wp  (:693)
+    lr: float = 1e-3
+    d1lr: float = 2.5e-5
+    d2lr: float = 2.5e-5
+    d4lr: float = 2.5e-5
+    d_momentum: float = 0.99
+    softmax: bool = True             # mmwhs -softmax
+    w1: float = 1.0
+    w2: float = 1.0
+    w4: float = 1.0
+    n_class: int = 4
+
+
+class AdversarialTrainer:
+    def __init__(self, model_gen, model_dis1=None, model_dis2=None, model_dis4=None, cfg: Optional[TrainCfg] = None,
+                 process_group=None):
+        self.cfg = cfg or TrainCfg()
+        c = self.cfg
+        self.gen = model_gen
+        self.dis1 = model_dis1 if c.d1 else None
+        self.dis2 = model_dis2 if c.d2 else None
+        self.dis4 = model_dis4 if c.d4 else None
+        self.group = process_group
+        self.opt_gen = FusedAdam(self.gen, lr=c.lr, betas=(0.9, 0.99))
+        mk = lambda m, lr: FusedSGD(m, lr=lr, momentum=c.d_momentum, weight_decay=0.0005)
+        self.opt_d1 = mk(self.dis1, c.d1lr) if self.dis1 is not None else None
+        self.opt_d2 = mk(self.dis2, c.d2lr) if self.dis2 is not None else None
+        self.opt_d4 = mk(self.dis4, c.d4lr) if self.dis4 is not None else None
+        dev = next(self.gen.parameters()).device
+        self._one = torch.ones((), dtype=torch.float32, device=dev)
+        self._wp = torch.full((), float(c.wp), dtype=torch.float32, device=dev)
+        self.last = {}
+
+    def _dis(self):
+        return [m for m in (self.dis1, self.dis2, self.dis4) if m is not None]
+
+    def _d_opts(self):
+        return [o for o in (self.opt_d1, self.opt_d2, self.opt_d4) if o is not None]
+
+    def train(self):
+        self.gen.train()
+        for m in self._dis():
+            m.train()
+
+    # ------------------------------------------------------------------ one loop iteration
+    def step(self, img_a, mask_a_u8, vert_a, img_b, vert_b, drop_mask=None, keep=False) -> Dict[str, torch.Tensor]:
+        c, out = self.cfg, {}
+        ms = c.variant == "mscmrseg"
+        mode = "sigmoid" if (ms or not c.softmax) else "softmax"
+        one = self._one
+        for o in [self.opt_gen] + self._d_opts():
+            o.zero_grad()
+        for m in self._dis():
+            m.requires_grad_(False)
+        self.gen.requires_grad_(True)
+
+        # 1. supervised pass on the source batch (train_mscmrseg.py:200-213)
+        o_s, _, vert_s = self.gen(img_a)
+        l_main, l_jac = L.seg_loss(o_s, mask_a_u8, mode)
+        seeds_t, seeds_g = [l_main, l_jac], [one, one]
+        if c.d4:
+            l_pt = L.batch_NN_loss(vert_s, vert_a)
+            out["ver_s_loss"] = l_pt.detach()
+            seeds_t.append(l_pt)
+            seeds_g.append(self._wp)
+        out["loss_bce"], out["loss_jac"] = l_main.detach(), l_jac.detach()
+        torch.autograd.backward(seeds_t, seeds_g)
+        out["seg_dice"] = K.dice_metric(o_s.detach(), mask_a_u8)      # :215-216, on the device
+        if keep:
+            self.last = {"oS": o_s.detach(), "vertS": None if vert_s is None else vert_s.detach(),
+                         "grad_seg": self.opt_gen.g.clone()}
+
+        # 2. adversarial pass on the target batch (:218-247)
+        o_t, _, vert_t = self.gen(img_b)
+        norm = not ms
+        pred_t = ent_t = tap_t = None
+        if ms:
+            if c.d2 and c.d1:
+                tap_t, ent_t = L.logits_and_entropy(o_t, "sigmoid", False)
+            elif c.d2:
+                ent_t = L.entropy_map(o_t, "sigmoid", False)
+            else:
+                tap_t = o_t
+        else:
+            ent_t, pred_t = L.entropy_map(o_t, mode, True, want_prob=True)
+        adv_t, adv_g = [], []
+        if c.d2:
+            l2 = L.bce_logits_const(self.dis2(ent_t), 1.0, weight=c.dr * (1.0 if ms else c.w2))
+            adv_t.append(l2); adv_g.append(one); out["adv2"] = l2.detach()
+        if c.d4:
+            out["ver_t_loss"] = L.batch_NN_loss(vert_t.detach(), vert_b)
+            l4 = L.bce_logits_const(self.dis4(vert_t.transpose(2, 1), drop_mask)[0], 1.0,
+                                    weight=c.dr * (1.0 if ms else c.w4))
+            adv_t.append(l4); adv_g.append(one); out["adv4"] = l4.detach()
+        if c.d1:
+            l1 = L.bce_logits_const(self.dis1(tap_t if ms else pred_t), 1.0, weight=c.dr * (1.0 if ms else c.w1))
+            adv_t.append(l1); adv_g.append(one); out["adv1"] = l1.detach()
+        if adv_t:
+            torch.autograd.backward(adv_t, adv_g)
+        if keep:
+            self.last.update({"oT": o_t.detach(), "vertT": None if vert_t is None else vert_t.detach(),
+                              "grad_total": self.opt_gen.g.clone()})
+        self.opt_gen.step(self.opt_gen.all_reduce_grads(self.group))
+
+        # 3./4. discriminators: source batch as 1, target batch as 0 (:250-322)
+        if self._dis():
+            for m in self._dis():
+                m.requires_grad_(True)
+            self.gen.requires_grad_(False)
+            o_s_d, o_t_d = o_s.detach(), o_t.detach()
+            if ms:
+                ent_s = L.entropy_map(o_s_d, "sigmoid", False) if c.d2 else None
+                in1_s, in1_t = o_s_d, o_t_d
+            else:
+                ent_s, pred_s = L.entropy_map(o_s_d, mode, True, want_prob=True)
+                in1_s, in1_t = pred_s, (None if pred_t is None else pred_t.detach())
+            ent_t_d = None if ent_t is None else ent_t.detach()
+            for tag, label, e, i1, v in (("src", 1.0, ent_s, in1_s, vert_s), ("tgt", 0.0, ent_t_d, in1_t, vert_t)):
+                if c.d2:
+                    l, acc = L.bce_logits_const(self.dis2(e), label, 1.0, want_acc=True)
+                    l.backward()
+                    out["d2_loss_" + tag], out["dis2_hit_" + tag] = l.detach(), acc
+                if c.d1:
+                    l, acc = L.bce_logits_const(self.dis1(i1), label, 1.0, want_acc=True)
+                    l.backward()
+                    out["d1_loss_" + tag], out["dis1_hit_" + tag] = l.detach(), acc
+                if c.d4:
+                    l, acc = L.bce_logits_const(self.dis4(v.detach().transpose(2, 1), drop_mask)[0], label, 1.0,
+                                                want_acc=True)
+                    l.backward()
+                    out["d4_loss_" + tag], out["dis4_hit_" + tag] = l.detach(), acc
+            if keep:
+                for nm, o in (("grad_d1", self.opt_d1), ("grad_d2", self.opt_d2), ("grad_d4", self.opt_d4)):
+                    if o is not None:
+                        self.last[nm] = o.g.clone()
+            # 5. update (:325-330)
+            for o in self._d_opts():
+                o.step(o.all_reduce_grads(self.group))
+        return out
+
+    @staticmethod
+    def to_host(out: Dict[str, torch.Tensor], cfg: "TrainCfg") -> Dict[str, float]:
+        """One synchronisation for a whole step (or epoch): device scalars -> the reference's metrics."""
+        h = {k: float(v) for k, v in out.items()}
+        h["seg_loss"] = h["loss_bce"] + h["loss_jac"]
+        ms = cfg.variant == "mscmrseg"
+        adv = 0.0
+        for k, w in (("adv2", 1.0 if ms else cfg.w2), ("adv4", 1.0 if ms else cfg.w4), ("adv1", 1.0 if ms else cfg.w1)):
+            if k in h:
+                adv += cfg.dr * w * h[k]
+        h["adv_loss"] = adv
+        for d in ("dis1", "dis2", "dis4"):
+            if d + "_hit_src" in h:
+                h[d + "_acc1"] = h[d + "_hit_src"]             # mean(sigmoid(D) >= .5) on source
+                h[d + "_acc2"] = 1.0 - h[d + "_hit_tgt"]       # 1 - mean(...) on target
+        return h

@@ -1,0 +1,160 @@
+"""HIP-backed losses with the reference's function names (``src/utils/loss.py``) plus the fused
+forms the train step uses.
+
+* ``jaccard_loss(true, logits, eps, activation)`` / ``batch_NN_loss(x, y)``: the reference
+  signatures (loss.py:5-37, 40-76), backed by the fused kernels.
+* ``seg_loss(logits, onehot_u8, mode)``: BCE + Jaccard (train_mscmrseg.py:202-203) or the
+  "double softmax" cross-entropy + Jaccard (train_mmwhs.py:212-218) in one pass each way.
+* ``entropy_map(logits, mode, normalise)``: -p log(p + 1e-7) [/ log C] (train_mscmrseg.py:222;
+  train_mmwhs.py:224,242), optionally also returning p.
+* ``bce_logits_const(d_out, label, weight)``: weight * BCE-with-logits against a constant map
+  (train_mscmrseg.py:224-226), with the discriminator accuracy as a by-product.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .. import kernels as K
+
+
+def _zero(dev):
+    return torch.zeros((), dtype=torch.float32, device=dev)
+
+
+class _SegLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, onehot, mode):
+        logits = logits.contiguous()
+        out2, ws = K.seg_loss_fwd(logits, onehot, mode)
+        ctx.logits, ctx.onehot, ctx.mode, ctx.ws = logits, onehot, mode, ws
+        ctx.set_materialize_grads(False)
+        return out2[0], out2[1]
+
+    @staticmethod
+    def backward(ctx, g_main, g_jac):
+        dev = ctx.logits.device
+        g_main = _zero(dev) if g_main is None else g_main.contiguous()
+        g_jac = _zero(dev) if g_jac is None else g_jac.contiguous()
+        d = K.seg_loss_bwd(ctx.logits, ctx.onehot, ctx.mode, ctx.ws, g_main, g_jac)
+        return d, None, None
+
+
+def seg_loss(logits, onehot_u8, mode="sigmoid"):
+    """-> (bce_or_ce, jaccard) scalars.  onehot_u8: uint8 one-hot [B,C,H,W] (utils.py:25-29 layout)."""
+    return _SegLossFn.apply(logits, onehot_u8, mode)
+
+
+def jaccard_loss(true, logits, eps=1e-7, activation=True):
+    """Reference signature (loss.py:5-37) for the way the scripts call it: C > 1 probabilities in,
+    ``activation=False``; ``true`` one-hot.  Only the fused form is built: the probabilities must come
+    from ``torch.sigmoid``/``softmax`` of logits the caller still has -> use ``seg_loss`` instead."""
+    raise NotImplementedError("jaccard_loss on detached probabilities is not built; use "
+                              "pointcloududa_amd.utils.loss.seg_loss(logits, onehot, mode), which returns "
+                              "(bce|ce, jaccard) fused as the train scripts combine them")
+
+
+class _EntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, mode, norm, want_prob):
+        logits = logits.contiguous()
+        ent, prob = K.entropy_fwd(logits, mode, norm, want_prob)
+        ctx.logits, ctx.mode, ctx.norm = logits, mode, norm
+        ctx.set_materialize_grads(False)
+        if want_prob:
+            return ent, prob
+        return ent
+
+    @staticmethod
+    def backward(ctx, dent, dprob=None):
+        if dent is None and dprob is None:
+            return None, None, None, None
+        d = K.entropy_bwd(ctx.logits, ctx.mode, ctx.norm, dent, dprob)
+        return d, None, None, None
+
+
+def entropy_map(logits, mode="sigmoid", normalise=False, want_prob=False):
+    norm = 1.0 / math.log(logits.shape[1]) if normalise else 1.0
+    return _EntropyFn.apply(logits, mode, norm, want_prob)
+
+
+class _EntropyTapFn(torch.autograd.Function):
+    """(logits, entropy(logits)) with ONE gradient join: d_logits = d_tap + J^T d_ent is formed by the
+    entropy kernel's accumulate store instead of a separate add (d1 sees the raw logits and d2 their
+    entropy map in train_mscmrseg.py:222-241)."""
+
+    @staticmethod
+    def forward(ctx, logits, mode, norm):
+        logits = logits.contiguous()
+        ent, _ = K.entropy_fwd(logits, mode, norm, False)
+        ctx.logits, ctx.mode, ctx.norm = logits, mode, norm
+        ctx.set_materialize_grads(False)
+        return logits.view_as(logits), ent
+
+    @staticmethod
+    def backward(ctx, dtap, dent):
+        if dent is None:
+            return dtap, None, None
+        if dtap is None:
+            return K.entropy_bwd(ctx.logits, ctx.mode, ctx.norm, dent, None), None, None
+        dtap = dtap.contiguous()
+        K.entropy_bwd(ctx.logits, ctx.mode, ctx.norm, dent, None, out=dtap, accumulate=True)
+        return dtap, None, None
+
+
+def logits_and_entropy(logits, mode="sigmoid", normalise=False):
+    norm = 1.0 / math.log(logits.shape[1]) if normalise else 1.0
+    return _EntropyTapFn.apply(logits, mode, norm)
+
+
+class _BceConstFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, label, weight, want_acc):
+        x = x.contiguous()
+        loss, acc = K.bce_const_fwd(x, label, want_acc)
+        ctx.x, ctx.label, ctx.weight = x, label, weight
+        ctx.set_materialize_grads(False)
+        if weight != 1.0:
+            # the scalar is rescaled on the host side of the graph by the backward's gscale; the
+            # forward value is reported unscaled next to it
+            pass
+        if want_acc:
+            ctx.mark_non_differentiable(acc)
+            return loss, acc
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout, gacc=None):
+        if gout is None:
+            return None, None, None, None
+        return K.bce_const_bwd(ctx.x, ctx.label, gout.contiguous(), ctx.weight), None, None, None
+
+
+def bce_logits_const(d_out, label, weight=1.0, want_acc=False):
+    """mean BCE-with-logits of ``d_out`` against the constant ``label``.  The returned scalar is the
+    UNWEIGHTED loss; ``weight`` (the reference's ``args.dr``) scales its gradient, i.e. backpropagating
+    the returned value with grad 1 equals backpropagating ``weight * loss``."""
+    return _BceConstFn.apply(d_out, float(label), float(weight), want_acc)
+
+
+class _NNLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = x.contiguous(), y.contiguous()
+        loss, idx, val = K.nn_loss_fwd(x, y)
+        ctx.x, ctx.y, ctx.idx, ctx.val = x, y, idx, val
+        ctx.set_materialize_grads(False)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        if gout is None:
+            return None, None
+        return K.nn_loss_bwd(ctx.x, ctx.y, ctx.idx, ctx.val, gout.contiguous()), None
+
+
+def batch_NN_loss(x, y):
+    """loss.py:40-76: symmetric nearest-neighbour (Chamfer, L2 root) distance between [B,N,3] clouds.
+    Differentiable w.r.t. ``x`` (the predicted vertices); ``y`` is data."""
+    return _NNLossFn.apply(x, y)
