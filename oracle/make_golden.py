@@ -110,17 +110,32 @@ def gold_param_counts():
 
 
 # --------------------------------------------------------------------------- #
-def gold_seg(tag, cfg: ON.SegCfg, b, hw, seed, full_tensors):
+def gold_seg(tag, cfg: ON.SegCfg, b, hw, seed, full_tensors, softmax=False):
+    """forward + backward of the segmenter under the reference's OWN supervised loss
+    (train_mscmrseg.py:202-209: BCE + Jaccard [+ point NN loss]; train_mmwhs.py:212-218 when
+    ``softmax``).  A random-weight loss would make every weight gradient a sum of random-sign
+    terms, i.e. cancellation-dominated and ill-conditioned (1e-4 input noise moves such a gradient
+    by percents even in the fp32 reference): the real loss gives coherent gradients."""
     params = ON.make_params(ON.seg_param_shapes(cfg), seed)
-    rng = np.random.default_rng(seed + 1)
-    x = torch.from_numpy(rng.random((b, cfg.in_channels, hw, hw), dtype=np.float32))
-    wl = torch.from_numpy(rng.normal(0, 1, (b, cfg.n_class, hw, hw)).astype(np.float32))
-    wv = torch.from_numpy(rng.normal(0, 1, (b, 300, 3)).astype(np.float32))
+    img, mask, vert, _, _ = synth_batch(b, cfg.in_channels, cfg.n_class, hw, seed=seed + 1)
+    x = torch.from_numpy(img)
+    ya = torch.tensor(mask, dtype=torch.float32)
+
+    def total(lo, ve):
+        if softmax:
+            pr = F.softmax(lo, dim=1)
+            l1 = F.cross_entropy(pr, torch.from_numpy(np.argmax(mask, axis=1)).long())
+        else:
+            pr = torch.sigmoid(lo)
+            l1 = torch.nn.BCELoss()(pr, ya)
+        l2 = ref_loss.jaccard_loss(logits=pr, true=ya, activation=False)
+        l3 = ref_loss.batch_NN_loss(x=ve, y=torch.tensor(vert)) if cfg.pointnet else 0.0
+        return l1 + l2 + l3
 
     ref = load_into(ref_seg(cfg), params).train()
     xr = x.clone().requires_grad_(True)
     lo, _, ve = ref(xr)
-    loss = (lo * wl).sum() / lo.numel() + ((ve * wv).sum() / ve.numel() if cfg.pointnet else 0.0)
+    loss = total(lo, ve)
     loss.backward()
     g_ref = {k: p.grad for k, p in ref.named_parameters()}
     sd_after = ref.state_dict()
@@ -128,8 +143,10 @@ def gold_seg(tag, cfg: ON.SegCfg, b, hw, seed, full_tensors):
     p2 = {k: (v.clone().requires_grad_(True) if ON.is_trainable(k) else v.clone()) for k, v in params.items()}
     xo = x.clone().requires_grad_(True)
     lo2, ve2 = ON.seg_forward(p2, xo, cfg, training=True)
-    loss2 = (lo2 * wl).sum() / lo2.numel() + ((ve2 * wv).sum() / ve2.numel() if cfg.pointnet else 0.0)
+    m2, j2 = (OL.seg_loss_softmax if softmax else OL.seg_loss_sigmoid)(lo2, torch.from_numpy(mask))
+    loss2 = m2 + j2 + (OL.batch_nn_loss(ve2, torch.from_numpy(vert)) if cfg.pointnet else 0.0)
     loss2.backward()
+    close(loss2, loss, 1e-5, tag + " loss")
     close(lo2, lo, 1e-5, tag + " logits")
     if cfg.pointnet:
         close(ve2, ve, 1e-5, tag + " verts")
@@ -214,7 +231,7 @@ def gold_pncls(tag, ft, ext, b, seed):
     l2.backward()
     close(y2, y, 1e-5, tag + " y"); close(tr2, tr, 1e-5, tag + " trans")
     close(xo.grad, xr.grad, 2e-4, tag + " dx")
-    out = {"seed": np.int64(seed), "y": y.detach().numpy(), "trans": tr.detach().numpy(),
+    out = {"seed": np.int64(seed), "b": np.int64(b), "y": y.detach().numpy(), "trans": tr.detach().numpy(),
            "loss": np.float64(loss.item()), "dx": xr.grad.numpy()}
     if ft:
         close(trf2, trf, 1e-5, tag + " trans_feat")
@@ -458,7 +475,9 @@ def gold_step(tag, cfg: ON.SegCfg, b, hw, seed, n_steps=2, full=True):
         for nm, m, pd in (("gen", gen, orc.gen), ("d1", d1, orc.dis1), ("d2", d2, orc.dis2), ("d4", d4, orc.dis4)):
             for k, v in m.state_dict().items():
                 if v.dtype.is_floating_point:
-                    close(pd[k], v, 2e-4, "%s step%d param %s.%s" % (tag, it, nm, k))
+                    # Adam's first update is lr*sign(g) for |g| >> eps: a near-zero gradient whose sign is
+                    # rounding noise moves its parameter by up to 2*lr = 2e-3 between implementations
+                    close(pd[k], v, 2.5e-3, "%s step%d param %s.%s" % (tag, it, nm, k))
                     out["s%d/psum/%s/%s" % (it, nm, k)] = np.float64(v.double().sum().item())
                     out["s%d/pabs/%s/%s" % (it, nm, k)] = np.float64(v.double().abs().sum().item())
     np.savez_compressed(os.path.join(GOLD, tag + ".npz"), **out)
@@ -472,16 +491,16 @@ def main():
     small = ON.SegCfg(filters=4, in_channels=1, n_class=4, pointnet=True, fc_inch=9)
     gold_seg("seg_small", small, b=2, hw=128, seed=100, full_tensors=True)
     gold_seg("seg_small_3ch_nopoint", ON.SegCfg(filters=8, in_channels=3, n_class=5, pointnet=False), b=2, hw=64,
-             seed=110, full_tensors=True)
+             seed=110, full_tensors=True, softmax=True)
     gold_disc("disc_small", 4, False, b=2, hw=64, seed=200)
     gold_disc("disc_ext_small", 5, True, b=2, hw=128, seed=210)
-    gold_pncls("pncls", False, False, b=4, seed=300)
-    gold_pncls("pncls_ft_ext", True, True, b=3, seed=310)
+    gold_pncls("pncls", False, False, b=16, seed=300)
+    gold_pncls("pncls_ft_ext", True, True, b=12, seed=310)
     gold_step("step_small", small, b=4, hw=128, seed=400, n_steps=2, full=True)
     if os.environ.get("GOLDEN_FULL", "1") == "1":
         full = ON.SegCfg(filters=32, in_channels=1, n_class=4, pointnet=True, fc_inch=121)
         gold_seg("seg_full256", full, b=2, hw=256, seed=500, full_tensors=False)
-        gold_step("step_full256", full, b=2, hw=256, seed=600, n_steps=1, full=False)
+        gold_step("step_full256", full, b=4, hw=256, seed=600, n_steps=1, full=False)
 
 
 if __name__ == "__main__":

@@ -292,7 +292,7 @@ __device__ __forceinline__ bf16x8 lds_tr_frag(const unsigned char* p0, const uns
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <bool X3, int CO_BLKS>
+template <bool X3, int CO_BLKS, bool CLAMP>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const int x_cap, float* db_partial) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CO_TILE = 32 * CO_BLKS;
@@ -343,9 +343,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const i
     const int tyi = tmp % p.tiles_y;
     const int n = tmp / p.tiles_y;
     const int y0 = tyi * TH, x0 = txi * TW;
+    int oy0 = y0 * p.stride + p.dy_min, ox0 = x0 * p.stride + p.dx_min;
+    int th = p.ih_t, tw = p.iw_t;
+    if (CLAMP) {   // LDS tile = halo tile clipped to the image (+ one zero record), as in igemm_kernel
+      const int y1 = min(oy0 + th, p.in_h), x1 = min(ox0 + tw, p.in_w);
+      oy0 = max(oy0, 0); ox0 = max(ox0, 0);
+      th = max(y1 - oy0, 0); tw = max(x1 - ox0, 0);
+    }
+    const int npix = th * tw;
     __syncthreads();
-    stage_x_chunk<X3>(Xhi, Xlo, p.x, n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row,
-                      y0 * p.stride + p.dy_min, x0 * p.stride + p.dx_min, p.ih_t, p.iw_t, 4, tid);
+    stage_x_chunk<X3>(Xhi, Xlo, p.x, n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row, oy0, ox0, th, tw, 4, tid);
+    if (CLAMP && tid < 5) {
+      *(uint4*)(Xhi + (size_t)npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
+      if (X3) *(uint4*)(Xlo + (size_t)npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
+    }
     // dZ tile [CO_TILE][128 px] in natural (pixel-contiguous) order
 #pragma unroll
     for (int j = 0; j < CO_TILE / 16; ++j) {
@@ -389,21 +400,35 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const i
       const bf16x8 ah = lds_frag(Zhi + aoff);
       bf16x8 al;
       if (X3) al = lds_frag(Zlo + aoff);
-      int rowb[2];
+      int rowb[2], rty[2], rtx[2];
+      const int colb = ((g & 1) * 16 + 4 * tp) * 2;
 #pragma unroll
       for (int sel = 0; sel < 2; ++sel) {
         const int pl = ks * 16 + 8 * (g >> 1) + 4 * sel + tq;
-        const int ty = pl >> p.twl, tx = pl & (TW - 1);
-        rowb[sel] = ((ty * p.stride) * p.iw_t + tx * p.stride) * IG_REC_BYTES + ((g & 1) * 16 + 4 * tp) * 2;
+        rty[sel] = pl >> p.twl; rtx[sel] = pl & (TW - 1);
+        rowb[sel] = ((rty[sel] * p.stride) * p.iw_t + rtx[sel] * p.stride) * IG_REC_BYTES + colb;
       }
 #pragma unroll
       for (int ti = 0; ti < MAXT; ++ti) {
         if (ti < my_cnt) {   // wave-uniform: EXEC stays all ones for the transposed reads
           const int t = my_t0 + ti;
-          const int toff = ((p.dy[t] - p.dy_min) * p.iw_t + (p.dx[t] - p.dx_min)) * IG_REC_BYTES;
-          const bf16x8 bh = lds_tr_frag(Xhi + rowb[0] + toff, Xhi + rowb[1] + toff);
+          int r0, r1;
+          if (CLAMP) {
+            int ra[2];
+#pragma unroll
+            for (int sel = 0; sel < 2; ++sel) {
+              const int gy = (y0 + rty[sel]) * p.stride + p.dy[t], gx = (x0 + rtx[sel]) * p.stride + p.dx[t];
+              const bool ok = ((unsigned)gy < (unsigned)p.in_h) & ((unsigned)gx < (unsigned)p.in_w);
+              ra[sel] = (ok ? (gy - oy0) * tw + (gx - ox0) : npix) * IG_REC_BYTES + colb;
+            }
+            r0 = ra[0]; r1 = ra[1];
+          } else {
+            const int toff = ((p.dy[t] - p.dy_min) * p.iw_t + (p.dx[t] - p.dx_min)) * IG_REC_BYTES;
+            r0 = rowb[0] + toff; r1 = rowb[1] + toff;
+          }
+          const bf16x8 bh = lds_tr_frag(Xhi + r0, Xhi + r1);
           if (X3) {
-            const bf16x8 bl = lds_tr_frag(Xlo + rowb[0] + toff, Xlo + rowb[1] + toff);
+            const bf16x8 bl = lds_tr_frag(Xlo + r0, Xlo + r1);
             acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[ti], 0, 0, 0);
             acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[ti], 0, 0, 0);
           }
@@ -800,9 +825,9 @@ extern "C" size_t pcuda_conv2d_wgrad_workspace_size(const pcuda_conv_geom* g) {
   return ((size_t)w.ksplit * g->cout * g->cin * g->k * g->k + (size_t)w.ksplit * g->cout) * sizeof(float) + 256;
 }
 
-template <bool X3, int CO_BLKS>
+template <bool X3, int CO_BLKS, bool CLAMP>
 static int launch_wgrad_t(const WgradParams& p, int x_cap, size_t lds, float* dbp, dim3 grid, hipStream_t s) {
-  auto kern = wgrad_kernel<X3, CO_BLKS>;
+  auto kern = wgrad_kernel<X3, CO_BLKS, CLAMP>;
   static size_t lds_set = 0;
   if (lds > 32 * 1024 && lds > lds_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HARD);
@@ -846,17 +871,24 @@ extern "C" int pcuda_conv2d_wgrad(const pcuda_conv_geom* g, int prec, const pcud
   const long long welems = (long long)g->cout * g->cin * t.n;
   float* dbp = db ? (float*)workspace + (size_t)w.ksplit * welems : nullptr;
 
-  const int x_cap = w.ih_t * w.iw_t;
+  const int full = w.ih_t * w.iw_t;
+  const int clipped = (w.ih_t < g->in_h ? w.ih_t : g->in_h) * (w.iw_t < g->in_w ? w.iw_t : g->in_w) + 1;
   const size_t mul = x3 ? 2 : 1;
-  const size_t lds = (size_t)x_cap * IG_REC_BYTES * mul + (size_t)w.co_tile * WG_ZROW * mul;
+  const size_t zb = (size_t)w.co_tile * WG_ZROW * mul;
+  bool clamp = clipped * 2 <= full;
+  if (!clamp && (size_t)full * IG_REC_BYTES * mul + zb > (size_t)LDS_HARD) clamp = true;
+  const int x_cap = clamp ? clipped : full;
+  const size_t lds = (size_t)x_cap * IG_REC_BYTES * mul + zb;
   if (lds > (size_t)LDS_HARD) PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv2d_wgrad: tile %dx%d does not fit LDS", w.ih_t, w.iw_t);
   const dim3 grid(w.n_co_tiles * w.n_chunks * w.tap_groups, w.ksplit);
   {
     const double flops = 2.0 * g->n * (double)g->out_h * g->out_w * g->cout * (double)g->cin * t.n;
     ProfScope prof(PCUDA_FAM_CONV_WGRAD, flops, s);
     int rc;
-    if (x3) rc = w.co_blks == 2 ? launch_wgrad_t<true, 2>(p, x_cap, lds, dbp, grid, s) : launch_wgrad_t<true, 1>(p, x_cap, lds, dbp, grid, s);
-    else rc = w.co_blks == 2 ? launch_wgrad_t<false, 2>(p, x_cap, lds, dbp, grid, s) : launch_wgrad_t<false, 1>(p, x_cap, lds, dbp, grid, s);
+#define WG_GO(X3_, CB_) (clamp ? launch_wgrad_t<X3_, CB_, true>(p, x_cap, lds, dbp, grid, s) : launch_wgrad_t<X3_, CB_, false>(p, x_cap, lds, dbp, grid, s))
+    if (x3) rc = w.co_blks == 2 ? WG_GO(true, 2) : WG_GO(true, 1);
+    else rc = w.co_blks == 2 ? WG_GO(false, 2) : WG_GO(false, 1);
+#undef WG_GO
     if (rc) return rc;
   }
   {

@@ -47,13 +47,15 @@ def masks_to_pointclouds(mask_u8: torch.Tensor, firsts: torch.Tensor, number_poi
     -> int32 [B,number_points,3] rows (z,y,x); all zeros where the mask has <= 50 foreground pixels."""
     b, h, w = mask_u8.shape
     if max_verts <= 0:
-        max_verts = 3 * 4 * (h + w) * 4
+        max_verts = 3 * 8 * (h + w)
     verts, counts = K.surface_vertices(mask_u8.contiguous(), max_verts)
     # npy2point.py:116: sample only when the binarised mask has more than 50 foreground pixels
     area = (mask_u8 > 0).flatten(1).sum(1)
     counts = torch.where(area > 50, counts, torch.zeros_like(counts)).to(torch.int32)
-    if int(counts.max()) > max_verts:
+    n_used = int(counts.max())                       # one host sync: this is loader-side code
+    if n_used > max_verts:
         raise RuntimeError("surface has more than max_verts=%d vertices" % max_verts)
+    verts = verts[:, :max(n_used, 1)].contiguous()
     idx = K.fps(verts.to(torch.float64), counts, firsts.to(torch.int32), number_points)
     safe = idx.clamp(min=0).long()
     out = torch.gather(verts, 1, safe[..., None].expand(-1, -1, 3))

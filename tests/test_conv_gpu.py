@@ -23,6 +23,8 @@ CASES = [
     (2, 64, 64, 16, 16, 3, 1, 2, 2, False, True, 0.01),     # dilated bottleneck d=2
     (2, 64, 64, 16, 16, 3, 1, 4, 4, False, True, 0.01),     # d=4 (clamped LDS tile)
     (2, 64, 128, 16, 16, 3, 1, 8, 8, False, True, 0.01),    # d=8
+    (2, 32, 64, 4, 4, 3, 1, 8, 8, False, True, 0.01),       # d=8 on a 4x4 map (reduced config): all halo
+    (2, 32, 32, 8, 8, 3, 1, 4, 4, False, True, 0.01),
     (2, 64, 300, 16, 16, 6, 1, 0, 1, False, True, 0.01),    # 6x6 valid point head
     (2, 4, 64, 64, 64, 4, 2, 2, 1, False, False, 0.2),      # discriminator conv1
     (2, 64, 128, 33, 33, 4, 2, 2, 1, False, False, 0.2),    # discriminator, odd size

@@ -1,0 +1,214 @@
+"""Whole-network parity: the HIP-backed modules against golden vectors produced by the REFERENCE
+modules (tests/golden/*.npz from oracle/make_golden.py).  Parameters are regenerated from the same
+numpy seeds and load_state_dict()-ed, so state_dict key compatibility is exercised too.
+
+Tolerances (bf16x3 parity mode): 1e-3 of the tensor's scale, the north-star figure; observed errors
+are one to two orders of magnitude below that."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(mod, params, dev):
+    mod.load_state_dict({k: v.clone() for k, v in params.items()}, strict=True)
+    return mod.to(dev).train()
+
+
+def _strided(t, n=4096):
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n]
+
+
+def _check_grads(mod, g, tol, tol_elem=None):
+    """per-parameter gradient norms (and samples) against the reference's.  Parameters whose reference
+    gradient is rounding noise (a bias feeding a BatchNorm has an exactly-zero true gradient) are only
+    required to be equally negligible: the floor is 1e-3 of the model's total gradient norm."""
+    worst = 0.0
+    tol_elem = tol if tol_elem is None else tol_elem
+    total = sum(float(g[k]) ** 2 for k in g.files if k.startswith("gnorm/")) ** 0.5
+    floor = 1e-3 * total
+    for k, p in mod.named_parameters():
+        if "gnone/" + k in g:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        if "gnorm/" + k not in g:
+            continue
+        ref_norm = float(g["gnorm/" + k])
+        got_norm = float(p.grad.double().norm())
+        assert abs(got_norm - ref_norm) <= tol * ref_norm + floor, (k, got_norm, ref_norm)
+        if ref_norm < 10 * floor:
+            continue
+        if "g/" + k in g:
+            e = rel_err(p.grad, g["g/" + k]); worst = max(worst, e)
+            assert e < tol_elem, (k, e)
+        elif "gs/" + k in g:
+            e = rel_err(_strided(p.grad, len(g["gs/" + k])), g["gs/" + k]); worst = max(worst, e)
+            assert e < tol_elem, (k, e)
+    return worst
+
+
+@pytest.mark.parametrize("tag,cfg_kw,softmax", [
+    ("seg_small", dict(filters=4, in_channels=1, n_class=4, pointnet=True, fc_inch=9), False),
+    ("seg_small_3ch_nopoint", dict(filters=8, in_channels=3, n_class=5, pointnet=False), True),
+    ("seg_full256", dict(filters=32, in_channels=1, n_class=4, pointnet=True, fc_inch=121), False),
+])
+def test_segmenter_vs_reference_golden(dev, tag, cfg_kw, softmax):
+    """forward + backward under the reference's own supervised loss (train_mscmrseg.py:202-209 /
+    train_mmwhs.py:212-218).  Outputs and loss: 1e-3 (north-star); observed ~1e-4.
+    Gradients: 5e-2 on norms / 1e-1 elementwise.  The reference network's gradients are discontinuous
+    in its activations (max-pool argmax, LeakyReLU sign): scripts/gradient_conditioning.py shows that
+    1e-6 relative noise on the FIRST conv output of the fp32 oracle already moves some weight gradients
+    by 1-2 % (one routing flip at the 8x8 level is 1/128 of a sum), so no two fp32-class
+    implementations agree better than ~1e-2 there.  Kernel-level gradient exactness (1e-4 / 1e-5 on
+    identical inputs) is covered by test_conv_gpu.py, test_pointwise_gpu.py and
+    test_block_backward_exact below."""
+    from oracle import nets as ON
+    from oracle.synth import synth_batch
+    from pointcloududa_amd.networks import Segmentation_model_Point
+    from pointcloududa_amd.utils import loss as L
+    g = np.load(os.path.join(GOLD, tag + ".npz"))
+    seed, b, hw = int(g["seed"]), int(g["b"]), int(g["hw"])
+    cfg = ON.SegCfg(**cfg_kw)
+    params = ON.make_params(ON.seg_param_shapes(cfg), seed)
+    model = _load(Segmentation_model_Point(**cfg_kw), params, dev)
+    assert list(model.state_dict().keys()) == list(params.keys())
+    img, mask, vert, _, _ = synth_batch(b, cfg.in_channels, cfg.n_class, hw, seed=seed + 1)
+    x = torch.from_numpy(img).to(dev).requires_grad_(True)
+    logits, none, verts = model(x)
+    assert none is None
+    one = torch.ones((), device=dev)
+    l_main, l_jac = L.seg_loss(logits, torch.from_numpy(mask).to(dev), "softmax" if softmax else "sigmoid")
+    seeds, grads, total = [l_main, l_jac], [one, one], float(l_main.detach()) + float(l_jac.detach())
+    if cfg.pointnet:
+        l_pt = L.batch_NN_loss(verts, torch.from_numpy(vert).to(dev))
+        seeds.append(l_pt); grads.append(one); total += float(l_pt.detach())
+    torch.autograd.backward(seeds, grads)
+    assert abs(total - float(g["loss"])) < 1e-4 * max(1.0, abs(float(g["loss"])))
+    if "logits" in g:
+        assert rel_err(logits, g["logits"]) < 1e-3
+        assert rel_err(x.grad, g["dx"]) < 1e-1
+    else:
+        assert rel_err(_strided(logits), g["logits_s"]) < 1e-3
+        assert rel_err(_strided(x.grad), g["dx_s"]) < 1e-1
+    if cfg.pointnet:
+        assert rel_err(verts, g["verts"]) < 1e-3
+    _check_grads(model, g, 5e-2, 1e-1)
+    sd = model.state_dict()
+    for k in params:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert rel_err(sd[k], g["bn/" + k]) < 1e-4, k
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == 1
+
+
+@pytest.mark.parametrize("tag,inch,ext,hw", [("disc_small", 4, False, 64), ("disc_ext_small", 5, True, 128)])
+def test_discriminator_vs_reference_golden(dev, tag, inch, ext, hw):
+    from oracle import nets as ON
+    from pointcloududa_amd.networks import UncertaintyDiscriminator
+    from pointcloududa_amd.utils import loss as L
+    g = np.load(os.path.join(GOLD, tag + ".npz"))
+    seed = int(g["seed"])
+    params = ON.make_params(ON.disc_param_shapes(inch, ext), seed, std=0.02)
+    model = _load(UncertaintyDiscriminator(in_channel=inch, ext=ext), params, dev)
+    rng = np.random.default_rng(seed + 1)
+    x = torch.from_numpy(rng.normal(0, 1, (2, inch, hw, hw)).astype(np.float32)).to(dev).requires_grad_(True)
+    d = model(x)
+    loss = L.bce_logits_const(d, 1.0)
+    loss.backward()
+    assert rel_err(d, g["out"]) < 1e-3
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4
+    assert rel_err(_strided(x.grad), g["dx_s"]) < 1e-2
+    assert abs(float(x.grad.double().norm()) - float(g["dx_norm"])) < 1e-2 * float(g["dx_norm"])
+    _check_grads(model, g, 1e-2)
+    # frozen discriminator (adversarial phase): input gradient only, no parameter gradients
+    model.zero_grad(set_to_none=True)
+    model.requires_grad_(False)
+    x2 = x.detach().clone().requires_grad_(True)
+    L.bce_logits_const(model(x2), 1.0).backward()
+    assert rel_err(_strided(x2.grad), g["dx_s"]) < 1e-2
+    assert all(p.grad is None for p in model.parameters())
+
+
+@pytest.mark.parametrize("tag,ft,ext", [("pncls", False, False), ("pncls_ft_ext", True, True)])
+def test_pointnet_cls_vs_reference_golden(dev, tag, ft, ext):
+    from oracle import nets as ON
+    from pointcloududa_amd.networks import PointNetCls
+    from pointcloududa_amd.utils import loss as L
+    g = np.load(os.path.join(GOLD, tag + ".npz"))
+    seed, b = int(g["seed"]), int(g["b"])
+    params = ON.make_params(ON.pointnet_cls_param_shapes(ft, ext=ext), seed)
+    model = _load(PointNetCls(feature_transform=ft, ext=ext, drop=0.0), params, dev)
+    assert list(model.state_dict().keys()) == list(params.keys())
+    rng = np.random.default_rng(seed + 1)
+    x = torch.from_numpy(rng.random((b, 3, 300), dtype=np.float32)).to(dev).requires_grad_(True)
+    y, trans, trans_feat = model(x)
+    loss = L.bce_logits_const(y, 0.0)
+    loss.backward()
+    # BatchNorm1d over a batch of 12-16 right after a max over 300 points (argmax routing) amplifies
+    # rounding: 5e-3 on outputs; gradients only to ~1e-1 (same discontinuity argument as above)
+    assert rel_err(y, g["y"]) < 5e-3 and rel_err(trans, g["trans"]) < 5e-3
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-3
+    assert rel_err(x.grad, g["dx"]) < 2e-1
+    if ft:
+        assert rel_err(_strided(trans_feat), g["trans_feat_s"]) < 5e-3
+    else:
+        assert trans_feat is None
+    _check_grads(model, g, 1e-1, 3.5e-1)
+    sd = model.state_dict()
+    for k in params:
+        if "bn/" + k in g:
+            assert rel_err(sd[k], g["bn/" + k]) < 1e-3, k
+
+
+def test_block_backward_exact(dev):
+    """One decoder block (concat -> conv -> LeakyReLU -> BN -> conv -> LeakyReLU -> BN) backward on the HIP
+    kernels against PyTorch-CPU autograd fed the IDENTICAL block inputs: with the routing decisions
+    shared, every gradient agrees to 1e-4 (observed ~1e-5)."""
+    import torch.nn.functional as F
+    from oracle import nets as ON
+    from pointcloududa_amd import kernels as K
+    from pointcloududa_amd.kernels import TA
+    from pointcloududa_amd.networks import Segmentation_model_Point
+    cfg_kw = dict(filters=4, in_channels=1, n_class=4, pointnet=True, fc_inch=9)
+    params = ON.make_params(ON.seg_param_shapes(ON.SegCfg(**cfg_kw)), 100)
+    m = _load(Segmentation_model_Point(**cfg_kw), params, dev)
+    rng = np.random.default_rng(101)
+    x = torch.from_numpy(rng.random((2, 1, 128, 128), dtype=np.float32)).to(dev)
+    P = m._tensor_dict()
+    _, _, S = m._engine.forward(P, x, True)
+    blk = "decoder.decoder2_1"
+    xs, x2s, a0, st0, a1, st1 = S[blk]
+    p = {k: v.clone() for k, v in params.items()}
+    skip = (xs.t * xs.scale[None, :, None, None] + xs.shift[None, :, None, None]).cpu()
+    xin = torch.cat([skip, x2s.cpu()], 1).requires_grad_(True)
+    w0, w3 = p[blk + ".0.weight"].requires_grad_(True), p[blk + ".3.weight"].requires_grad_(True)
+    z0p = F.conv2d(xin, w0, p[blk + ".0.bias"], padding=1); z0p.retain_grad()
+    y0 = F.batch_norm(F.leaky_relu(z0p, 0.01), None, None, p[blk + ".2.weight"], p[blk + ".2.bias"], True); y0.retain_grad()
+    z1p = F.conv2d(y0, w3, p[blk + ".3.bias"], padding=1); z1p.retain_grad()
+    y1 = F.batch_norm(F.leaky_relu(z1p, 0.01), None, None, p[blk + ".5.weight"], p[blk + ".5.bias"], True)
+    gy = torch.from_numpy(rng.normal(0, 1, y1.shape).astype(np.float32))
+    y1.backward(gy)
+    dg, db = torch.zeros(4, device=dev), torch.zeros(4, device=dev)
+    op3, op0 = m._engine.ops[blk + ".3"], m._engine.ops[blk + ".0"]
+    dz1 = K.bn_backward(gy.to(dev), a1, st1, P[blk + ".5.weight"], dg, db, act_slope=0.01, accumulate=False)
+    assert rel_err(dz1, z1p.grad) < 1e-4
+    dw3, db3 = torch.zeros(4, 4, 3, 3, device=dev), torch.zeros(4, device=dev)
+    op3.wgrad(TA(a0, st0.scale, st0.shift), dz1, dw3, db3, 128, 128, accumulate=False)
+    assert rel_err(dw3, w3.grad) < 1e-4
+    d_y0 = op3.dgrad(dz1, P[blk + ".3.weight"], 128, 128)
+    assert rel_err(d_y0, y0.grad) < 1e-4
+    dz0 = K.bn_backward(d_y0, a0, st0, P[blk + ".2.weight"], dg, db, act_slope=0.01, accumulate=False)
+    assert rel_err(dz0, z0p.grad) < 1e-4
+    dw0, db0 = torch.zeros(4, 8, 3, 3, device=dev), torch.zeros(4, device=dev)
+    op0.wgrad(xs, dz0, dw0, db0, 128, 128, x2=x2s, accumulate=False)
+    assert rel_err(dw0, w0.grad) < 1e-4
+    d1, d2 = torch.empty(2, 4, 128, 128, device=dev), torch.empty(2, 4, 128, 128, device=dev)
+    op0.dgrad(dz0, P[blk + ".0.weight"], 128, 128, dx=d1, dx2=d2)
+    assert rel_err(torch.cat([d1, d2], 1), xin.grad) < 1e-4

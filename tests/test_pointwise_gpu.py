@@ -1,0 +1,137 @@
+"""HBM-bound kernels (BatchNorm train fwd/bwd fused with LeakyReLU, pooling, upsample backward,
+dense ops, optimisers) against plain PyTorch-CPU fp32 references, through the C ABI."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(rng, *shape, scale=1.0):
+    return torch.from_numpy(rng.normal(0, scale, shape).astype(np.float32))
+
+
+@pytest.mark.parametrize("shape", [(3, 8, 32, 32), (2, 5, 70, 66), (4, 16, 300), (6, 32)])
+@pytest.mark.parametrize("post_relu", [False, True])
+def test_bn_train_forward_backward(dev, shape, post_relu):
+    from pointcloududa_amd import kernels as K
+    rng = np.random.default_rng(1)
+    c = shape[1]
+    z = _rand(rng, *shape)
+    gamma, beta = _rand(rng, c) * 0.2 + 1, _rand(rng, c) * 0.2
+    rm0, rv0 = _rand(rng, c) * 0.1, torch.rand(c) + 0.5
+    gy, gy2 = _rand(rng, *shape), _rand(rng, *shape)
+    slope = 0.01
+    # reference: [z -> a = lrelu(z) -> y = BN(a)]  or  [a -> BN -> relu]
+    zr = z.clone().requires_grad_(True)
+    g_r, b_r = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm, rv = rm0.clone(), rv0.clone()
+    a_ref = zr if post_relu else F.leaky_relu(zr, slope)
+    y_ref = F.batch_norm(a_ref, rm, rv, g_r, b_r, True, 0.1, 1e-5)
+    if post_relu:
+        y_ref = F.relu(y_ref)
+    y_ref.backward(gy + gy2)
+
+    a = (z if post_relu else F.leaky_relu(z, slope)).to(dev)
+    part, nt, cnt = K.bn_stats(a)
+    rmd, rvd = rm0.to(dev), rv0.to(dev)
+    st = K.bn_finalize(part, nt, cnt, gamma.to(dev), beta.to(dev), rmd, rvd)
+    y = K.bn_apply(a, st, relu=post_relu)
+    assert rel_err(y, y_ref) < 2e-5
+    assert rel_err(rmd, rm) < 1e-5 and rel_err(rvd, rv) < 1e-5
+    dg, db = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
+    dz = K.bn_backward(gy.to(dev), a, st, gamma.to(dev), dg, db, dy2=gy2.to(dev), post_relu=post_relu,
+                       act_slope=slope, accumulate=False)
+    assert rel_err(dz, zr.grad) < 5e-5
+    assert rel_err(dg, g_r.grad) < 5e-5 and rel_err(db, b_r.grad) < 5e-5
+
+
+def test_maxpool_upsample_add(dev):
+    from pointcloududa_amd import kernels as K
+    from pointcloududa_amd.kernels import TA
+    rng = np.random.default_rng(2)
+    x = _rand(rng, 2, 6, 32, 48)
+    sc, sf = _rand(rng, 6) * 0.5 + (-0.2), _rand(rng, 6)          # negative scales too: max does not commute
+    xr = (x * sc[None, :, None, None] + sf[None, :, None, None]).requires_grad_(True)
+    y_ref = F.max_pool2d(xr, 2)
+    g1, g2 = _rand(rng, *y_ref.shape), _rand(rng, *y_ref.shape)
+    y_ref.backward(g1 + g2)
+    y, idx = K.maxpool2_fwd(TA(x.to(dev), sc.to(dev), sf.to(dev)))
+    assert rel_err(y, y_ref) < 1e-6
+    dx = K.maxpool2_bwd(g1.to(dev), idx, 32, 48, dy2=g2.to(dev))
+    assert rel_err(dx, xr.grad) < 1e-6
+    u = _rand(rng, 2, 3, 8, 10).requires_grad_(True)
+    up = F.interpolate(u, scale_factor=2, mode="nearest")
+    gu = _rand(rng, *up.shape)
+    up.backward(gu)
+    assert rel_err(K.upsample2_bwd(gu.to(dev)), u.grad) < 1e-6
+    ts = [_rand(rng, 1000) for _ in range(4)]
+    assert rel_err(K.add_n([t.to(dev) for t in ts]), ts[0] + ts[1] + ts[2] + ts[3]) < 1e-6
+    assert rel_err(K.add_n([t.to(dev) for t in ts[:2]]), ts[0] + ts[1]) < 1e-6
+    assert rel_err(K.mul(ts[0].to(dev), ts[1].to(dev)), ts[0] * ts[1]) < 1e-6
+    a = _rand(rng, 2, 5, 16, 16)
+    gy = _rand(rng, 2, 5, 16, 16)
+    assert rel_err(K.lrelu_bwd(gy.to(dev), a.to(dev), 0.2), torch.where(a > 0, gy, 0.2 * gy)) < 1e-6
+    db = torch.zeros(5, device=dev)
+    K.channel_sum(gy.to(dev), db, accumulate=False)
+    assert rel_err(db, gy.sum((0, 2, 3))) < 1e-5
+
+
+def test_dense_ops(dev):
+    from pointcloududa_amd import kernels as K
+    rng = np.random.default_rng(3)
+    for m, k, n in [(32, 1024, 512), (5, 121, 3), (600, 9, 3), (7, 256, 9)]:
+        x, w, b = _rand(rng, m, k), _rand(rng, n, k, scale=0.1), _rand(rng, n)
+        xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y_ref = F.linear(xr, wr, br)
+        g = _rand(rng, m, n)
+        y_ref.backward(g)
+        assert rel_err(K.linear_fwd(x.to(dev), w.to(dev), b.to(dev)), y_ref) < 1e-5
+        assert rel_err(K.linear_bwd_x(g.to(dev), w.to(dev)), xr.grad) < 1e-5
+        dw, db = torch.zeros(n, k, device=dev), torch.zeros(n, device=dev)
+        K.linear_bwd_w(g.to(dev), x.to(dev), dw, db, accumulate=False)
+        assert rel_err(dw, wr.grad) < 1e-5 and rel_err(db, br.grad) < 1e-5
+    t, x = _rand(rng, 4, 3, 3), _rand(rng, 4, 3, 300)
+    assert rel_err(K.bmm(t.to(dev), x.to(dev), ta=True), torch.bmm(t.transpose(1, 2), x)) < 1e-5
+    assert rel_err(K.bmm(t.to(dev), x.to(dev)), torch.bmm(t, x)) < 1e-5
+    assert rel_err(K.bmm(x.to(dev), x.to(dev), tb=True), torch.bmm(x, x.transpose(1, 2))) < 1e-5
+    t64, x64 = _rand(rng, 3, 64, 64), _rand(rng, 3, 64, 300)
+    assert rel_err(K.bmm(t64.to(dev), x64.to(dev), ta=True), torch.bmm(t64.transpose(1, 2), x64)) < 1e-5
+    h = _rand(rng, 3, 70, 300)
+    h[0, 0, 5] = h[0, 0, 200] = 9.0                                # tie: first occurrence wins
+    v, idx = K.max_points_fwd(h.to(dev))
+    vr, ir = h.max(dim=2)
+    assert torch.equal(v.cpu(), vr) and int(idx[0, 0]) == 5
+    g = _rand(rng, 3, 70)
+    ref = torch.zeros_like(h).scatter_(2, idx.cpu().long()[..., None], g[..., None])
+    assert rel_err(K.max_points_bwd(g.to(dev), idx, 300), ref) < 1e-7
+
+
+def test_fused_optimisers(dev):
+    from pointcloududa_amd import kernels as K
+    rng = np.random.default_rng(4)
+    p0, steps = _rand(rng, 5000), 3
+    grads = [_rand(rng, 5000) for _ in range(steps)]
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-3, betas=(0.9, 0.99))
+    p, m, v = p0.to(dev), torch.zeros(5000, device=dev), torch.zeros(5000, device=dev)
+    for i, g in enumerate(grads):
+        pr.grad = g.clone(); opt.step()
+        K.adam_step(p, g.to(dev), m, v, 1e-3, 0.9, 0.99, 1e-8, 0.0, i + 1)
+        assert rel_err(p, pr.detach()) < 1e-6
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.SGD([pr], lr=2.5e-5, momentum=0.99, weight_decay=0.0005)
+    p, buf = p0.to(dev), torch.zeros(5000, device=dev)
+    for i, g in enumerate(grads):
+        pr.grad = g.clone(); opt.step()
+        K.sgd_step(p, g.to(dev), buf, 2.5e-5, 0.99, 0.0005, i == 0)
+        assert rel_err(p, pr.detach()) < 1e-6
+    # grad_scale = 1/world (data-parallel mean of summed gradients)
+    p2, m2, v2 = p0.to(dev), torch.zeros(5000, device=dev), torch.zeros(5000, device=dev)
+    K.adam_step(p2, (grads[0] * 4).to(dev), m2, v2, 1e-3, 0.9, 0.99, 1e-8, 0.0, 1, grad_scale=0.25)
+    p3, m3, v3 = p0.to(dev), torch.zeros(5000, device=dev), torch.zeros(5000, device=dev)
+    K.adam_step(p3, grads[0].to(dev), m3, v3, 1e-3, 0.9, 0.99, 1e-8, 0.0, 1)
+    assert rel_err(p2, p3) < 1e-6
