@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Benchmark of the PointCloudUDA adversarial train step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+Metric (BASELINE.json): adversarial train-step images/sec (segmenter + 3 discriminators) at 256x256.
+One "step" = one iteration of the reference's train_epoch loop (train_mscmrseg.py:183-330): source
+batch fwd+bwd, target batch fwd + adversarial bwd, Adam on G, two passes per discriminator, SGD on
+the D's.  img/s = bs * steps/s, bs = the reference's -bs (source images per step; an equal number
+of target images rides along).  Weak scaling: every rank runs the full per-GPU batch, gradients
+are all-reduced over RCCL before the optimiser kernels.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     the dominant kernel family (implicit-GEMM MFMA convolution: forward + dgrad launches)
+               timed live with HIP events on the launch stream over extra profiled steps
+  cpu_baseline the oracle's CPU restatement of the same step, timed on this host (rank 0, N = 1)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # BASELINE.json configs[2]: the configuration the metric (seg + 3 discriminators) is quoted on
+    "full_uda": dict(desc="MS-CMRSeg full UDA: UNet(PointNet head) + d1 + d2 + d4, 256x256x1, 4 classes",
+                     batch=32, d1=True, d2=True, d4=True, gflop_per_pair=282.0),
+    # BASELINE.json configs[1]
+    "unet_d2": dict(desc="MS-CMRSeg UNet + entropy-map discriminator (d2), 256x256x1, 4 classes",
+                    batch=16, d1=False, d2=True, d4=False, gflop_per_pair=243.0),
+}
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def synth_device_batch(b, hw, n_class, seed, dev):
+    """device-resident synthetic batch in the reference's layout: images U[0,1),
+    one-hot uint8 nested-ellipse masks, vertices = HIP sampler(mask) / 255."""
+    from pointcloududa_amd.utils.npy2point import masks_to_pointclouds
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:hw, 0:hw].astype(np.float64)
+
+    def labels():
+        lab = np.zeros((b, hw, hw), dtype=np.int64)
+        for i in range(b):
+            cy = hw * (0.5 + 0.08 * (rng.random() - 0.5))
+            cx = hw * (0.5 + 0.08 * (rng.random() - 0.5))
+            for k in range(1, n_class):
+                ry = hw * 0.36 * (n_class - k) / (n_class - 1)
+                rx = hw * 0.28 * (n_class - k) / (n_class - 1)
+                lab[i][((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0] = k
+        return lab
+
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    img_a = torch.rand((b, 1, hw, hw), generator=g).to(dev)
+    img_b = torch.rand((b, 1, hw, hw), generator=g).to(dev)
+    lab_a, lab_b = labels(), labels()
+    onehot = torch.from_numpy(np.ascontiguousarray(np.moveaxis(np.eye(n_class, dtype=np.uint8)[lab_a], -1, 1))).to(dev)
+    firsts = torch.from_numpy(rng.integers(0, 1 << 30, size=(2, b)).astype(np.int32)).to(dev)
+    va = masks_to_pointclouds(torch.from_numpy((lab_a > 0).astype(np.uint8)).to(dev), firsts[0]).float() / 255.0
+    vb = masks_to_pointclouds(torch.from_numpy((lab_b > 0).astype(np.uint8)).to(dev), firsts[1]).float() / 255.0
+    return img_a, onehot, va.contiguous(), img_b, vb.contiguous()
+
+
+def build_trainer(wl, dev, seed, group=None):
+    from pointcloududa_amd.networks import PointNetCls, Segmentation_model_Point, UncertaintyDiscriminator
+    from pointcloududa_amd.train_step import AdversarialTrainer, TrainCfg
+    torch.manual_seed(seed)                       # train_mscmrseg.py:668-670 seeds torch + numpy with 0
+    np.random.seed(seed)
+    gen = Segmentation_model_Point(filters=32, in_channels=1, n_class=4, pointnet=wl["d4"], fc_inch=121).to(dev)
+    d1 = UncertaintyDiscriminator(in_channel=4).to(dev) if wl["d1"] else None
+    d2 = UncertaintyDiscriminator(in_channel=4).to(dev) if wl["d2"] else None
+    d4 = PointNetCls().to(dev) if wl["d4"] else None          # dropout p = 0.3 as in the reference
+    cfg = TrainCfg(variant="mscmrseg", d1=wl["d1"], d2=wl["d2"], d4=wl["d4"], n_class=4)
+    tr = AdversarialTrainer(gen, d1, d2, d4, cfg, process_group=group)
+    tr.train()
+    return tr
+
+
+def cpu_baseline(wl, budget_s=20.0):
+    """The oracle (CPU restatement of the reference step) on this host's cores, on a bounded
+    sample: B = 2 pairs per step, as many steps as fit the budget (>= 1 after one warm-up)."""
+    from oracle import nets as ON
+    from oracle.step import OracleTrainer, StepCfg
+    from oracle.synth import synth_batch
+    cores = min(os.cpu_count() or 1, 16)       # oneDNN convs at batch 2 do not scale past a socket's worth of threads
+    torch.set_num_threads(cores)
+    cfg = ON.SegCfg(filters=32, in_channels=1, n_class=4, pointnet=wl["d4"], fc_inch=121)
+    scfg = StepCfg(d1=wl["d1"], d2=wl["d2"], d4=wl["d4"], n_class=4)
+    pg = ON.make_params(ON.seg_param_shapes(cfg), 1)
+    p1 = ON.make_params(ON.disc_param_shapes(4), 2, std=0.02) if wl["d1"] else None
+    p2 = ON.make_params(ON.disc_param_shapes(4), 3, std=0.02) if wl["d2"] else None
+    p4 = ON.make_params(ON.pointnet_cls_param_shapes(), 4) if wl["d4"] else None
+    orc = OracleTrainer(cfg, scfg, pg, p1, p2, p4)
+    b = 2
+    batch = synth_batch(b, 1, 4, 256, seed=5)
+    t0 = time.perf_counter()
+    orc.step(*batch)                                           # warm-up (also the fallback sample)
+    warm = time.perf_counter() - t0
+    t0, n = time.perf_counter(), 0
+    while warm < budget_s / 2 and n < 8:
+        orc.step(*batch)
+        n += 1
+        if time.perf_counter() - t0 + warm > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    if n == 0:
+        n, dt = 1, warm
+    return {"value": round(b * n / dt, 3), "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": "%d step(s) of the same workload at batch %d (fp32, torch CPU oracle, %d threads)" % (n, b, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="full_uda", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--precision", default=os.environ.get("PCUDA_PRECISION", "bf16x3"), choices=["bf16x3", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)      # RCCL over xGMI
+    if args.gpus != world and rank == 0:
+        print("note: --gpus %d but WORLD_SIZE %d: using the launcher's world size" % (args.gpus, world), file=sys.stderr)
+
+    import pointcloududa_amd as P
+    from pointcloududa_amd import kernels as K
+    P.set_precision(args.precision)
+    wl = WORKLOADS[args.workload]
+    b = args.batch or wl["batch"]
+    tr = build_trainer(wl, dev, seed=0)
+    batch = synth_device_batch(b, 256, 4, seed=100 + rank, dev=dev)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.step(*batch)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = tr.step(*batch)
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    host = tr.to_host(out, tr.cfg)
+    if not all(np.isfinite(v) for v in host.values()):
+        raise SystemExit("non-finite loss in the benchmark step: %r" % host)
+
+    result = {
+        "metric": "adversarial train-step images/sec (seg+3 discr) at 256x256",
+        "value": round(b * world * args.steps / dt, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16x3 MFMA (split-bf16, fp32 accumulate; fp32 storage)" if args.precision == "bf16x3"
+                 else "bf16 MFMA (fp32 accumulate; fp32 storage)",
+        "data": "synthetic",
+        "config": {"workload": wl["desc"], "per_gpu_batch": b, "global_batch": b * world, "precision": args.precision,
+                   "parallelism": "dp%d" % world, "algorithmic_gflop_per_pair": wl["gflop_per_pair"],
+                   "losses": {k: round(host[k], 5) for k in ("seg_loss", "adv_loss") if k in host}},
+    }
+
+    if rank == 0 and world == 1 and not args.no_roofline:
+        K.prof_reset()
+        K.prof_enable(True)
+        nprof = 2
+        for _ in range(nprof):
+            tr.step(*batch)
+        torch.cuda.synchronize()
+        K.prof_enable(False)
+        if os.environ.get("PCUDA_PROF_DUMP"):
+            K.prof_dump(os.environ["PCUDA_PROF_DUMP"])
+        ms, flops, launches = K.prof_read(0)
+        wms, wflops, wl_n = K.prof_read(1)
+        pms, pbytes, pl_n = K.prof_read(2)
+        K.prof_reset()
+        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        result["roofline"] = {
+            "kernel": "igemm_kernel (implicit-GEMM MFMA conv: forward + dgrad)", "bound": "mfma",
+            "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+            "traffic": None, "launches_per_step": launches // nprof, "avg_launch_us": round(1000.0 * ms / max(launches, 1), 2),
+            "ms_per_step": round(ms / nprof, 3),
+            "mfma_flops_per_algorithmic_flop": 3 if args.precision == "bf16x3" else 1,
+            "other": {
+                "wgrad_kernel": {"achieved_tflops": round(wflops / (wms * 1e-3) / 1e12, 2) if wms > 0 else 0.0,
+                                 "ms_per_step": round(wms / nprof, 3), "launches_per_step": wl_n // nprof},
+                "pointwise": {"achieved_gbps": round(pbytes / (pms * 1e-3) / 1e9, 1) if pms > 0 else 0.0,
+                              "ms_per_step": round(pms / nprof, 3), "launches_per_step": pl_n // nprof,
+                              "peak_gbps": 8000.0},
+            },
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(wl)
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

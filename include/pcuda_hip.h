@@ -57,6 +57,8 @@ int pcuda_prof_reset(void);
 /* synchronises the recorded events; ms = summed kernel time, work = summed algorithmic
  * FLOPs (conv families) or bytes (pointwise), launches = number of launches */
 int pcuda_prof_read(int family, double* ms, double* work, long long* launches);
+/* writes one CSV row per recorded launch (family, work, ms, shape tag) */
+int pcuda_prof_dump(const char* path);
 
 /* ------------------------------------------------------------------------------------
  * 2-D convolution: replaces nn.Conv2d forward/backward at

@@ -32,7 +32,7 @@ void pcuda_set_error(const char* fmt, ...);
 struct ProfScope {
   int fam;
   void* ev0;
-  ProfScope(int family, double work, hipStream_t s);
+  ProfScope(int family, double work, hipStream_t s, const char* tag = nullptr);
   ~ProfScope();
   hipStream_t stream;
 };

@@ -37,6 +37,7 @@ struct IgemmParams {
   int tiles_x, tiles_y, n;
   int n_co_tiles;
   int clamp;               // 1: LDS tile = tile clipped to the image (+ one zero record)
+  int dbg;                 // PCUDA_DBG bits (timing experiments only): 1 no X loads, 2 no MFMA, 4 no epilogue, 8 no W copy
 };
 
 // wgrad: dW[r][c][tap] = sum_{n,oy,ox} dZ[r][oy,ox] * X[c][oy*stride + dy[t]][ox*stride + dx[t]]

@@ -10,6 +10,8 @@
 //                     one launch per stride-parity class = transposed convolution)
 //   wgrad           : wgrad_kernel  (reduction over pixels; X read back through
 //                     ds_read_b64_tr_b16, split-K partial slabs + deterministic reduce)
+#include <stdlib.h>
+
 #include "conv_igemm.h"
 
 // ------------------------------------------------------------------------------------------
@@ -41,49 +43,114 @@ __global__ void pack_kernel(const PackParams p) {
 // stage one 32-channel chunk of a haloed input tile into LDS, pixel-major, bf16 hi (+ lo)
 // ------------------------------------------------------------------------------------------
 template <bool X3>
+__device__ __forceinline__ void stage_write(unsigned char* __restrict__ xhi, unsigned char* __restrict__ xlo,
+                                            const float (&v)[8], int pix, int g) {
+  uint4 hi, lo;
+  if (X3) {
+    split2(v[0], v[1], hi.x, lo.x); split2(v[2], v[3], hi.y, lo.y);
+    split2(v[4], v[5], hi.z, lo.z); split2(v[6], v[7], hi.w, lo.w);
+    *(uint4*)(xlo + (size_t)pix * IG_REC_BYTES + g * 16) = lo;
+  } else {
+    hi.x = pack_bf16x2(v[0], v[1]); hi.y = pack_bf16x2(v[2], v[3]);
+    hi.z = pack_bf16x2(v[4], v[5]); hi.w = pack_bf16x2(v[6], v[7]);
+  }
+  *(uint4*)(xhi + (size_t)pix * IG_REC_BYTES + g * 16) = hi;
+}
+
+// PF pixels per thread (npix <= PF*256), everything unrolled.  Instruction-lean by construction:
+//  * the channel plane base (p + n*sn + c*sc) is wave-uniform -> SGPR pair; each lane adds ONE 32-bit
+//    byte offset computed once per pixel slot -> `global_load_dword v, v_off, s[base]`, no 64-bit VALU;
+//  * loads are UNCONDITIONAL on clamped (always valid) addresses and the padding zeros are selected
+//    afterwards: a per-lane `if (inb) load` makes hipcc branch around every load and wait for it
+//    (cdna_hip_programming.md, "Three .s-level traps" (c));
+//  * the lazy-BatchNorm scale/shift are read in uniform control flow (scalar loads), one fma per value.
+// Phase 1 issues all 32*PF loads of the chunk, phase 2 applies the affine, splits and writes LDS.
+template <bool X3, int PF>
+__device__ __forceinline__ void stage_x_chunk_mlp(unsigned char* __restrict__ xhi, unsigned char* __restrict__ xlo,
+                                                  const pcuda_src& x, int n, int cin, int chunk, int in_h, int in_w,
+                                                  int in_shift, int in_row, int oy0, int ox0, int th, int tw,
+                                                  int ngroups, int tid0) {
+  const int npix = th * tw;
+  const int cbase = chunk * 32;
+  const int tid = tid0;   // first pixel slot of this lane (callers may offset it to walk big tiles)
+  unsigned voff[PF];
+  bool inb[PF];
+#pragma unroll
+  for (int s = 0; s < PF; ++s) {
+    const int pix = min(tid + s * 256, npix - 1);
+    const int iy = pix / tw, ix = pix - iy * tw;
+    const int gy = oy0 + iy, gx = ox0 + ix;
+    inb[s] = (tid + s * 256 < npix) & ((unsigned)gy < (unsigned)in_h) & ((unsigned)gx < (unsigned)in_w);
+    const int cy = min(max(gy, 0), in_h - 1), cx = min(max(gx, 0), in_w - 1);
+    voff[s] = (unsigned)((cy >> in_shift) * in_row + (cx >> in_shift)) * 4u;
+  }
+  const char* b1 = (const char*)(x.p1 + (long long)n * x.sn1);
+  const char* b2 = (const char*)(x.p2 + (long long)n * x.sn2);
+  float v[PF][4][8];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (g < ngroups) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = min(cbase + g * 8 + j, cin - 1);   // wave-uniform, clamped
+        const char* chan = (c < x.c1) ? b1 + (long long)c * x.sc1 * 4 : b2 + (long long)(c - x.c1) * x.sc2 * 4;
+#pragma unroll
+        for (int s = 0; s < PF; ++s) v[s][g][j] = *(const float*)(chan + voff[s]);
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (g < ngroups) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = cbase + g * 8 + j;
+        const bool cok = c < cin;
+        float sc = 1.f, sh = 0.f;
+        if (cok) {
+          if (c < x.c1) { if (x.scale1) { sc = x.scale1[c]; sh = x.shift1[c]; } }
+          else { if (x.scale2) { sc = x.scale2[c - x.c1]; sh = x.shift2[c - x.c1]; } }
+        }
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+          const float t = fmaf(v[s][g][j], sc, sh);
+          v[s][g][j] = (inb[s] & cok) ? t : 0.f;
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < PF; ++s)
+        if (tid + s * 256 < npix) stage_write<X3>(xhi, xlo, v[s][g], tid + s * 256, g);
+    }
+  }
+}
+
+template <bool X3>
 __device__ __forceinline__ void stage_x_chunk(unsigned char* __restrict__ xhi, unsigned char* __restrict__ xlo,
                                               const pcuda_src& x, int n, int cin, int chunk, int in_h, int in_w,
                                               int in_shift, int in_row, int oy0, int ox0, int th, int tw,
                                               int ngroups, int tid) {
   const int npix = th * tw;
-  const int cbase = chunk * 32;
-  for (int pix = tid; pix < npix; pix += 256) {
-    const int iy = pix / tw, ix = pix - iy * tw;
-    const int gy = oy0 + iy, gx = ox0 + ix;
-    const bool inb = ((unsigned)gy < (unsigned)in_h) & ((unsigned)gx < (unsigned)in_w);
-    const long long off = (long long)(gy >> in_shift) * in_row + (gx >> in_shift);
-    for (int g = 0; g < ngroups; ++g) {
-      float v[8];
+  if (npix <= 256) { stage_x_chunk_mlp<X3, 1>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, tid); return; }
+  if (npix <= 512) { stage_x_chunk_mlp<X3, 2>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, tid); return; }
+  if (npix <= 768) { stage_x_chunk_mlp<X3, 3>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, tid); return; }
+  for (int pix0 = 0; pix0 < npix; pix0 += 512)   // big tiles: 512 pixels at a time
+    stage_x_chunk_mlp<X3, 2>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, tid + pix0);
+}
+
+// contiguous global -> LDS copy of nvec 16-B vectors, 4 loads per lane in flight
+__device__ __forceinline__ void copy_vec16(unsigned char* __restrict__ dst, const uint4* __restrict__ src, int nvec,
+                                           int tid) {
+  for (int base = 0; base < nvec; base += 1024) {
+    uint4 r[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int c = cbase + g * 8 + j;   // wave-uniform
-        float val = 0.f;
-        if (c < cin) {
-          if (c < x.c1) {
-            if (inb) {
-              val = x.p1[(long long)n * x.sn1 + (long long)c * x.sc1 + off];
-              if (x.scale1) val = val * x.scale1[c] + x.shift1[c];
-            }
-          } else {
-            const int cc = c - x.c1;
-            if (inb) {
-              val = x.p2[(long long)n * x.sn2 + (long long)cc * x.sc2 + off];
-              if (x.scale2) val = val * x.scale2[cc] + x.shift2[cc];
-            }
-          }
-        }
-        v[j] = val;
-      }
-      uint4 hi, lo;
-      if (X3) {
-        split2(v[0], v[1], hi.x, lo.x); split2(v[2], v[3], hi.y, lo.y);
-        split2(v[4], v[5], hi.z, lo.z); split2(v[6], v[7], hi.w, lo.w);
-        *(uint4*)(xlo + (size_t)pix * IG_REC_BYTES + g * 16) = lo;
-      } else {
-        hi.x = pack_bf16x2(v[0], v[1]); hi.y = pack_bf16x2(v[2], v[3]);
-        hi.z = pack_bf16x2(v[4], v[5]); hi.w = pack_bf16x2(v[6], v[7]);
-      }
-      *(uint4*)(xhi + (size_t)pix * IG_REC_BYTES + g * 16) = hi;
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + tid + u * 256;
+      r[u] = src[i < nvec ? i : nvec - 1];   // unconditional (clamped) load keeps r[] in registers
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + tid + u * 256;
+      if (i < nvec) ((uint4*)dst)[i] = r[u];
     }
   }
 }
@@ -152,8 +219,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p, const i
     const int cvalid = min(32, p.cin - chunk * 32);
     const int nks = cvalid > 16 ? 2 : 1;
     __syncthreads();   // every wave is done reading the previous chunk's X / W
-    stage_x_chunk<X3>(Xhi, Xlo, p.x, n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row, oy0, ox0, th, tw,
-                      nks * 2, tid);
+    if (!(p.dbg & 1))
+      stage_x_chunk<X3>(Xhi, Xlo, p.x, n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row, oy0, ox0, th, tw,
+                        nks * 2, tid);
     if (CLAMP && tid < 5) {   // the all-zero record that out-of-image taps read
       *(uint4*)(Xhi + (size_t)npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
       if (X3) *(uint4*)(Xlo + (size_t)npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
@@ -165,15 +233,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p, const i
         const long long slab = (long long)CO_TILE * IG_REC;   // bf16 elements per tap
         const uint16_t* src = p.wpack + (((long long)cot * p.nchunks + chunk) * p.ntaps + t0) * slab;
         const int nvec = tgc * CO_TILE * 5;                  // 16-B vectors
-        const uint4* s4 = (const uint4*)src;
-        for (int i = tid; i < nvec; i += 256) ((uint4*)Whi)[i] = s4[i];
-        if (X3) {
-          const uint4* l4 = (const uint4*)(src + p.w_lo_off);
-          for (int i = tid; i < nvec; i += 256) ((uint4*)Wlo)[i] = l4[i];
+        if (!(p.dbg & 8)) {
+          copy_vec16(Whi, (const uint4*)src, nvec, tid);
+          if (X3) copy_vec16(Wlo, (const uint4*)(src + p.w_lo_off), nvec, tid);
         }
       }
       __syncthreads();
-      for (int tl = 0; tl < tgc; ++tl) {
+      for (int tl = 0; tl < ((p.dbg & 2) ? 0 : tgc); ++tl) {
         const int t = t0 + tl;
         int baddr[NPB];
         if (CLAMP) {
@@ -224,28 +290,52 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p, const i
   // ---- epilogue: bias + LeakyReLU, NCHW store (register i = one output channel, the 32 lanes of
   // a half-wave = 32 consecutive pixels), optional per-tile BatchNorm partial sums.
   __syncthreads();
+  if (p.dbg & 4) {
+    if (acc[0][0][0] == 123.456f) p.y.p1[0] = 1.f;   // keep the accumulators live
+    return;
+  }
   float* sred = (float*)smem;   // [4 waves][CO_TILE][2]
+  // per-lane output pixel offsets (elements within a plane), computed once
+  int poff[NPB];
+  bool pok[NPB];
+#pragma unroll
+  for (int pb = 0; pb < NPB; ++pb) {
+    const int ly = y0 + pty[pb], lx = x0 + ptx[pb];
+    pok[pb] = (ly < p.lh) & (lx < p.lw);
+    poff[pb] = (ly * p.oy_mul + p.oy_off) * p.out_w + (lx * p.ox_mul + p.ox_off);
+  }
+  const int co0 = cot * CO_TILE;
+  // fast path: the two half-waves (rows r0 and r0+4) of every register land in the same destination
+  // tensor -> the plane base of row r0 is wave-uniform (SGPR) and lanes add a 32-bit offset
+  const bool uni = (p.y.c1 >= p.cout) | ((p.y.c1 & 7) == 0);
+  float* const yb1 = p.y.p1 + (long long)n * p.y.sn1;
+  float* const yb2 = p.y.p2 + (long long)n * p.y.sn2;
 #pragma unroll
   for (int cb = 0; cb < CO_BLKS; ++cb) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int row = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-      const int co = cot * CO_TILE + row;
+      const int row0 = cb * 32 + (i & 3) + 8 * (i >> 2);   // wave-uniform
+      const int row = row0 + 4 * h;
+      const int co = co0 + row;
       const bool cok = co < p.cout;
       const float b = (cok && p.bias) ? p.bias[co] : 0.f;
-      float* plane = nullptr;
-      if (cok) {
-        plane = (co < p.y.c1) ? p.y.p1 + (long long)n * p.y.sn1 + (long long)co * p.y.sc1
-                              : p.y.p2 + (long long)n * p.y.sn2 + (long long)(co - p.y.c1) * p.y.sc2;
+      float* plane;
+      if (uni) {
+        const int cu = min(co0 + row0, p.cout - 1);
+        float* base = (cu < p.y.c1) ? yb1 + (long long)cu * p.y.sc1 : yb2 + (long long)(cu - p.y.c1) * p.y.sc2;
+        const long long hs = (cu < p.y.c1) ? p.y.sc1 : p.y.sc2;
+        plane = base + (h ? 4 * hs : 0);
+      } else {
+        const int cc = min(co, p.cout - 1);
+        plane = (cc < p.y.c1) ? yb1 + (long long)cc * p.y.sc1 : yb2 + (long long)(cc - p.y.c1) * p.y.sc2;
       }
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int pb = 0; pb < NPB; ++pb) {
-        const int ly = y0 + pty[pb], lx = x0 + ptx[pb];
-        if (cok && ly < p.lh && lx < p.lw) {
-          float v = acc[cb][pb][i] + b;
-          v = v > 0.f ? v : v * p.slope;
-          float* dst = plane + (long long)(ly * p.oy_mul + p.oy_off) * p.out_w + (lx * p.ox_mul + p.ox_off);
+        float v = acc[cb][pb][i] + b;
+        v = v > 0.f ? v : v * p.slope;
+        float* dst = plane + poff[pb];
+        if (cok & pok[pb]) {
           if (p.accumulate) v += *dst;
           *dst = v;
           s1 += v;
@@ -281,6 +371,315 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p, const i
 }
 
 // ------------------------------------------------------------------------------------------
+// Persistent, software-pipelined forward / dgrad kernel (the default).  Same tiling as igemm_kernel,
+// but a workgroup walks a strided list of (tile, 32-channel chunk) stages and keeps the NEXT stage's
+// input loads in flight (32*PF dwords per lane, in registers) while the current stage copies its
+// weights, runs its MFMAs and stores its outputs.  With only 1-2 workgroups per CU (LDS-limited) the
+// unpipelined kernel left HBM idle during compute and the matrix cores idle during staging.
+// ------------------------------------------------------------------------------------------
+template <int PF>
+struct XPre {
+  float v[PF][4][8];
+  bool inb[PF];
+};
+
+template <int PF>
+__device__ __forceinline__ void xpre_issue(XPre<PF>& pre, const pcuda_src& x, int n, int cin, int chunk, int in_h,
+                                           int in_w, int in_shift, int in_row, int oy0, int ox0, int tw, int npix,
+                                           int ngroups, int tid) {
+  const int cbase = chunk * 32;
+  unsigned voff[PF];
+#pragma unroll
+  for (int s = 0; s < PF; ++s) {
+    const int pix = min(tid + s * 256, npix - 1);
+    const int iy = pix / tw, ix = pix - iy * tw;
+    const int gy = oy0 + iy, gx = ox0 + ix;
+    pre.inb[s] = (tid + s * 256 < npix) & ((unsigned)gy < (unsigned)in_h) & ((unsigned)gx < (unsigned)in_w);
+    const int cy = min(max(gy, 0), in_h - 1), cx = min(max(gx, 0), in_w - 1);
+    voff[s] = (unsigned)((cy >> in_shift) * in_row + (cx >> in_shift)) * 4u;
+  }
+  const char* b1 = (const char*)(x.p1 + (long long)n * x.sn1);
+  const char* b2 = (const char*)(x.p2 + (long long)n * x.sn2);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (g < ngroups) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = min(cbase + g * 8 + j, cin - 1);   // wave-uniform, clamped
+        const char* chan = (c < x.c1) ? b1 + (long long)c * x.sc1 * 4 : b2 + (long long)(c - x.c1) * x.sc2 * 4;
+#pragma unroll
+        for (int s = 0; s < PF; ++s) pre.v[s][g][j] = *(const float*)(chan + voff[s]);
+      }
+    }
+  }
+}
+
+template <bool X3, int PF>
+__device__ __forceinline__ void xpre_commit(XPre<PF>& pre, unsigned char* __restrict__ xhi,
+                                            unsigned char* __restrict__ xlo, const pcuda_src& x, int cin, int chunk,
+                                            int npix, int ngroups, int tid) {
+  const int cbase = chunk * 32;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (g < ngroups) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = cbase + g * 8 + j;
+        const bool cok = c < cin;
+        float sc = 1.f, sh = 0.f;
+        if (cok) {
+          if (c < x.c1) { if (x.scale1) { sc = x.scale1[c]; sh = x.shift1[c]; } }
+          else { if (x.scale2) { sc = x.scale2[c - x.c1]; sh = x.shift2[c - x.c1]; } }
+        }
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+          const float t = fmaf(pre.v[s][g][j], sc, sh);
+          pre.v[s][g][j] = (pre.inb[s] & cok) ? t : 0.f;
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < PF; ++s)
+        if (tid + s * 256 < npix) stage_write<X3>(xhi, xlo, pre.v[s][g], tid + s * 256, g);
+    }
+  }
+}
+
+struct TileGeom {
+  int cot, pt, n, y0, x0, oy0, ox0, th, tw, npix;
+};
+
+template <bool CLAMP, int NPB>
+__device__ __forceinline__ TileGeom tile_decode(const IgemmParams& p, int L) {
+  TileGeom g;
+  g.cot = L % p.n_co_tiles;
+  g.pt = L / p.n_co_tiles;
+  const int txi = g.pt % p.tiles_x;
+  const int tmp = g.pt / p.tiles_x;
+  const int tyi = tmp % p.tiles_y;
+  g.n = tmp / p.tiles_y;
+  const int TW = 1 << p.twl, TH = (128 * NPB) >> p.twl;
+  g.y0 = tyi * TH; g.x0 = txi * TW;
+  g.oy0 = g.y0 * p.in_step + p.dy_min; g.ox0 = g.x0 * p.in_step + p.dx_min;
+  g.th = p.ih_t; g.tw = p.iw_t;
+  if (CLAMP) {
+    const int y1 = min(g.oy0 + g.th, p.in_h), x1 = min(g.ox0 + g.tw, p.in_w);
+    g.oy0 = max(g.oy0, 0); g.ox0 = max(g.ox0, 0);
+    g.th = max(y1 - g.oy0, 0); g.tw = max(x1 - g.ox0, 0);
+  }
+  g.npix = g.th * g.tw;
+  return g;
+}
+
+template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF>
+__global__ __launch_bounds__(256, 2) void igemm_pipe_kernel(const IgemmParams p, const int x_cap, const int total) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int CO_TILE = 32 * CO_BLKS;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int TW = 1 << p.twl;
+
+  // XCD-aware persistent schedule: the 8 XCDs own contiguous eighths of the (pixel tile, co tile) list;
+  // the workgroups of one XCD (blockIdx % 8) interleave over it, so concurrent workgroups touch
+  // adjacent tiles (shared halo rows and weights hit that XCD's L2).
+  const int nx = min(8, (int)gridDim.x);                          // XCD groups that actually have workgroups
+  const int xcd = blockIdx.x % nx, slot = blockIdx.x / nx;
+  const int gx = ((int)gridDim.x - xcd + nx - 1) / nx;            // workgroups in this group
+  const int lo = (int)((long long)total * xcd / nx), hi = (int)((long long)total * (xcd + 1) / nx);
+
+  unsigned char* Xhi = smem;
+  unsigned char* Xlo = smem + (size_t)x_cap * IG_REC_BYTES;
+  unsigned char* Whi = smem + (size_t)(X3 ? 2 : 1) * x_cap * IG_REC_BYTES;
+  unsigned char* Wlo = Whi + (size_t)p.tg * CO_TILE * IG_REC_BYTES;
+  float* sred = (float*)smem;   // [4 waves][CO_TILE][2], reused between a tile's last MFMA and the next commit
+
+  int pty[NPB], ptx[NPB];
+#pragma unroll
+  for (int pb = 0; pb < NPB; ++pb) {
+    const int pl = w * (32 * NPB) + pb * 32 + r;
+    pty[pb] = pl >> p.twl;
+    ptx[pb] = pl & (TW - 1);
+  }
+
+  f32x16 acc[CO_BLKS][NPB];
+  XPre<PF> pre;
+
+  int L = lo + slot, chunk = 0;
+  bool have = L < hi;
+  TileGeom g;
+  if (have) {
+    g = tile_decode<CLAMP, NPB>(p, L);
+    xpre_issue<PF>(pre, p.x, g.n, p.cin, 0, p.in_h, p.in_w, p.in_shift, p.in_row, g.oy0, g.ox0, g.tw, g.npix,
+                   min(32, p.cin) > 16 ? 4 : 2, tid);
+  }
+  while (have) {
+    const int cvalid = min(32, p.cin - chunk * 32);
+    const int nks = cvalid > 16 ? 2 : 1;
+    __syncthreads();   // every wave is done with the previous stage's X / W / reduction scratch
+    xpre_commit<X3, PF>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.npix, nks * 2, tid);
+    if (CLAMP && tid < 5) {
+      *(uint4*)(Xhi + (size_t)g.npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
+      if (X3) *(uint4*)(Xlo + (size_t)g.npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
+    }
+    // next stage: its loads stay in flight through everything below
+    int nL = L, nchunk = chunk + 1;
+    if (nchunk == p.nchunks) { nchunk = 0; nL = L + gx; }
+    const bool nhave = nL < hi;
+    TileGeom ng = g;
+    if (nhave) {
+      if (nL != L) ng = tile_decode<CLAMP, NPB>(p, nL);
+      xpre_issue<PF>(pre, p.x, ng.n, p.cin, nchunk, p.in_h, p.in_w, p.in_shift, p.in_row, ng.oy0, ng.ox0, ng.tw,
+                     ng.npix, min(32, p.cin - nchunk * 32) > 16 ? 4 : 2, tid);
+    }
+
+    if (chunk == 0) {
+#pragma unroll
+      for (int cb = 0; cb < CO_BLKS; ++cb)
+#pragma unroll
+        for (int pb = 0; pb < NPB; ++pb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[cb][pb][i] = 0.f;
+    }
+    int bbase[NPB];
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb)
+      bbase[pb] = ((pty[pb] * p.in_step) * g.tw + ptx[pb] * p.in_step) * IG_REC_BYTES + h * 16;
+
+    for (int t0 = 0; t0 < p.ntaps; t0 += p.tg) {
+      if (t0 > 0) __syncthreads();
+      const int tgc = min(p.tg, p.ntaps - t0);
+      {
+        const long long slab = (long long)CO_TILE * IG_REC;
+        const uint16_t* src = p.wpack + (((long long)g.cot * p.nchunks + chunk) * p.ntaps + t0) * slab;
+        const int nvec = tgc * CO_TILE * 5;
+        copy_vec16(Whi, (const uint4*)src, nvec, tid);
+        if (X3) copy_vec16(Wlo, (const uint4*)(src + p.w_lo_off), nvec, tid);
+      }
+      __syncthreads();
+      for (int tl = 0; tl < tgc; ++tl) {
+        const int t = t0 + tl;
+        int baddr[NPB];
+        if (CLAMP) {
+#pragma unroll
+          for (int pb = 0; pb < NPB; ++pb) {
+            const int gy = (g.y0 + pty[pb]) * p.in_step + p.dy[t];
+            const int gxx = (g.x0 + ptx[pb]) * p.in_step + p.dx[t];
+            const bool ok = ((unsigned)gy < (unsigned)p.in_h) & ((unsigned)gxx < (unsigned)p.in_w);
+            const int idx = ok ? (gy - g.oy0) * g.tw + (gxx - g.ox0) : g.npix;
+            baddr[pb] = idx * IG_REC_BYTES + h * 16;
+          }
+        } else {
+          const int toff = ((p.dy[t] - p.dy_min) * g.tw + (p.dx[t] - p.dx_min)) * IG_REC_BYTES;
+#pragma unroll
+          for (int pb = 0; pb < NPB; ++pb) baddr[pb] = bbase[pb] + toff;
+        }
+        const int abase = (tl * CO_TILE + r) * IG_REC_BYTES + h * 16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          if (ks < nks) {
+            bf16x8 ah[CO_BLKS], al[CO_BLKS], bh[NPB], bl[NPB];
+#pragma unroll
+            for (int cb = 0; cb < CO_BLKS; ++cb) {
+              ah[cb] = lds_frag(Whi + abase + cb * 32 * IG_REC_BYTES + ks * 32);
+              if (X3) al[cb] = lds_frag(Wlo + abase + cb * 32 * IG_REC_BYTES + ks * 32);
+            }
+#pragma unroll
+            for (int pb = 0; pb < NPB; ++pb) {
+              bh[pb] = lds_frag(Xhi + baddr[pb] + ks * 32);
+              if (X3) bl[pb] = lds_frag(Xlo + baddr[pb] + ks * 32);
+            }
+#pragma unroll
+            for (int cb = 0; cb < CO_BLKS; ++cb)
+#pragma unroll
+              for (int pb = 0; pb < NPB; ++pb) {
+                if (X3) {
+                  acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cb], bh[pb], acc[cb][pb], 0, 0, 0);
+                  acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb], bl[pb], acc[cb][pb], 0, 0, 0);
+                }
+                acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb], bh[pb], acc[cb][pb], 0, 0, 0);
+              }
+          }
+        }
+      }
+    }
+
+    if (chunk == p.nchunks - 1) {
+      // ---- epilogue of this tile (see igemm_kernel)
+      if (p.stats) __syncthreads();   // sred aliases the X tile: wait for every wave's last fragment reads
+      int poff[NPB];
+      bool pok[NPB];
+#pragma unroll
+      for (int pb = 0; pb < NPB; ++pb) {
+        const int ly = g.y0 + pty[pb], lx = g.x0 + ptx[pb];
+        pok[pb] = (ly < p.lh) & (lx < p.lw);
+        poff[pb] = (ly * p.oy_mul + p.oy_off) * p.out_w + (lx * p.ox_mul + p.ox_off);
+      }
+      const int co0 = g.cot * CO_TILE;
+      const bool uni = (p.y.c1 >= p.cout) | ((p.y.c1 & 7) == 0);
+      float* const yb1 = p.y.p1 + (long long)g.n * p.y.sn1;
+      float* const yb2 = p.y.p2 + (long long)g.n * p.y.sn2;
+#pragma unroll
+      for (int cb = 0; cb < CO_BLKS; ++cb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row0 = cb * 32 + (i & 3) + 8 * (i >> 2);
+          const int row = row0 + 4 * h;
+          const int co = co0 + row;
+          const bool cok = co < p.cout;
+          const float b = (cok && p.bias) ? p.bias[co] : 0.f;
+          float* plane;
+          if (uni) {
+            const int cu = min(co0 + row0, p.cout - 1);
+            float* base = (cu < p.y.c1) ? yb1 + (long long)cu * p.y.sc1 : yb2 + (long long)(cu - p.y.c1) * p.y.sc2;
+            const long long hs = (cu < p.y.c1) ? p.y.sc1 : p.y.sc2;
+            plane = base + (h ? 4 * hs : 0);
+          } else {
+            const int cc = min(co, p.cout - 1);
+            plane = (cc < p.y.c1) ? yb1 + (long long)cc * p.y.sc1 : yb2 + (long long)(cc - p.y.c1) * p.y.sc2;
+          }
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int pb = 0; pb < NPB; ++pb) {
+            float v = acc[cb][pb][i] + b;
+            v = v > 0.f ? v : v * p.slope;
+            float* dst = plane + poff[pb];
+            if (cok & pok[pb]) {
+              if (p.accumulate) v += *dst;
+              *dst = v;
+              s1 += v;
+              s2 += v * v;
+            }
+          }
+          if (p.stats) {
+            s1 = half_wave_sum(s1);
+            s2 = half_wave_sum(s2);
+            if (r == 0) {
+              sred[(w * CO_TILE + row) * 2 + 0] = s1;
+              sred[(w * CO_TILE + row) * 2 + 1] = s2;
+            }
+          }
+        }
+      }
+      if (p.stats) {
+        __syncthreads();
+        if (tid < CO_TILE) {
+          const int co = g.cot * CO_TILE + tid;
+          if (co < p.cout) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) {
+              s1 += sred[(ww * CO_TILE + tid) * 2 + 0];
+              s2 += sred[(ww * CO_TILE + tid) * 2 + 1];
+            }
+            p.stats[((long long)g.pt * p.cout + co) * 2 + 0] = s1;
+            p.stats[((long long)g.pt * p.cout + co) * 2 + 1] = s2;
+          }
+        }
+      }
+    }
+    L = nL; chunk = nchunk; g = ng; have = nhave;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // wgrad kernel.  Block = (co-tile, 32-channel chunk, tap group) x split-K slice; loops over its
 // 128-pixel tiles, keeping dW tiles [32 rows][32 ci] per tap in the accumulators.
 // ------------------------------------------------------------------------------------------
@@ -292,12 +691,12 @@ __device__ __forceinline__ bf16x8 lds_tr_frag(const unsigned char* p0, const uns
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <bool X3, int CO_BLKS, bool CLAMP>
+template <bool X3, int CO_BLKS, bool CLAMP, int TAPS_MAX>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const int x_cap, float* db_partial) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CO_TILE = 32 * CO_BLKS;
   constexpr int NWT = 4 / CO_BLKS;             // waves sharing one row block
-  constexpr int MAXT = CO_BLKS == 2 ? 5 : 3;   // taps per wave (block handles <= 9 taps)
+  constexpr int MAXT = (TAPS_MAX + NWT - 1) / NWT;   // taps per wave (block handles <= TAPS_MAX taps)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
 
   const int bx = blockIdx.x;
@@ -357,7 +756,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const i
       *(uint4*)(Xhi + (size_t)npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
       if (X3) *(uint4*)(Xlo + (size_t)npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
     }
-    // dZ tile [CO_TILE][128 px] in natural (pixel-contiguous) order
+    // dZ tile [CO_TILE][128 px] in natural (pixel-contiguous) order; all loads first, then the writes
+    float zv[CO_TILE / 16][8];
 #pragma unroll
     for (int j = 0; j < CO_TILE / 16; ++j) {
       const int item = tid + 256 * j;
@@ -366,20 +766,28 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const i
       const int pl = oct * 8;
       const int ty = pl >> p.twl, tx = pl & (TW - 1);
       const int oy = y0 + ty, ox = x0 + tx;
-      float v[8];
+      const bool rowok = (co < p.cout) & (oy < p.out_h);
+      const int cco = min(co, p.cout - 1), coy = min(oy, p.out_h - 1);
+      const float* rowp = p.dz + (long long)n * p.dz_sn + (long long)cco * p.dz_sc + (long long)coy * p.out_w;
+      if (p.aligned4) {   // wave-uniform: out_w % 8 == 0, so an octet is inside or outside the row as a whole
+        const int cox = min(ox, p.out_w - 8);
+        const float4 a = *(const float4*)(rowp + cox), b = *(const float4*)(rowp + cox + 4);
+        const bool ok = rowok & (ox + 8 <= p.out_w);
+        zv[j][0] = ok ? a.x : 0.f; zv[j][1] = ok ? a.y : 0.f; zv[j][2] = ok ? a.z : 0.f; zv[j][3] = ok ? a.w : 0.f;
+        zv[j][4] = ok ? b.x : 0.f; zv[j][5] = ok ? b.y : 0.f; zv[j][6] = ok ? b.z : 0.f; zv[j][7] = ok ? b.w : 0.f;
+      } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = 0.f;
-      if (co < p.cout && oy < p.out_h) {
-        const float* src = p.dz + (long long)n * p.dz_sn + (long long)co * p.dz_sc + (long long)oy * p.out_w + ox;
-        if (p.aligned4 && ox + 8 <= p.out_w) {
-          const float4 a = *(const float4*)src, b = *(const float4*)(src + 4);
-          v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (ox + e < p.out_w) v[e] = src[e];
+        for (int e = 0; e < 8; ++e) {
+          const float t = rowp[min(ox + e, p.out_w - 1)];
+          zv[j][e] = (rowok & (ox + e < p.out_w)) ? t : 0.f;
         }
       }
+    }
+#pragma unroll
+    for (int j = 0; j < CO_TILE / 16; ++j) {
+      const int item = tid + 256 * j;
+      const int row = item >> 4, oct = item & 15;
+      const float(&v)[8] = zv[j];
       if (do_db) dbacc[j] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
       uint4 hi, lo;
       if (X3) {
@@ -659,6 +1067,50 @@ int launch_igemm_c(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
                      : launch_igemm_t<X3, CO_BLKS, false, 1>(p, pl.x_cap, pl.lds, s);
 }
 
+template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF>
+int launch_pipe_t(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
+  auto kern = igemm_pipe_kernel<X3, CO_BLKS, CLAMP, NPB, PF>;
+  static size_t lds_set = 0;
+  if (pl.lds > 32 * 1024 && pl.lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HARD);
+    if (e != hipSuccess) PCUDA_FAIL(PCUDA_E_LAUNCH, "igemm_pipe: cannot raise dynamic LDS: %s", hipGetErrorString(e));
+    lds_set = LDS_HARD;
+  }
+  const int total = p.n_co_tiles * p.n * p.tiles_x * p.tiles_y;
+  // persistent grid = what is resident at once (registers and LDS both limit it)
+  static int occ_cache[4] = {0, 0, 0, 0};   // by LDS class: <=53K, <=80K, <=160K
+  const int cls = pl.lds <= 54528 ? 0 : (pl.lds <= 81920 ? 1 : 2);
+  if (occ_cache[cls] == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, pl.lds) != hipSuccess || nb < 1) nb = 1;
+    const int lds_lim = (int)((size_t)LDS_HARD / pl.lds);
+    if (nb > lds_lim) nb = lds_lim;
+    if (nb > 4) nb = 4;
+    if (nb < 1) nb = 1;
+    occ_cache[cls] = nb;
+  }
+  int grid = occ_cache[cls] * 256;
+  if (grid > total) grid = total;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), pl.lds, s, p, pl.x_cap, total);
+  PCUDA_CHECK_LAUNCH("igemm_pipe_kernel");
+  return PCUDA_OK;
+}
+
+template <bool X3, int CO_BLKS, bool CLAMP, int NPB>
+int launch_pipe_pf(const IgemmParams& p, const IgemmPlan& pl, int pf, hipStream_t s) {
+  if (pf == 1) return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 1>(p, pl, s);
+  if (pf == 2) return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 2>(p, pl, s);
+  return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 3>(p, pl, s);
+}
+
+template <bool X3, int CO_BLKS>
+int launch_pipe_c(const IgemmParams& p, const IgemmPlan& pl, int pf, hipStream_t s) {
+  if (pl.clamp) return pl.npb == 2 ? launch_pipe_pf<X3, CO_BLKS, true, 2>(p, pl, pf, s)
+                                   : launch_pipe_pf<X3, CO_BLKS, true, 1>(p, pl, pf, s);
+  return pl.npb == 2 ? launch_pipe_pf<X3, CO_BLKS, false, 2>(p, pl, pf, s)
+                     : launch_pipe_pf<X3, CO_BLKS, false, 1>(p, pl, pf, s);
+}
+
 int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
   const bool x3 = prec == PCUDA_PREC_BF16X3;
   const int co_blks = ig_co_blks(p.cout);
@@ -675,8 +1127,25 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
   memcpy(p.dx, taps.dx, sizeof(p.dx));
   p.dy_min = taps.dy_min; p.dx_min = taps.dx_min;
   p.ih_t = pl.ih_t; p.iw_t = pl.iw_t; p.clamp = pl.clamp; p.tg = pl.tg;
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("PCUDA_DBG"); dbg = e ? atoi(e) : 0; }
+    p.dbg = dbg;
+  }
   const double flops = 2.0 * p.n * (double)p.lh * p.lw * p.cout * (double)p.cin * taps.n;
-  ProfScope prof(PCUDA_FAM_CONV_FWD, flops, s);
+  char tag[160];
+  snprintf(tag, sizeof(tag), "igemm n%d red%d rows%d %dx%d taps%d step%d up%d tw%d npb%d clamp%d tg%d lds%zu", p.n, p.cin,
+           p.cout, p.lh, p.lw, taps.n, p.in_step, p.in_shift, 1 << pl.twl, pl.npb, pl.clamp, pl.tg, pl.lds);
+  ProfScope prof(PCUDA_FAM_CONV_FWD, flops, s, tag);
+  static int nopipe = -1;
+  if (nopipe < 0) { const char* e = getenv("PCUDA_NOPIPE"); nopipe = e ? atoi(e) : 0; }
+  const int max_pix = pl.clamp ? pl.x_cap - 1 : pl.ih_t * pl.iw_t;     // largest LDS tile of this launch
+  const int pf = (max_pix + 255) / 256;
+  // PF = 3 keeps 96 prefetch registers live next to the accumulators: only with one pixel block per wave
+  if (!nopipe && p.ntaps > 0 && (pf <= 2 || (pf == 3 && pl.npb == 1))) {
+    if (x3) return co_blks == 2 ? launch_pipe_c<true, 2>(p, pl, pf, s) : launch_pipe_c<true, 1>(p, pl, pf, s);
+    return co_blks == 2 ? launch_pipe_c<false, 2>(p, pl, pf, s) : launch_pipe_c<false, 1>(p, pl, pf, s);
+  }
   if (x3) return co_blks == 2 ? launch_igemm_c<true, 2>(p, pl, s) : launch_igemm_c<true, 1>(p, pl, s);
   return co_blks == 2 ? launch_igemm_c<false, 2>(p, pl, s) : launch_igemm_c<false, 1>(p, pl, s);
 }
@@ -693,7 +1162,7 @@ WgradPlan plan_wgrad(const pcuda_conv_geom* g) {
   w.n_co_tiles = cdiv(g->cout, w.co_tile);
   w.n_chunks = cdiv(g->cin, 32);
   const int ntaps = g->k * g->k;
-  w.tap_groups = cdiv(ntaps, 9);
+  w.tap_groups = ntaps <= 16 ? 1 : cdiv(ntaps, 9);   // 4x4 kernels keep all 16 taps in one block: X and dZ staged once
   w.taps_per_group = cdiv(ntaps, w.tap_groups);
   w.twl = ig_twl(g->out_w, g->out_h, 128);
   const int TW = 1 << w.twl, TH = 128 >> w.twl;
@@ -825,9 +1294,9 @@ extern "C" size_t pcuda_conv2d_wgrad_workspace_size(const pcuda_conv_geom* g) {
   return ((size_t)w.ksplit * g->cout * g->cin * g->k * g->k + (size_t)w.ksplit * g->cout) * sizeof(float) + 256;
 }
 
-template <bool X3, int CO_BLKS, bool CLAMP>
+template <bool X3, int CO_BLKS, bool CLAMP, int TAPS_MAX>
 static int launch_wgrad_t(const WgradParams& p, int x_cap, size_t lds, float* dbp, dim3 grid, hipStream_t s) {
-  auto kern = wgrad_kernel<X3, CO_BLKS, CLAMP>;
+  auto kern = wgrad_kernel<X3, CO_BLKS, CLAMP, TAPS_MAX>;
   static size_t lds_set = 0;
   if (lds > 32 * 1024 && lds > lds_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HARD);
@@ -867,7 +1336,7 @@ extern "C" int pcuda_conv2d_wgrad(const pcuda_conv_geom* g, int prec, const pcud
   p.twl = w.twl; p.tiles_x = w.tiles_x; p.tiles_y = w.tiles_y; p.n = g->n;
   p.ksplit = w.ksplit; p.n_co_tiles = w.n_co_tiles; p.n_chunks = w.n_chunks;
   p.partial = (float*)workspace;
-  p.aligned4 = ((g->out_w & 3) == 0 && (dy_sn & 3) == 0 && (dy_sc & 3) == 0 && (((uintptr_t)dy) & 15) == 0) ? 1 : 0;
+  p.aligned4 = ((g->out_w & 7) == 0 && (dy_sn & 3) == 0 && (dy_sc & 3) == 0 && (((uintptr_t)dy) & 15) == 0) ? 1 : 0;
   const long long welems = (long long)g->cout * g->cin * t.n;
   float* dbp = db ? (float*)workspace + (size_t)w.ksplit * welems : nullptr;
 
@@ -883,12 +1352,17 @@ extern "C" int pcuda_conv2d_wgrad(const pcuda_conv_geom* g, int prec, const pcud
   const dim3 grid(w.n_co_tiles * w.n_chunks * w.tap_groups, w.ksplit);
   {
     const double flops = 2.0 * g->n * (double)g->out_h * g->out_w * g->cout * (double)g->cin * t.n;
-    ProfScope prof(PCUDA_FAM_CONV_WGRAD, flops, s);
+    char tag[160];
+    snprintf(tag, sizeof(tag), "wgrad n%d cin%d cout%d %dx%d k%d s%d d%d ksplit%d clamp%d lds%zu", g->n, g->cin, g->cout,
+             g->out_h, g->out_w, g->k, g->stride, g->dil, w.ksplit, clamp ? 1 : 0, lds);
+    ProfScope prof(PCUDA_FAM_CONV_WGRAD, flops, s, tag);
     int rc;
-#define WG_GO(X3_, CB_) (clamp ? launch_wgrad_t<X3_, CB_, true>(p, x_cap, lds, dbp, grid, s) : launch_wgrad_t<X3_, CB_, false>(p, x_cap, lds, dbp, grid, s))
+#define WG_GO2(X3_, CB_, CL_) (w.taps_per_group > 9 ? launch_wgrad_t<X3_, CB_, CL_, 16>(p, x_cap, lds, dbp, grid, s) : launch_wgrad_t<X3_, CB_, CL_, 9>(p, x_cap, lds, dbp, grid, s))
+#define WG_GO(X3_, CB_) (clamp ? WG_GO2(X3_, CB_, true) : WG_GO2(X3_, CB_, false))
     if (x3) rc = w.co_blks == 2 ? WG_GO(true, 2) : WG_GO(true, 1);
     else rc = w.co_blks == 2 ? WG_GO(false, 2) : WG_GO(false, 1);
 #undef WG_GO
+#undef WG_GO2
     if (rc) return rc;
   }
   {

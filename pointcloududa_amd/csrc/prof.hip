@@ -2,6 +2,7 @@
 #include <stdarg.h>
 
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "common.h"
@@ -31,6 +32,7 @@ struct Rec {
   hipEvent_t e0, e1;
   int fam;
   double work;
+  std::string tag;
 };
 std::mutex g_mu;
 bool g_on = false;
@@ -49,7 +51,7 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
-ProfScope::ProfScope(int family, double work, hipStream_t s) : fam(family), ev0(nullptr), stream(s) {
+ProfScope::ProfScope(int family, double work, hipStream_t s, const char* tag) : fam(family), ev0(nullptr), stream(s) {
   if (!g_on) return;
   std::lock_guard<std::mutex> lk(g_mu);
   Rec r;
@@ -57,6 +59,7 @@ ProfScope::ProfScope(int family, double work, hipStream_t s) : fam(family), ev0(
   r.e1 = get_event();
   r.fam = family;
   r.work = work;
+  if (tag) r.tag = tag;
   if (!r.e0 || !r.e1) return;
   (void)hipEventRecord(r.e0, s);
   g_recs.push_back(r);
@@ -101,5 +104,21 @@ extern "C" int pcuda_prof_read(int family, double* ms, double* work, long long* 
   if (ms) *ms = t;
   if (work) *work = w;
   if (launches) *launches = n;
+  return PCUDA_OK;
+}
+
+// debugging aid: one CSV line per recorded launch (family,work,ms,tag)
+extern "C" int pcuda_prof_dump(const char* path) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  FILE* f = fopen(path, "w");
+  if (!f) PCUDA_FAIL(PCUDA_E_BADARG, "prof_dump: cannot open %s", path);
+  fprintf(f, "family,work,ms,tag\n");
+  for (auto& r : g_recs) {
+    (void)hipEventSynchronize(r.e1);
+    float dt = 0.f;
+    (void)hipEventElapsedTime(&dt, r.e0, r.e1);
+    fprintf(f, "%d,%.6g,%.6f,%s\n", r.fam, r.work, dt, r.tag.c_str());
+  }
+  fclose(f);
   return PCUDA_OK;
 }

@@ -538,3 +538,7 @@ def prof_read(family: int):
     ms, work, n = C.c_double(0), C.c_double(0), C.c_longlong(0)
     check(L.lib().pcuda_prof_read(family, C.byref(ms), C.byref(work), C.byref(n)), "prof_read")
     return ms.value, work.value, n.value
+
+
+def prof_dump(path: str):
+    check(L.lib().pcuda_prof_dump(path.encode()), "prof_dump")

@@ -1,0 +1,35 @@
+"""time single conv layers (forward, dgrad, wgrad) of the benchmark's shapes; PCUDA_DBG bits switch
+parts of igemm_kernel off for timing experiments"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pointcloududa_amd import kernels as K
+dev = torch.device("cuda", 0)
+K.set_precision(os.environ.get("PREC", "bf16x3"))
+CASES = {  # name: (n, cin, cout, h, w, k, s, p, d, up)
+    "g32": (32, 32, 32, 256, 256, 3, 1, 1, 1, False),
+    "g64": (32, 64, 64, 128, 128, 3, 1, 1, 1, False),
+    "g128": (32, 128, 128, 64, 64, 3, 1, 1, 1, False),
+    "g256": (32, 256, 256, 32, 32, 3, 1, 1, 1, False),
+    "b512": (32, 512, 512, 16, 16, 3, 1, 1, 1, False),
+    "d2": (32, 64, 128, 129, 129, 4, 2, 2, 1, False),
+    "d4": (32, 256, 512, 33, 33, 4, 2, 2, 1, False),
+}
+which = sys.argv[1:] or list(CASES)
+for name in which:
+    n, cin, cout, h, w, k, s, p, d, up = CASES[name]
+    op = K.ConvOp(cin, cout, k, stride=s, pad=p, dil=d, in_up=up)
+    x = torch.randn(n, cin, h, w, device=dev); wt = torch.randn(cout, cin, k, k, device=dev) * 0.05
+    b = torch.zeros(cout, device=dev)
+    oh, ow = op.out_hw(h, w)
+    gz = torch.randn(n, cout, oh, ow, device=dev)
+    dw = torch.zeros_like(wt)
+    fl = 2.0 * n * oh * ow * cout * cin * k * k
+    def t(fn, reps=10):
+        fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(reps): fn()
+        torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps
+    tf = t(lambda: op.forward(x, wt, b, 0.01, h, w, want_stats=True))
+    td = t(lambda: op.dgrad(gz, wt, h, w))
+    tw = t(lambda: op.wgrad(x, gz, dw, b, h, w))
+    print("%-5s fwd %7.3f ms %6.1f TF | dgrad %7.3f ms %6.1f TF | wgrad %7.3f ms %6.1f TF" % (name, tf*1e3, fl/tf/1e12, td*1e3, fl/td/1e12, tw*1e3, fl/tw/1e12), flush=True)

@@ -1,0 +1,5 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-.}"
+mkdir -p gpurun_out
+python __graft_entry__.py smoke 2>&1 | tail -3
+python bench.py --steps ${STEPS:-5} --warmup ${WARMUP:-2} "$@" 2>&1 | tail -5 | tee gpurun_out/bench_tail.log
