@@ -225,8 +225,11 @@ int pcuda_dice_metric(const float* logits, const uint8_t* onehot, int n, int c, 
 /* y[m][n] = x[m][k] . w[n][k]^T + b[n]   (nn.Linear; also conv1d k=1 seen as [B*L][C]) */
 int pcuda_linear_fwd(const float* x, const float* w, const float* b, float* y, int m, int k, int n, pcuda_stream_t s);
 int pcuda_linear_bwd_x(const float* dy, const float* w, float* dx, int m, int k, int n, int accumulate, pcuda_stream_t s);
+/* workspace (optional; pcuda_linear_bwd_w_workspace_size bytes) enables a deterministic split-K for
+ * long reductions into a small output (the point head's Linear over 300*B rows) */
+size_t pcuda_linear_bwd_w_workspace_size(int m, int k, int n);
 int pcuda_linear_bwd_w(const float* dy, const float* x, float* dw, float* db, int m, int k, int n, int accumulate,
-                       pcuda_stream_t s);
+                       void* workspace, size_t workspace_bytes, pcuda_stream_t s);
 /* max over the last axis of x[b][c][l] with argmax (PointNetCls.py:44,162) */
 int pcuda_max_points_fwd(const float* x, int b, int c, int l, float* y, int* idx, pcuda_stream_t s);
 int pcuda_max_points_bwd(const float* dy, const int* idx, int b, int c, int l, float* dx, pcuda_stream_t s);

@@ -77,7 +77,8 @@ _PROTOS = {
     "pcuda_dice_metric": (i32, [vp, vp, i32, i32, i64, vp, vp, sz, vp]),
     "pcuda_linear_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "pcuda_linear_bwd_x": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
-    "pcuda_linear_bwd_w": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "pcuda_linear_bwd_w_workspace_size": (sz, [i32, i32, i32]),
+    "pcuda_linear_bwd_w": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
     "pcuda_max_points_fwd": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "pcuda_max_points_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "pcuda_bmm": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),

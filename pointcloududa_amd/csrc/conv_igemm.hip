@@ -1021,6 +1021,8 @@ struct IgemmPlan {
 int plan_igemm(int rows, int lh, int lw, int in_h, int in_w, int in_step, const TapSet& taps, bool x3,
                IgemmPlan* pl) {
   const int co_tile = 32 * ig_co_blks(rows);
+  // (measured: preferring pipelinable plans over the clamped two-block plan loses on the small-map
+  // discriminator layers, so the largest tile that fits wins and the launcher picks the kernel)
   for (int npb = 2; npb >= 1; --npb) {
     pl->twl = ig_twl(lw, lh, 128 * npb);
     const int TW = 1 << pl->twl;
@@ -1176,7 +1178,8 @@ WgradPlan plan_wgrad(const pcuda_conv_geom* g) {
   long long ks = 1024 / base;
   if (ks < 1) ks = 1;
   if (ks > ntiles) ks = ntiles;
-  // keep the partial slabs below ~64 MB
+  // keep the partial slabs (written once, re-read once by the reduce kernel) below ~64 MB (measured:
+  // 32 MB costs the wgrad kernels more parallelism than the reduce kernel saves)
   const long long welems = (long long)g->cout * g->cin * ntaps;
   while (ks > 1 && ks * welems * 4 > (64ll << 20)) ks >>= 1;
   w.ksplit = (int)ks;

@@ -59,14 +59,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   }
 }
 
-// column sums: db[j] (+)= sum_i dy[i][j]
+// column sums: db[j] (+)= sum_i dy[i][j]; one workgroup per 64 columns, 4 row-strided waves,
+// fixed summation order (deterministic)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dy, int m, int n, float* db,
                                                      int accumulate) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
+  __shared__ float sh[4][64];
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63), wv = threadIdx.x >> 6;
   float s = 0.f;
-  for (int i = 0; i < m; ++i) s += dy[(long long)i * n + j];
-  db[j] = accumulate ? db[j] + s : s;
+  if (j < n)
+    for (int i = wv; i < m; i += 4) s += dy[(long long)i * n + j];
+  sh[wv][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (wv == 0 && j < n) {
+    const float t = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    db[j] = accumulate ? db[j] + t : t;
+  }
+}
+
+// out[i] (+)= sum_k part[k][i]  (fixed order)
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, long long numel, int ksplit,
+                                     float* __restrict__ out, int accumulate) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < numel;
+       i += (long long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < ksplit; ++k) s += part[(long long)k * numel + i];
+    out[i] = accumulate ? out[i] + s : s;
+  }
 }
 
 // one wave per (b, c) row of x[b][c][l]
@@ -123,14 +141,52 @@ extern "C" int pcuda_linear_bwd_x(const float* dy, const float* w, float* dx, in
   return launch_gemm(p, 1, (hipStream_t)s);
 }
 
+extern "C" size_t pcuda_linear_bwd_w_workspace_size(int m, int k, int n) {
+  const long long out_elems = (long long)n * k;
+  if (m >= 2048 && out_elems <= 65536) {
+    int ks = m / 256;
+    if (ks > 64) ks = 64;
+    return (size_t)(ks + 1) * out_elems * sizeof(float);
+  }
+  return 0;
+}
+
 extern "C" int pcuda_linear_bwd_w(const float* dy, const float* x, float* dw, float* db, int m, int k, int n,
-                                  int accumulate, pcuda_stream_t s) {
+                                  int accumulate, void* workspace, size_t workspace_bytes, pcuda_stream_t s) {
   if (!dy || !x || !dw) PCUDA_FAIL(PCUDA_E_BADARG, "linear_bwd_w: null pointer");
-  GemmParams p = {dy, 0, 1, n, x, 0, k, 1, dw, 0, k, 1, nullptr, n, k, m, accumulate};   // dw[j][c] = sum_i dy[i][j] x[i][c]
-  int rc = launch_gemm(p, 1, (hipStream_t)s);
-  if (rc) return rc;
+  // dw[j][c] = sum_i dy[i][j] x[i][c]: the reduction runs over the batch rows.  A long reduction into
+  // a small output (the point head's Linear(121,3) sees 300*B rows) is split into K-slices that run as
+  // "batches" of the strided GEMM into the caller's workspace, then summed in a fixed order.
+  const long long out_elems = (long long)n * k;
+  const size_t need = pcuda_linear_bwd_w_workspace_size(m, k, n);
+  int rc;
+  if (need > 0 && workspace && workspace_bytes >= need) {
+    float* slab = (float*)workspace;
+    int ks = m / 256;
+    if (ks > 64) ks = 64;
+    const int mk = (m + ks - 1) / ks;       // rows per slice
+    const int full = m / mk;                // complete slices run batched, the ragged tail as one more launch
+    GemmParams pb = {dy, (long long)mk * n, 1, n, x, (long long)mk * k, k, 1, slab, out_elems, k, 1, nullptr, n, k, mk, 0};
+    rc = launch_gemm(pb, full, (hipStream_t)s);
+    if (rc) return rc;
+    int nsl = full;
+    if (m - full * mk > 0) {
+      GemmParams pt = {dy + (long long)full * mk * n, 0, 1, n, x + (long long)full * mk * k, 0, k, 1,
+                       slab + (long long)full * out_elems, 0, k, 1, nullptr, n, k, m - full * mk, 0};
+      rc = launch_gemm(pt, 1, (hipStream_t)s);
+      if (rc) return rc;
+      ++nsl;
+    }
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(out_elems, 256)), dim3(256), 0, (hipStream_t)s,
+                       (const float*)slab, out_elems, nsl, dw, accumulate);
+    PCUDA_CHECK_LAUNCH("splitk_reduce_kernel");
+  } else {
+    GemmParams p = {dy, 0, 1, n, x, 0, k, 1, dw, 0, k, 1, nullptr, n, k, m, accumulate};
+    rc = launch_gemm(p, 1, (hipStream_t)s);
+    if (rc) return rc;
+  }
   if (db) {
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, dy, m, n, db, accumulate);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(n, 64)), dim3(256), 0, (hipStream_t)s, dy, m, n, db, accumulate);
     PCUDA_CHECK_LAUNCH("colsum_kernel");
   }
   return PCUDA_OK;

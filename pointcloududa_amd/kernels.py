@@ -456,8 +456,11 @@ def linear_bwd_x(dy, w):
 def linear_bwd_w(dy, x, dw, db, accumulate=True):
     m, n = dy.shape
     k = x.shape[1]
-    check(L.lib().pcuda_linear_bwd_w(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), _ptr(db), m, k, n,
-                                     1 if accumulate else 0, _stream()), "linear_bwd_w")
+    lib = L.lib()
+    nb = lib.pcuda_linear_bwd_w_workspace_size(m, k, n)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dy.device) if nb else None
+    check(lib.pcuda_linear_bwd_w(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), _ptr(db), m, k, n,
+                                 1 if accumulate else 0, _ptr(ws), nb, _stream()), "linear_bwd_w")
 
 
 def max_points_fwd(x):

@@ -1,0 +1,46 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads without a GPU and exports exactly the
+symbols include/pcuda_hip.h declares; argument validation fails loudly instead of launching."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "pcuda_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pcuda_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from pointcloududa_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    lib = _lib.lib()
+    decl = _declared()
+    assert len(decl) >= 45
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for name in decl:
+        assert hasattr(handle, name), "header declares %s but the library does not export it" % name
+    assert sorted(_lib.EXPORTED_SYMBOLS) == decl, "ctypes prototypes and the header disagree: %r" % (
+        sorted(set(_lib.EXPORTED_SYMBOLS) ^ set(decl)),)
+    assert lib.pcuda_version() == 1
+
+
+def test_bad_arguments_are_rejected_without_a_gpu():
+    from pointcloududa_amd import _lib
+    from pointcloududa_amd._lib import ConvGeom, check
+    lib = _lib.lib()
+    g = ConvGeom(2, 8, 8, 16, 16, 15, 15, 3, 1, 1, 1, 0)            # out size inconsistent with the geometry
+    assert lib.pcuda_conv2d_packed_fwd_bytes(ctypes.byref(g), 0) == 0
+    rc = lib.pcuda_conv2d_pack_fwd(ctypes.byref(g), 0, None, None, None)
+    assert rc == -1 and b"pack_fwd" in lib.pcuda_last_error()
+    with pytest.raises(RuntimeError, match="adam_step"):
+        check(lib.pcuda_adam_step(None, None, None, None, 0, 1e-3, 0.9, 0.99, 1e-8, 0.0, 1, 1.0, None), "adam_step")
+    g2 = ConvGeom(2, 8, 8, 16, 16, 16, 16, 3, 1, 1, 1, 0)
+    assert lib.pcuda_conv2d_packed_fwd_bytes(ctypes.byref(g2), 0) == 2 * lib.pcuda_conv2d_packed_fwd_bytes(ctypes.byref(g2), 1) > 0
+    assert lib.pcuda_conv2d_wgrad_workspace_size(ctypes.byref(g2)) > 0
+    assert lib.pcuda_conv2d_fwd_tiles(ctypes.byref(g2), 0) == 2
+    assert lib.pcuda_seg_loss_workspace_size(2, 4, 256) > 0
