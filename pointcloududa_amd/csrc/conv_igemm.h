@@ -33,7 +33,7 @@ struct IgemmParams {
   float slope;
   int accumulate;
   float* stats;            // [tile][cout][2] partial (sum, sumsq) of the stored values, or NULL
-  int twl;                 // log2(tile width); tile = 256 logical pixels
+  int tw, th, tmagic;      // output tile TW x TH (TW*TH <= 128*NPB slots, any TW <= 256); tmagic = 65536/TW + 1
   int tiles_x, tiles_y, n;
   int n_co_tiles;
   int clamp;               // 1: LDS tile = tile clipped to the image (+ one zero record)
@@ -53,7 +53,7 @@ struct WgradParams {
   signed char dy[IG_MAX_TAPS], dx[IG_MAX_TAPS];
   int ih_t, iw_t;          // LDS tile dims per tap group are computed from the FULL tap span
   int dy_min, dx_min;
-  int twl;                 // tile = 128 logical pixels
+  int tw, th, tmagic;      // output tile TW x TH <= 128 slots
   int tiles_x, tiles_y, n;
   int ksplit;              // gridDim.y
   int n_co_tiles, n_chunks;
@@ -74,18 +74,5 @@ struct PackParams {
 };
 
 static inline int ig_co_blks(int rows) { return rows > 32 ? 2 : 1; }
-// log2 of the tile width for tiles of `tile_px` logical pixels: minimise the padded area,
-// ties -> 32-wide rows (one MFMA column block = one 128-B output row segment)
-static inline int ig_twl(int lw, int lh, int tile_px) {
-  int best = 5;
-  long long best_cost = -1;
-  const int order[6] = {5, 6, 4, 7, 3, 8};
-  for (int oi = 0; oi < 6; ++oi) {
-    const int twl = order[oi];
-    const int tw = 1 << twl, th = tile_px >> twl;
-    if (th < 1) continue;
-    const long long cost = (long long)((lw + tw - 1) / tw) * tw * (long long)((lh + th - 1) / th) * th;
-    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = twl; }
-  }
-  return best;
-}
+// pixel slot -> (row, col) of a TW-wide tile without an integer division (exact for slot < 256, TW <= 256)
+#define IG_TY(pl, magic) (((pl) * (magic)) >> 16)

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p, const i
   const int tmp = pt / p.tiles_x;
   const int tyi = tmp % p.tiles_y;
   const int n = tmp / p.tiles_y;
-  const int TW = 1 << p.twl, TH = (128 * NPB) >> p.twl;
+  const int TW = p.tw, TH = p.th, TPIX = TW * TH;
   const int y0 = tyi * TH, x0 = txi * TW;
 
   int oy0 = y0 * p.in_step + p.dy_min, ox0 = x0 * p.in_step + p.dx_min;
@@ -199,11 +199,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p, const i
 
   // per-lane pixel of each MFMA column block
   int pty[NPB], ptx[NPB], bbase[NPB];
+  bool pvalid[NPB];
 #pragma unroll
   for (int pb = 0; pb < NPB; ++pb) {
-    const int pl = w * (32 * NPB) + pb * 32 + r;
-    pty[pb] = pl >> p.twl;
-    ptx[pb] = pl & (TW - 1);
+    const int plr = w * (32 * NPB) + pb * 32 + r;
+    pvalid[pb] = plr < TPIX;
+    const int pl = min(plr, TPIX - 1);          // idle slots of a non-power-of-two tile read a valid pixel
+    pty[pb] = IG_TY(pl, p.tmagic);
+    ptx[pb] = pl - pty[pb] * TW;
     bbase[pb] = ((pty[pb] * p.in_step) * tw + ptx[pb] * p.in_step) * IG_REC_BYTES + h * 16;
   }
 
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p, const i
 #pragma unroll
   for (int pb = 0; pb < NPB; ++pb) {
     const int ly = y0 + pty[pb], lx = x0 + ptx[pb];
-    pok[pb] = (ly < p.lh) & (lx < p.lw);
+    pok[pb] = pvalid[pb] & (ly < p.lh) & (lx < p.lw);
     poff[pb] = (ly * p.oy_mul + p.oy_off) * p.out_w + (lx * p.ox_mul + p.ox_off);
   }
   const int co0 = cot * CO_TILE;
@@ -417,10 +420,18 @@ __device__ __forceinline__ void xpre_issue(XPre<PF>& pre, const pcuda_src& x, in
 template <bool X3, int PF>
 __device__ __forceinline__ void xpre_commit(XPre<PF>& pre, unsigned char* __restrict__ xhi,
                                             unsigned char* __restrict__ xlo, const pcuda_src& x, int cin, int chunk,
-                                            int npix, int ngroups, int tid) {
+                                            int npix, int ngroups, int nwrite, int tid) {
   const int cbase = chunk * 32;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
+    if (g >= ngroups && g < nwrite) {   // channels past cin inside a 16-wide k-step: zeros, not LDS garbage
+#pragma unroll
+      for (int s = 0; s < PF; ++s)
+        if (tid + s * 256 < npix) {
+          *(uint4*)(xhi + (size_t)(tid + s * 256) * IG_REC_BYTES + g * 16) = make_uint4(0, 0, 0, 0);
+          if (X3) *(uint4*)(xlo + (size_t)(tid + s * 256) * IG_REC_BYTES + g * 16) = make_uint4(0, 0, 0, 0);
+        }
+    }
     if (g < ngroups) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -457,7 +468,7 @@ __device__ __forceinline__ TileGeom tile_decode(const IgemmParams& p, int L) {
   const int tmp = g.pt / p.tiles_x;
   const int tyi = tmp % p.tiles_y;
   g.n = tmp / p.tiles_y;
-  const int TW = 1 << p.twl, TH = (128 * NPB) >> p.twl;
+  const int TW = p.tw, TH = p.th;
   g.y0 = tyi * TH; g.x0 = txi * TW;
   g.oy0 = g.y0 * p.in_step + p.dy_min; g.ox0 = g.x0 * p.in_step + p.dx_min;
   g.th = p.ih_t; g.tw = p.iw_t;
@@ -475,7 +486,7 @@ __global__ __launch_bounds__(256, 2) void igemm_pipe_kernel(const IgemmParams p,
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CO_TILE = 32 * CO_BLKS;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
-  const int TW = 1 << p.twl;
+  const int TW = p.tw, TPIX = p.tw * p.th;
 
   // XCD-aware persistent schedule: the 8 XCDs own contiguous eighths of the (pixel tile, co tile) list;
   // the workgroups of one XCD (blockIdx % 8) interleave over it, so concurrent workgroups touch
@@ -492,11 +503,14 @@ __global__ __launch_bounds__(256, 2) void igemm_pipe_kernel(const IgemmParams p,
   float* sred = (float*)smem;   // [4 waves][CO_TILE][2], reused between a tile's last MFMA and the next commit
 
   int pty[NPB], ptx[NPB];
+  bool pvalid[NPB];
 #pragma unroll
   for (int pb = 0; pb < NPB; ++pb) {
-    const int pl = w * (32 * NPB) + pb * 32 + r;
-    pty[pb] = pl >> p.twl;
-    ptx[pb] = pl & (TW - 1);
+    const int plr = w * (32 * NPB) + pb * 32 + r;
+    pvalid[pb] = plr < TPIX;
+    const int pl = min(plr, TPIX - 1);
+    pty[pb] = IG_TY(pl, p.tmagic);
+    ptx[pb] = pl - pty[pb] * TW;
   }
 
   f32x16 acc[CO_BLKS][NPB];
@@ -508,13 +522,13 @@ __global__ __launch_bounds__(256, 2) void igemm_pipe_kernel(const IgemmParams p,
   if (have) {
     g = tile_decode<CLAMP, NPB>(p, L);
     xpre_issue<PF>(pre, p.x, g.n, p.cin, 0, p.in_h, p.in_w, p.in_shift, p.in_row, g.oy0, g.ox0, g.tw, g.npix,
-                   min(32, p.cin) > 16 ? 4 : 2, tid);
+                   (min(32, p.cin) + 7) >> 3, tid);
   }
   while (have) {
     const int cvalid = min(32, p.cin - chunk * 32);
     const int nks = cvalid > 16 ? 2 : 1;
     __syncthreads();   // every wave is done with the previous stage's X / W / reduction scratch
-    xpre_commit<X3, PF>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.npix, nks * 2, tid);
+    xpre_commit<X3, PF>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.npix, (cvalid + 7) >> 3, nks * 2, tid);
     if (CLAMP && tid < 5) {
       *(uint4*)(Xhi + (size_t)g.npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
       if (X3) *(uint4*)(Xlo + (size_t)g.npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
@@ -527,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void igemm_pipe_kernel(const IgemmParams p,
     if (nhave) {
       if (nL != L) ng = tile_decode<CLAMP, NPB>(p, nL);
       xpre_issue<PF>(pre, p.x, ng.n, p.cin, nchunk, p.in_h, p.in_w, p.in_shift, p.in_row, ng.oy0, ng.ox0, ng.tw,
-                     ng.npix, min(32, p.cin - nchunk * 32) > 16 ? 4 : 2, tid);
+                     ng.npix, (min(32, p.cin - nchunk * 32) + 7) >> 3, tid);
     }
 
     if (chunk == 0) {
@@ -609,7 +623,7 @@ __global__ __launch_bounds__(256, 2) void igemm_pipe_kernel(const IgemmParams p,
 #pragma unroll
       for (int pb = 0; pb < NPB; ++pb) {
         const int ly = g.y0 + pty[pb], lx = g.x0 + ptx[pb];
-        pok[pb] = (ly < p.lh) & (lx < p.lw);
+        pok[pb] = pvalid[pb] & (ly < p.lh) & (lx < p.lw);
         poff[pb] = (ly * p.oy_mul + p.oy_off) * p.out_w + (lx * p.ox_mul + p.ox_off);
       }
       const int co0 = g.cot * CO_TILE;
@@ -692,7 +706,7 @@ __device__ __forceinline__ bf16x8 lds_tr_frag(const unsigned char* p0, const uns
 }
 
 template <bool X3, int CO_BLKS, bool CLAMP, int TAPS_MAX>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const int x_cap, float* db_partial) {
+__global__ __launch_bounds__(256, (TAPS_MAX <= 9 ? 2 : 1)) void wgrad_kernel(const WgradParams p, const int x_cap, float* db_partial) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CO_TILE = 32 * CO_BLKS;
   constexpr int NWT = 4 / CO_BLKS;             // waves sharing one row block
@@ -716,7 +730,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const i
   unsigned char* Zhi = smem + (size_t)(X3 ? 2 : 1) * x_cap * IG_REC_BYTES;
   unsigned char* Zlo = Zhi + (size_t)CO_TILE * WG_ZROW;
 
-  const int TW = 1 << p.twl, TH = 128 >> p.twl;
+  const int TW = p.tw, TH = p.th, TPIX = TW * TH;
   const int ntiles = p.n * p.tiles_y * p.tiles_x;
   const int tile_lo = (int)((long long)kslice * ntiles / p.ksplit);
   const int tile_hi = (int)((long long)(kslice + 1) * ntiles / p.ksplit);
@@ -764,22 +778,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const i
       const int row = item >> 4, oct = item & 15;
       const int co = cot * CO_TILE + row;
       const int pl = oct * 8;
-      const int ty = pl >> p.twl, tx = pl & (TW - 1);
-      const int oy = y0 + ty, ox = x0 + tx;
-      const bool rowok = (co < p.cout) & (oy < p.out_h);
-      const int cco = min(co, p.cout - 1), coy = min(oy, p.out_h - 1);
-      const float* rowp = p.dz + (long long)n * p.dz_sn + (long long)cco * p.dz_sc + (long long)coy * p.out_w;
-      if (p.aligned4) {   // wave-uniform: out_w % 8 == 0, so an octet is inside or outside the row as a whole
-        const int cox = min(ox, p.out_w - 8);
-        const float4 a = *(const float4*)(rowp + cox), b = *(const float4*)(rowp + cox + 4);
-        const bool ok = rowok & (ox + 8 <= p.out_w);
+      const int cco = min(co, p.cout - 1);
+      const float* planep = p.dz + (long long)n * p.dz_sn + (long long)cco * p.dz_sc;
+      if (p.aligned4) {   // wave-uniform: TW % 8 == 0 and out_w % 8 == 0 -> an octet is inside or outside a row as a whole
+        const int ty = IG_TY(pl, p.tmagic), tx = pl - ty * TW;
+        const int oy = y0 + ty, ox = x0 + tx;
+        const bool ok = (co < p.cout) & (pl < TPIX) & (oy < p.out_h) & (ox + 8 <= p.out_w);
+        const float* rowp = planep + (long long)min(oy, p.out_h - 1) * p.out_w + min(ox, p.out_w - 8);
+        const float4 a = *(const float4*)rowp, b = *(const float4*)(rowp + 4);
         zv[j][0] = ok ? a.x : 0.f; zv[j][1] = ok ? a.y : 0.f; zv[j][2] = ok ? a.z : 0.f; zv[j][3] = ok ? a.w : 0.f;
         zv[j][4] = ok ? b.x : 0.f; zv[j][5] = ok ? b.y : 0.f; zv[j][6] = ok ? b.z : 0.f; zv[j][7] = ok ? b.w : 0.f;
-      } else {
+      } else {            // any tile width: the 8 pixels of an octet may wrap to the next tile row
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float t = rowp[min(ox + e, p.out_w - 1)];
-          zv[j][e] = (rowok & (ox + e < p.out_w)) ? t : 0.f;
+          const int ple = min(pl + e, TPIX - 1);
+          const int ty = IG_TY(ple, p.tmagic), tx = ple - ty * TW;
+          const int oy = y0 + ty, ox = x0 + tx;
+          const float t = planep[(long long)min(oy, p.out_h - 1) * p.out_w + min(ox, p.out_w - 1)];
+          zv[j][e] = ((co < p.cout) & (pl + e < TPIX) & (oy < p.out_h) & (ox < p.out_w)) ? t : 0.f;
         }
       }
     }
@@ -812,8 +828,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const i
       const int colb = ((g & 1) * 16 + 4 * tp) * 2;
 #pragma unroll
       for (int sel = 0; sel < 2; ++sel) {
-        const int pl = ks * 16 + 8 * (g >> 1) + 4 * sel + tq;
-        rty[sel] = pl >> p.twl; rtx[sel] = pl & (TW - 1);
+        const int pl = min(ks * 16 + 8 * (g >> 1) + 4 * sel + tq, TPIX - 1);   // idle slots carry dZ = 0
+        rty[sel] = IG_TY(pl, p.tmagic); rtx[sel] = pl - rty[sel] * TW;
         rowb[sel] = ((rty[sel] * p.stride) * p.iw_t + rtx[sel] * p.stride) * IG_REC_BYTES + colb;
       }
 #pragma unroll
@@ -1013,37 +1029,66 @@ int plan_lds(bool x3, int co_tile, int x_cap, int ntaps, int* tg_out, size_t* ld
 }
 
 struct IgemmPlan {
-  int npb, twl, tiles_x, tiles_y, ih_t, iw_t, clamp, x_cap, tg;
+  int npb, tw, th, tiles_x, tiles_y, ih_t, iw_t, clamp, x_cap, tg;
   size_t lds;
 };
 
-// tile shape / LDS plan of one generic launch: depends only on geometry, taps and precision
-int plan_igemm(int rows, int lh, int lw, int in_h, int in_w, int in_step, const TapSet& taps, bool x3,
-               IgemmPlan* pl) {
-  const int co_tile = 32 * ig_co_blks(rows);
-  // (measured: preferring pipelinable plans over the clamped two-block plan loses on the small-map
-  // discriminator layers, so the largest tile that fits wins and the launcher picks the kernel)
-  for (int npb = 2; npb >= 1; --npb) {
-    pl->twl = ig_twl(lw, lh, 128 * npb);
-    const int TW = 1 << pl->twl;
-    const int TH = (128 * npb) >> pl->twl;
-    if (TH < 1) continue;
-    pl->npb = npb;
-    pl->tiles_x = cdiv(lw, TW);
-    pl->tiles_y = cdiv(lh, TH);
-    pl->ih_t = (TH - 1) * in_step + (taps.dy_max - taps.dy_min) + 1;
-    pl->iw_t = (TW - 1) * in_step + (taps.dx_max - taps.dx_min) + 1;
-    const int full = pl->ih_t * pl->iw_t;
-    const int clipped = (pl->ih_t < in_h ? pl->ih_t : in_h) * (pl->iw_t < in_w ? pl->iw_t : in_w) + 1;
-    // clamp mode pays ~10 VALU per tap and lane; use it when the halo is mostly padding
-    for (int attempt = 0; attempt < 2; ++attempt) {
-      pl->clamp = attempt == 0 ? ((clipped * 2 <= full) ? 1 : 0) : 1;
-      pl->x_cap = pl->clamp ? clipped : full;
-      if (plan_lds(x3, co_tile, pl->x_cap, taps.n, &pl->tg, &pl->lds) == 0) return 0;
-      if (pl->clamp) break;
+// candidate output-tile widths: powers of two plus even splits of the row (so a 17- or 33-wide map is
+// not padded to 32 / 64)
+int tile_width_candidates(int lw, int tile_px, int* out) {
+  int n = 0;
+  for (int t = 8; t <= 256 && t <= tile_px; t <<= 1) out[n++] = t;
+  for (int parts = 1; parts <= 4; ++parts) {
+    const int t = (lw + parts - 1) / parts;
+    if (t >= 4 && t <= 256 && t <= tile_px) {
+      bool dup = false;
+      for (int i = 0; i < n; ++i) dup |= out[i] == t;
+      if (!dup) out[n++] = t;
     }
   }
-  return -1;
+  return n;
+}
+
+// tile shape / LDS plan of one generic launch: depends only on geometry, taps and precision.
+// Minimises the number of MFMA pixel slots (tiles x slots per tile); ties prefer 32-pixel-aligned rows
+// (128-B output segments), two pixel blocks per wave, wider tiles.
+int plan_igemm(int rows, int lh, int lw, int in_h, int in_w, int in_step, const TapSet& taps, bool x3,
+               IgemmPlan* best) {
+  const int co_tile = 32 * ig_co_blks(rows);
+  long long best_key = -1;
+  for (int npb = 2; npb >= 1; --npb) {
+    const int TP = 128 * npb;
+    int cand[16];
+    const int nc = tile_width_candidates(lw, TP, cand);
+    for (int ci = 0; ci < nc; ++ci) {
+      IgemmPlan pl;
+      pl.npb = npb; pl.tw = cand[ci]; pl.th = TP / pl.tw;
+      if (pl.th < 1) continue;
+      pl.tiles_x = cdiv(lw, pl.tw);
+      pl.tiles_y = cdiv(lh, pl.th);
+      pl.ih_t = (pl.th - 1) * in_step + (taps.dy_max - taps.dy_min) + 1;
+      pl.iw_t = (pl.tw - 1) * in_step + (taps.dx_max - taps.dx_min) + 1;
+      const int full = pl.ih_t * pl.iw_t;
+      const int clipped = (pl.ih_t < in_h ? pl.ih_t : in_h) * (pl.iw_t < in_w ? pl.iw_t : in_w) + 1;
+      bool ok = false;
+      // clamp mode pays ~10 VALU per tap and lane; use it when the halo is mostly padding
+      for (int attempt = 0; attempt < 2 && !ok; ++attempt) {
+        pl.clamp = attempt == 0 ? ((clipped * 2 <= full) ? 1 : 0) : 1;
+        pl.x_cap = pl.clamp ? clipped : full;
+        ok = plan_lds(x3, co_tile, pl.x_cap, taps.n, &pl.tg, &pl.lds) == 0;
+        if (pl.clamp) break;
+      }
+      if (!ok) continue;
+      // primary: MFMA pixel slots; then 32-pixel-aligned rows (128-B output segments: measured faster than
+      // 16x16 tiles despite their smaller halo); then staged input pixels per output slot (halo overhead,
+      // in 1/64ths); then two pixel blocks per wave
+      const long long slots = (long long)pl.tiles_x * pl.tiles_y * TP;
+      const long long halo = (long long)pl.x_cap * 64 / TP;
+      const long long key = (slots << 24) + ((pl.tw & 31) ? (1ll << 20) : 0) + (halo << 8) + (npb == 1 ? 1 : 0);
+      if (best_key < 0 || key < best_key) { best_key = key; *best = pl; }
+    }
+  }
+  return best_key < 0 ? -1 : 0;
 }
 
 template <bool X3, int CO_BLKS, bool CLAMP, int NPB>
@@ -1123,7 +1168,7 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
                p.in_step, taps.dy_max - taps.dy_min);
   p.n_co_tiles = cdiv(p.cout, co_tile);
   p.nchunks = cdiv(p.cin, 32);
-  p.twl = pl.twl; p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y;
+  p.tw = pl.tw; p.th = pl.th; p.tmagic = 65536 / pl.tw + 1; p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y;
   p.ntaps = taps.n;
   memcpy(p.dy, taps.dy, sizeof(p.dy));
   memcpy(p.dx, taps.dx, sizeof(p.dx));
@@ -1137,7 +1182,7 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
   const double flops = 2.0 * p.n * (double)p.lh * p.lw * p.cout * (double)p.cin * taps.n;
   char tag[160];
   snprintf(tag, sizeof(tag), "igemm n%d red%d rows%d %dx%d taps%d step%d up%d tw%d npb%d clamp%d tg%d lds%zu", p.n, p.cin,
-           p.cout, p.lh, p.lw, taps.n, p.in_step, p.in_shift, 1 << pl.twl, pl.npb, pl.clamp, pl.tg, pl.lds);
+           p.cout, p.lh, p.lw, taps.n, p.in_step, p.in_shift, pl.tw, pl.npb, pl.clamp, pl.tg, pl.lds);
   ProfScope prof(PCUDA_FAM_CONV_FWD, flops, s, tag);
   static int nopipe = -1;
   if (nopipe < 0) { const char* e = getenv("PCUDA_NOPIPE"); nopipe = e ? atoi(e) : 0; }
@@ -1153,7 +1198,7 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
 }
 
 struct WgradPlan {
-  int co_blks, co_tile, n_co_tiles, n_chunks, tap_groups, taps_per_group, twl, tiles_x, tiles_y, ksplit;
+  int co_blks, co_tile, n_co_tiles, n_chunks, tap_groups, taps_per_group, tw, th, tiles_x, tiles_y, ksplit;
   int ih_t, iw_t;
 };
 
@@ -1166,8 +1211,21 @@ WgradPlan plan_wgrad(const pcuda_conv_geom* g) {
   const int ntaps = g->k * g->k;
   w.tap_groups = ntaps <= 16 ? 1 : cdiv(ntaps, 9);   // 4x4 kernels keep all 16 taps in one block: X and dZ staged once
   w.taps_per_group = cdiv(ntaps, w.tap_groups);
-  w.twl = ig_twl(g->out_w, g->out_h, 128);
-  const int TW = 1 << w.twl, TH = 128 >> w.twl;
+  {   // 128-slot tile with the fewest tiles; ties prefer widths that keep the float4 dZ path (TW % 8 == 0)
+    int cand[16];
+    const int nc = tile_width_candidates(g->out_w, 128, cand);
+    long long best_key = -1;
+    w.tw = 32; w.th = 4;
+    for (int ci = 0; ci < nc; ++ci) {
+      const int tw = cand[ci], th = 128 / tw;
+      if (th < 1) continue;
+      const int span = (g->k - 1) * g->dil;
+      const long long halo = (long long)((th - 1) * g->stride + span + 1) * ((tw - 1) * g->stride + span + 1);
+      const long long key = ((long long)cdiv(g->out_w, tw) * cdiv(g->out_h, th) << 24) + ((tw & 31) ? (1ll << 20) : 0) + halo;
+      if (best_key < 0 || key < best_key) { best_key = key; w.tw = tw; w.th = th; }
+    }
+  }
+  const int TW = w.tw, TH = w.th;
   w.tiles_x = cdiv(g->out_w, TW);
   w.tiles_y = cdiv(g->out_h, TH);
   const int span = (g->k - 1) * g->dil;
@@ -1336,10 +1394,10 @@ extern "C" int pcuda_conv2d_wgrad(const pcuda_conv_geom* g, int prec, const pcud
   memcpy(p.dx, t.dx, sizeof(p.dx));
   p.dy_min = t.dy_min; p.dx_min = t.dx_min;
   p.ih_t = w.ih_t; p.iw_t = w.iw_t;
-  p.twl = w.twl; p.tiles_x = w.tiles_x; p.tiles_y = w.tiles_y; p.n = g->n;
+  p.tw = w.tw; p.th = w.th; p.tmagic = 65536 / w.tw + 1; p.tiles_x = w.tiles_x; p.tiles_y = w.tiles_y; p.n = g->n;
   p.ksplit = w.ksplit; p.n_co_tiles = w.n_co_tiles; p.n_chunks = w.n_chunks;
   p.partial = (float*)workspace;
-  p.aligned4 = ((g->out_w & 7) == 0 && (dy_sn & 3) == 0 && (dy_sc & 3) == 0 && (((uintptr_t)dy) & 15) == 0) ? 1 : 0;
+  p.aligned4 = ((g->out_w & 7) == 0 && (w.tw & 7) == 0 && (dy_sn & 3) == 0 && (dy_sc & 3) == 0 && (((uintptr_t)dy) & 15) == 0) ? 1 : 0;
   const long long welems = (long long)g->cout * g->cin * t.n;
   float* dbp = db ? (float*)workspace + (size_t)w.ksplit * welems : nullptr;
 
