@@ -59,6 +59,7 @@ struct WgradParams {
   int n_co_tiles, n_chunks;
   float* partial;          // [ksplit][cout][cin][ntaps_total] fp32
   int aligned4;            // dz rows can be read with float4
+  int dbg;                 // PCUDA_DBG bits (timing experiments only): 16 no X staging, 32 no dZ staging, 64 no MFMA
 };
 
 struct PackParams {
