@@ -69,7 +69,7 @@ template <bool X3, int PF>
 __device__ __forceinline__ void stage_x_chunk_mlp(unsigned char* __restrict__ xhi, unsigned char* __restrict__ xlo,
                                                   const pcuda_src& x, int n, int cin, int chunk, int in_h, int in_w,
                                                   int in_shift, int in_row, int oy0, int ox0, int th, int tw,
-                                                  int ngroups, int tid0) {
+                                                  int ngroups, int nwrite, int tid0) {
   const int npix = th * tw;
   const int cbase = chunk * 32;
   const int tid = tid0;   // first pixel slot of this lane (callers may offset it to walk big tiles)
@@ -101,6 +101,14 @@ __device__ __forceinline__ void stage_x_chunk_mlp(unsigned char* __restrict__ xh
   }
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
+    if (g >= ngroups && g < nwrite) {   // k-step channels past cin: zeros, not LDS garbage
+#pragma unroll
+      for (int s = 0; s < PF; ++s)
+        if (tid + s * 256 < npix) {
+          *(uint4*)(xhi + (size_t)(tid + s * 256) * IG_REC_BYTES + g * 16) = make_uint4(0, 0, 0, 0);
+          if (X3) *(uint4*)(xlo + (size_t)(tid + s * 256) * IG_REC_BYTES + g * 16) = make_uint4(0, 0, 0, 0);
+        }
+    }
     if (g < ngroups) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -124,17 +132,22 @@ __device__ __forceinline__ void stage_x_chunk_mlp(unsigned char* __restrict__ xh
   }
 }
 
-template <bool X3>
+template <bool X3, int MAXPF = 3>
 __device__ __forceinline__ void stage_x_chunk(unsigned char* __restrict__ xhi, unsigned char* __restrict__ xlo,
                                               const pcuda_src& x, int n, int cin, int chunk, int in_h, int in_w,
                                               int in_shift, int in_row, int oy0, int ox0, int th, int tw,
-                                              int ngroups, int tid) {
+                                              int ngroups, int nwrite, int tid) {
   const int npix = th * tw;
-  if (npix <= 256) { stage_x_chunk_mlp<X3, 1>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, tid); return; }
-  if (npix <= 512) { stage_x_chunk_mlp<X3, 2>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, tid); return; }
-  if (npix <= 768) { stage_x_chunk_mlp<X3, 3>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, tid); return; }
+  if (MAXPF == 1) {   // register-tight callers (wgrad: 80+ accumulator registers): 32 loads in flight per lane
+    for (int pix0 = 0; pix0 < npix; pix0 += 256)
+      stage_x_chunk_mlp<X3, 1>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, nwrite, tid + pix0);
+    return;
+  }
+  if (npix <= 256) { stage_x_chunk_mlp<X3, 1>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, nwrite, tid); return; }
+  if (npix <= 512) { stage_x_chunk_mlp<X3, 2>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, nwrite, tid); return; }
+  if (npix <= 768) { stage_x_chunk_mlp<X3, 3>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, nwrite, tid); return; }
   for (int pix0 = 0; pix0 < npix; pix0 += 512)   // big tiles: 512 pixels at a time
-    stage_x_chunk_mlp<X3, 2>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, tid + pix0);
+    stage_x_chunk_mlp<X3, 2>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, nwrite, tid + pix0);
 }
 
 // contiguous global -> LDS copy of nvec 16-B vectors, 4 loads per lane in flight
@@ -224,7 +237,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p, const i
     __syncthreads();   // every wave is done reading the previous chunk's X / W
     if (!(p.dbg & 1))
       stage_x_chunk<X3>(Xhi, Xlo, p.x, n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row, oy0, ox0, th, tw,
-                        nks * 2, tid);
+                        (cvalid + 7) >> 3, nks * 2, tid);
     if (CLAMP && tid < 5) {   // the all-zero record that out-of-image taps read
       *(uint4*)(Xhi + (size_t)npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
       if (X3) *(uint4*)(Xlo + (size_t)npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
@@ -748,7 +761,6 @@ __global__ __launch_bounds__(256, (TAPS_MAX <= 9 ? 2 : 1)) void wgrad_kernel(con
   // transposed-read lane roles: 16-lane group g -> k half (g>>1), column block (g&1)
   const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
   const int cvalid = min(32, p.cin - chunk * 32);
-  (void)cvalid;
 
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
     const int txi = tile % p.tiles_x;
@@ -766,7 +778,8 @@ __global__ __launch_bounds__(256, (TAPS_MAX <= 9 ? 2 : 1)) void wgrad_kernel(con
     const int npix = th * tw;
     __syncthreads();
     if (!(p.dbg & 16))
-      stage_x_chunk<X3>(Xhi, Xlo, p.x, n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row, oy0, ox0, th, tw, 4, tid);
+      stage_x_chunk<X3, 1>(Xhi, Xlo, p.x, n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row, oy0, ox0, th, tw,
+                           (cvalid + 7) >> 3, 4, tid);
     if (CLAMP && tid < 5) {
       *(uint4*)(Xhi + (size_t)npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
       if (X3) *(uint4*)(Xlo + (size_t)npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
