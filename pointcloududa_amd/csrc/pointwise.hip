@@ -14,6 +14,25 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
   return sh[0] + sh[1] + sh[2] + sh[3];   // blockDim = 256
 }
 
+
+// 16-B vector path: used when hw % 4 == 0 and every plane base / stride is 16-B aligned
+template <int VEC> struct VecT;
+template <> struct VecT<1> { typedef float T; };
+template <> struct VecT<4> { typedef float4 T; };
+template <int VEC> __device__ __forceinline__ void vload(const float* p, float (&v)[VEC]);
+template <> __device__ __forceinline__ void vload<1>(const float* p, float (&v)[1]) { v[0] = *p; }
+template <> __device__ __forceinline__ void vload<4>(const float* p, float (&v)[4]) {
+  const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <int VEC> __device__ __forceinline__ void vstore(float* p, const float (&v)[VEC]);
+template <> __device__ __forceinline__ void vstore<1>(float* p, const float (&v)[1]) { *p = v[0]; }
+template <> __device__ __forceinline__ void vstore<4>(float* p, const float (&v)[4]) {
+  *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+}
+static inline bool vec_ok(const void* p, long long sn, long long sc, long long hw) {
+  return p == nullptr || ((((uintptr_t)p) & 15) == 0 && (sn & 3) == 0 && (sc & 3) == 0 && (hw & 3) == 0);
+}
+
 // ---------------------------------------------------------------------------- statistics
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ a, long long sn, long long sc,
                                                        long long hw, int c, float* __restrict__ partials) {
@@ -78,6 +97,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   }
 }
 
+template <int VEC>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ a, long long a_sn, long long a_sc,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        int relu, float* __restrict__ y, long long y_sn, long long y_sc,
@@ -87,14 +107,20 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   float* py = y + n * y_sn + ch * y_sc;
   const float sc = scale[ch], sf = shift[ch];
   const long long i0 = (long long)blockIdx.x * PCH, i1 = min(hw, i0 + PCH);
-  for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
-    float v = pa[i] * sc + sf;
-    if (relu) v = v > 0.f ? v : 0.f;
-    py[i] = v;
+  for (long long i = i0 + threadIdx.x * VEC; i < i1; i += 256 * VEC) {
+    float v[VEC];
+    vload<VEC>(pa + i, v);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      v[e] = v[e] * sc + sf;
+      if (relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
+    }
+    vstore<VEC>(py + i, v);
   }
 }
 
 // ---------------------------------------------------------------------------- backward
+template <int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float* __restrict__ dy, long long dy_sn, long long dy_sc, const float* __restrict__ dy2, long long dy2_sn,
     long long dy2_sc, const float* __restrict__ a, long long a_sn, long long a_sc, const float* __restrict__ mean,
@@ -109,13 +135,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
   const float sc = post_relu ? scale[ch] : 0.f, sf = post_relu ? shift[ch] : 0.f;
   const long long i0 = (long long)blockIdx.x * PCH, i1 = min(hw, i0 + PCH);
   float s1 = 0.f, s2 = 0.f;
-  for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
-    const float av = pa[i];
-    float g = pd[i];
-    if (pd2) g += pd2[i];
-    if (post_relu && !(av * sc + sf > 0.f)) g = 0.f;
-    s1 += g;
-    s2 += g * ((av - m) * is);
+  for (long long i = i0 + threadIdx.x * VEC; i < i1; i += 256 * VEC) {
+    float av[VEC], g[VEC], g2[VEC];
+    vload<VEC>(pa + i, av);
+    vload<VEC>(pd + i, g);
+    if (pd2) vload<VEC>(pd2 + i, g2);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float gg = pd2 ? g[e] + g2[e] : g[e];
+      if (post_relu && !(av[e] * sc + sf > 0.f)) gg = 0.f;
+      s1 += gg;
+      s2 += gg * ((av[e] - m) * is);
+    }
   }
   s1 = block_sum(s1, sh);
   s2 = block_sum(s2, sh);
@@ -160,6 +191,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   }
 }
 
+template <int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ dy, long long dy_sn, long long dy_sc, const float* __restrict__ dy2, long long dy2_sn,
     long long dy2_sc, const float* __restrict__ a, long long a_sn, long long a_sc, const float* __restrict__ coef,
@@ -173,21 +205,26 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
   const float c0 = coef[ch * 3 + 0], c1 = coef[ch * 3 + 1], c2 = coef[ch * 3 + 2];
   const float sc = post_relu ? scale[ch] : 0.f, sf = post_relu ? shift[ch] : 0.f;
   const long long i0 = (long long)blockIdx.x * PCH, i1 = min(hw, i0 + PCH);
-  for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
-    const float av = pa[i];
-    float g = pd[i];
-    if (pd2) g += pd2[i];
-    float out;
-    if (post_relu) {
-      if (!(av * sc + sf > 0.f)) g = 0.f;
-      out = c0 * g + c1 * av + c2;
-    } else {
-      out = (c0 * g + c1 * av + c2) * (av > 0.f ? 1.f : act_slope);
+  for (long long i = i0 + threadIdx.x * VEC; i < i1; i += 256 * VEC) {
+    float av[VEC], g[VEC], g2[VEC], out[VEC];
+    vload<VEC>(pa + i, av);
+    vload<VEC>(pd + i, g);
+    if (pd2) vload<VEC>(pd2 + i, g2);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float gg = pd2 ? g[e] + g2[e] : g[e];
+      if (post_relu) {
+        if (!(av[e] * sc + sf > 0.f)) gg = 0.f;
+        out[e] = c0 * gg + c1 * av[e] + c2;
+      } else {
+        out[e] = (c0 * gg + c1 * av[e] + c2) * (av[e] > 0.f ? 1.f : act_slope);
+      }
     }
-    pz[i] = out;
+    vstore<VEC>(pz + i, out);
   }
 }
 
+template <int VEC>
 __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* __restrict__ dy, long long dy_sn, long long dy_sc,
                                                         const float* __restrict__ dy2, long long dy2_sn,
                                                         long long dy2_sc, const float* __restrict__ a, long long a_sn,
@@ -199,10 +236,17 @@ __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* __restrict_
   const float* pa = a + n * a_sn + ch * a_sc;
   float* pz = dz + n * dz_sn + ch * dz_sc;
   const long long i0 = (long long)blockIdx.x * PCH, i1 = min(hw, i0 + PCH);
-  for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
-    float g = pd[i];
-    if (pd2) g += pd2[i];
-    pz[i] = pa[i] > 0.f ? g : g * slope;
+  for (long long i = i0 + threadIdx.x * VEC; i < i1; i += 256 * VEC) {
+    float av[VEC], g[VEC], g2[VEC], out[VEC];
+    vload<VEC>(pa + i, av);
+    vload<VEC>(pd + i, g);
+    if (pd2) vload<VEC>(pd2 + i, g2);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float gg = pd2 ? g[e] + g2[e] : g[e];
+      out[e] = av[e] > 0.f ? gg : gg * slope;
+    }
+    vstore<VEC>(pz + i, out);
   }
 }
 
@@ -363,8 +407,12 @@ extern "C" int pcuda_bn_apply(const float* a, long long a_sn, long long a_sc, co
                               pcuda_stream_t s) {
   if (!dims_ok(n, c, hw) || !a || !y || !scale || !shift) PCUDA_FAIL(PCUDA_E_BADARG, "bn_apply: bad arguments");
   ProfScope prof(PCUDA_FAM_POINTWISE, 8.0 * n * c * (double)hw, (hipStream_t)s);
-  hipLaunchKernelGGL(bn_apply_kernel, plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, a, a_sn, a_sc, scale, shift,
-                     relu, y, y_sn, y_sc, hw);
+  if (vec_ok(a, a_sn, a_sc, hw) && vec_ok(y, y_sn, y_sc, hw))
+    hipLaunchKernelGGL(bn_apply_kernel<4>, plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, a, a_sn, a_sc, scale,
+                       shift, relu, y, y_sn, y_sc, hw);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<1>, plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, a, a_sn, a_sc, scale,
+                       shift, relu, y, y_sn, y_sc, hw);
   PCUDA_CHECK_LAUNCH("bn_apply_kernel");
   return PCUDA_OK;
 }
@@ -381,8 +429,12 @@ extern "C" int pcuda_bn_bwd_reduce(const float* dy, long long dy_sn, long long d
   if (!dy || !a || !mean || !invstd || (post_relu && (!scale || !shift)))
     PCUDA_FAIL(PCUDA_E_BADARG, "bn_bwd_reduce: null pointer");
   ProfScope prof(PCUDA_FAM_POINTWISE, (dy2 ? 12.0 : 8.0) * n * c * (double)hw, (hipStream_t)s);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, dy, dy_sn, dy_sc, dy2,
-                     dy2_sn, dy2_sc, a, a_sn, a_sc, mean, invstd, scale, shift, post_relu, hw, c, red);
+  if (vec_ok(dy, dy_sn, dy_sc, hw) && vec_ok(dy2, dy2_sn, dy2_sc, hw) && vec_ok(a, a_sn, a_sc, hw))
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, dy, dy_sn, dy_sc,
+                       dy2, dy2_sn, dy2_sc, a, a_sn, a_sc, mean, invstd, scale, shift, post_relu, hw, c, red);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, dy, dy_sn, dy_sc,
+                       dy2, dy2_sn, dy2_sc, a, a_sn, a_sc, mean, invstd, scale, shift, post_relu, hw, c, red);
   PCUDA_CHECK_LAUNCH("bn_bwd_reduce_kernel");
   return PCUDA_OK;
 }
@@ -406,8 +458,13 @@ extern "C" int pcuda_bn_bwd_apply(const float* dy, long long dy_sn, long long dy
   if (!dims_ok(n, c, hw) || !dy || !a || !coef || !dz || (post_relu && (!scale || !shift)))
     PCUDA_FAIL(PCUDA_E_BADARG, "bn_bwd_apply: bad arguments");
   ProfScope prof(PCUDA_FAM_POINTWISE, (dy2 ? 16.0 : 12.0) * n * c * (double)hw, (hipStream_t)s);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, dy, dy_sn, dy_sc, dy2,
-                     dy2_sn, dy2_sc, a, a_sn, a_sc, coef, scale, shift, post_relu, act_slope, dz, dz_sn, dz_sc, hw);
+  if (vec_ok(dy, dy_sn, dy_sc, hw) && vec_ok(dy2, dy2_sn, dy2_sc, hw) && vec_ok(a, a_sn, a_sc, hw) &&
+      vec_ok(dz, dz_sn, dz_sc, hw))
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, dy, dy_sn, dy_sc,
+                       dy2, dy2_sn, dy2_sc, a, a_sn, a_sc, coef, scale, shift, post_relu, act_slope, dz, dz_sn, dz_sc, hw);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, dy, dy_sn, dy_sc,
+                       dy2, dy2_sn, dy2_sc, a, a_sn, a_sc, coef, scale, shift, post_relu, act_slope, dz, dz_sn, dz_sc, hw);
   PCUDA_CHECK_LAUNCH("bn_bwd_apply_kernel");
   return PCUDA_OK;
 }
@@ -418,8 +475,13 @@ extern "C" int pcuda_lrelu_bwd(const float* dy, long long dy_sn, long long dy_sc
                                pcuda_stream_t s) {
   if (!dims_ok(n, c, hw) || !dy || !a || !dz) PCUDA_FAIL(PCUDA_E_BADARG, "lrelu_bwd: bad arguments");
   ProfScope prof(PCUDA_FAM_POINTWISE, (dy2 ? 16.0 : 12.0) * n * c * (double)hw, (hipStream_t)s);
-  hipLaunchKernelGGL(lrelu_bwd_kernel, plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, dy, dy_sn, dy_sc, dy2,
-                     dy2_sn, dy2_sc, a, a_sn, a_sc, slope, dz, dz_sn, dz_sc, hw);
+  if (vec_ok(dy, dy_sn, dy_sc, hw) && vec_ok(dy2, dy2_sn, dy2_sc, hw) && vec_ok(a, a_sn, a_sc, hw) &&
+      vec_ok(dz, dz_sn, dz_sc, hw))
+    hipLaunchKernelGGL(lrelu_bwd_kernel<4>, plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, dy, dy_sn, dy_sc, dy2,
+                       dy2_sn, dy2_sc, a, a_sn, a_sc, slope, dz, dz_sn, dz_sc, hw);
+  else
+    hipLaunchKernelGGL(lrelu_bwd_kernel<1>, plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, dy, dy_sn, dy_sc, dy2,
+                       dy2_sn, dy2_sc, a, a_sn, a_sc, slope, dz, dz_sn, dz_sc, hw);
   PCUDA_CHECK_LAUNCH("lrelu_bwd_kernel");
   return PCUDA_OK;
 }
