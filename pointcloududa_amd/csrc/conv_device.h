@@ -1,0 +1,333 @@
+// Device-side staging helpers shared by the forward/dgrad and the wgrad kernels.
+#pragma once
+#include "conv_igemm.h"
+
+// ------------------------------------------------------------------------------------------
+// stage one 32-channel chunk of a haloed input tile into LDS, pixel-major, bf16 hi (+ lo)
+// ------------------------------------------------------------------------------------------
+template <bool X3>
+__device__ __forceinline__ void stage_write(unsigned char* __restrict__ xhi, unsigned char* __restrict__ xlo,
+                                            const float (&v)[8], int pix, int g) {
+  uint4 hi, lo;
+  if (X3) {
+    split2(v[0], v[1], hi.x, lo.x); split2(v[2], v[3], hi.y, lo.y);
+    split2(v[4], v[5], hi.z, lo.z); split2(v[6], v[7], hi.w, lo.w);
+    *(uint4*)(xlo + (size_t)pix * IG_REC_BYTES + g * 16) = lo;
+  } else {
+    hi.x = pack_bf16x2(v[0], v[1]); hi.y = pack_bf16x2(v[2], v[3]);
+    hi.z = pack_bf16x2(v[4], v[5]); hi.w = pack_bf16x2(v[6], v[7]);
+  }
+  *(uint4*)(xhi + (size_t)pix * IG_REC_BYTES + g * 16) = hi;
+}
+
+// wave-uniform channel -> plane pointer / lazy-BatchNorm affine of a two-source input.  Selects on
+// scalars (no branches per channel: the branchy form compiled to ~25 scalar instructions and three
+// branches per channel).
+__device__ __forceinline__ const char* src_chan(const pcuda_src& x, const char* b1, const char* b2, int c) {
+  const bool first = c < x.c1;
+  const char* cb = first ? b1 : b2;
+  return cb + (long long)(first ? c : c - x.c1) * (first ? x.sc1 : x.sc2) * 4;
+}
+__device__ __forceinline__ void src_affine(const pcuda_src& x, int c, float& sc, float& sh) {
+  const bool first = c < x.c1;
+  const float* scp = first ? x.scale1 : x.scale2;
+  const float* shp = first ? x.shift1 : x.shift2;
+  const int cc = first ? c : c - x.c1;
+  sc = 1.f; sh = 0.f;
+  if (scp) { sc = scp[cc]; sh = shp[cc]; }
+}
+
+// PF pixels per thread (npix <= PF*256), everything unrolled.  Instruction-lean by construction:
+//  * the channel plane base (p + n*sn + c*sc) is wave-uniform -> SGPR pair; each lane adds ONE 32-bit
+//    byte offset computed once per pixel slot -> `global_load_dword v, v_off, s[base]`, no 64-bit VALU;
+//  * loads are UNCONDITIONAL on clamped (always valid) addresses and the padding zeros are selected
+//    afterwards: a per-lane `if (inb) load` makes hipcc branch around every load and wait for it
+//    (cdna_hip_programming.md, "Three .s-level traps" (c));
+//  * the lazy-BatchNorm scale/shift are read in uniform control flow (scalar loads), one fma per value.
+// Phase 1 issues all 32*PF loads of the chunk, phase 2 applies the affine, splits and writes LDS.
+template <bool X3, int PF>
+__device__ __forceinline__ void stage_x_chunk_mlp(unsigned char* __restrict__ xhi, unsigned char* __restrict__ xlo,
+                                                  const pcuda_src& x, int n, int cin, int chunk, int in_h, int in_w,
+                                                  int in_shift, int in_row, int oy0, int ox0, int th, int tw,
+                                                  int ngroups, int nwrite, int tid0) {
+  const int npix = th * tw;
+  const int cbase = chunk * 32;
+  const int tid = tid0;   // first pixel slot of this lane (callers may offset it to walk big tiles)
+  unsigned voff[PF];
+  bool inb[PF];
+#pragma unroll
+  for (int s = 0; s < PF; ++s) {
+    const int pix = min(tid + s * 256, npix - 1);
+    const int iy = pix / tw, ix = pix - iy * tw;
+    const int gy = oy0 + iy, gx = ox0 + ix;
+    inb[s] = (tid + s * 256 < npix) & ((unsigned)gy < (unsigned)in_h) & ((unsigned)gx < (unsigned)in_w);
+    const int cy = min(max(gy, 0), in_h - 1), cx = min(max(gx, 0), in_w - 1);
+    voff[s] = (unsigned)((cy >> in_shift) * in_row + (cx >> in_shift)) * 4u;
+  }
+  const char* b1 = (const char*)(x.p1 + (long long)n * x.sn1);
+  const char* b2 = (const char*)(x.p2 + (long long)n * x.sn2);
+  float v[PF][4][8];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (g < ngroups) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = min(cbase + g * 8 + j, cin - 1);   // wave-uniform, clamped
+        const char* chan = src_chan(x, b1, b2, c);
+#pragma unroll
+        for (int s = 0; s < PF; ++s) v[s][g][j] = *(const float*)(chan + voff[s]);
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (g >= ngroups && g < nwrite) {   // k-step channels past cin: zeros, not LDS garbage
+#pragma unroll
+      for (int s = 0; s < PF; ++s)
+        if (tid + s * 256 < npix) {
+          *(uint4*)(xhi + (size_t)(tid + s * 256) * IG_REC_BYTES + g * 16) = make_uint4(0, 0, 0, 0);
+          if (X3) *(uint4*)(xlo + (size_t)(tid + s * 256) * IG_REC_BYTES + g * 16) = make_uint4(0, 0, 0, 0);
+        }
+    }
+    if (g < ngroups) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = cbase + g * 8 + j;
+        const bool cok = c < cin;
+        float sc, sh;
+        src_affine(x, min(c, cin - 1), sc, sh);
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+          const float t = fmaf(v[s][g][j], sc, sh);
+          v[s][g][j] = (inb[s] & cok) ? t : 0.f;
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < PF; ++s)
+        if (tid + s * 256 < npix) stage_write<X3>(xhi, xlo, v[s][g], tid + s * 256, g);
+    }
+  }
+}
+
+template <bool X3, int MAXPF = 3>
+__device__ __forceinline__ void stage_x_chunk(unsigned char* __restrict__ xhi, unsigned char* __restrict__ xlo,
+                                              const pcuda_src& x, int n, int cin, int chunk, int in_h, int in_w,
+                                              int in_shift, int in_row, int oy0, int ox0, int th, int tw,
+                                              int ngroups, int nwrite, int tid) {
+  const int npix = th * tw;
+  if (MAXPF == 1) {   // register-tight callers (wgrad: 80+ accumulator registers): 32 loads in flight per lane
+    for (int pix0 = 0; pix0 < npix; pix0 += 256)
+      stage_x_chunk_mlp<X3, 1>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, nwrite, tid + pix0);
+    return;
+  }
+  if (npix <= 256) { stage_x_chunk_mlp<X3, 1>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, nwrite, tid); return; }
+  if (npix <= 512) { stage_x_chunk_mlp<X3, 2>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, nwrite, tid); return; }
+  if (npix <= 768) { stage_x_chunk_mlp<X3, 3>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, nwrite, tid); return; }
+  for (int pix0 = 0; pix0 < npix; pix0 += 512)   // big tiles: 512 pixels at a time
+    stage_x_chunk_mlp<X3, 2>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, nwrite, tid + pix0);
+}
+
+// ------------------------------------------------------------------------------------------
+// Fast staging path (software-pipelined kernels).  Loads go through a buffer resource over the
+// chunk's source image: the per-lane pixel offset (32 bit) sits in voffset, the wave-uniform channel
+// offset in soffset, so a load costs one scalar add and no vector address arithmetic (the flat-address
+// form spent ~10 vector instructions per load on 64-bit pointers).  The hardware range check does the
+// zero padding: lanes outside the image (or past the tile) carry voffset = IG_OOB and read 0, channels
+// past the source's last plane exceed num_records and read 0.
+// Host guarantees (fast_src_ok): a 32-channel chunk never straddles the two sources and every
+// source image spans < 2^30 bytes.
+// ------------------------------------------------------------------------------------------
+#define IG_OOB 0x40000000u
+
+template <int PF>
+struct XFast {
+  float v[PF][32];
+  bool inb[PF];
+};
+
+// issue: npix halo pixels x (8*ngroups) channels of chunk `chunk`, image n; values stay in registers
+template <int PF>
+__device__ __forceinline__ void xfast_issue(XFast<PF>& pre, const pcuda_src& x, int n, int cin, int chunk, int in_h,
+                                            int in_w, int in_shift, int in_row, int oy0, int ox0, int tw, int npix,
+                                            int ngroups, int tid) {
+  const int c0 = chunk * 32;
+  const bool first = c0 < x.c1;
+  const float* base = first ? x.p1 + (long long)n * x.sn1 : x.p2 + (long long)n * x.sn2;
+  const int csrc = first ? min(x.c1, cin) : cin - x.c1;   // channels held by this source
+  const int cl0 = first ? c0 : c0 - x.c1;                 // chunk's first channel inside the source
+  const unsigned plane = (unsigned)(first ? x.sc1 : x.sc2) * 4u;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(csrc * plane), 0x00020000);
+  unsigned voff[PF];
+#pragma unroll
+  for (int s = 0; s < PF; ++s) {
+    const int pix = tid + s * 256;
+    const int iy = pix / tw, ix = pix - iy * tw;
+    const int gy = oy0 + iy, gx = ox0 + ix;
+    pre.inb[s] = (pix < npix) & ((unsigned)gy < (unsigned)in_h) & ((unsigned)gx < (unsigned)in_w);
+    voff[s] = pre.inb[s] ? (unsigned)((gy >> in_shift) * in_row + (gx >> in_shift)) * 4u : IG_OOB;
+  }
+  unsigned soff = (unsigned)cl0 * plane;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (g < ngroups) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s)
+          pre.v[s][g * 8 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[s], soff, 0));
+        soff += plane;
+      }
+    }
+  }
+}
+
+// commit: lazy-BatchNorm affine (if the source has one), bf16 hi/lo split, LDS write
+template <bool X3, int PF>
+__device__ __forceinline__ void xfast_commit(XFast<PF>& pre, unsigned char* __restrict__ xhi,
+                                             unsigned char* __restrict__ xlo, const pcuda_src& x, int cin, int chunk,
+                                             int npix, int ngroups, int nwrite, int tid) {
+  const int c0 = chunk * 32;
+  const bool first = c0 < x.c1;
+  const float* scp = first ? x.scale1 : x.scale2;
+  const float* shp = first ? x.shift1 : x.shift2;
+  const int csrc = first ? min(x.c1, cin) : cin - x.c1;
+  const int cl0 = first ? c0 : c0 - x.c1;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (g >= ngroups && g < nwrite) {   // channels past cin inside a 16-wide k-step: zeros, not LDS garbage
+#pragma unroll
+      for (int s = 0; s < PF; ++s)
+        if (tid + s * 256 < npix) {
+          *(uint4*)(xhi + (size_t)(tid + s * 256) * IG_REC_BYTES + g * 16) = make_uint4(0, 0, 0, 0);
+          if (X3) *(uint4*)(xlo + (size_t)(tid + s * 256) * IG_REC_BYTES + g * 16) = make_uint4(0, 0, 0, 0);
+        }
+    }
+    if (g < ngroups) {
+      if (scp) {   // uniform
+        float sc[8], sh[8];
+        if (cl0 + g * 8 + 8 <= csrc) {   // whole group valid: consecutive scalar loads
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { sc[j] = scp[cl0 + g * 8 + j]; sh[j] = shp[cl0 + g * 8 + j]; }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int cc = cl0 + g * 8 + j;
+            const bool cok = cc < csrc;
+            const float a = scp[min(cc, csrc - 1)], b = shp[min(cc, csrc - 1)];
+            sc[j] = cok ? a : 0.f; sh[j] = cok ? b : 0.f;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int s = 0; s < PF; ++s) {
+            const float t = fmaf(pre.v[s][g * 8 + j], sc[j], sh[j]);
+            pre.v[s][g * 8 + j] = pre.inb[s] ? t : 0.f;   // zero padding is applied AFTER the affine
+          }
+      }
+#pragma unroll
+      for (int s = 0; s < PF; ++s)
+        if (tid + s * 256 < npix) {
+          float (&v)[32] = pre.v[s];
+          const float vv[8] = {v[g * 8 + 0], v[g * 8 + 1], v[g * 8 + 2], v[g * 8 + 3],
+                               v[g * 8 + 4], v[g * 8 + 5], v[g * 8 + 6], v[g * 8 + 7]};
+          stage_write<X3>(xhi, xlo, vv, tid + s * 256, g);
+        }
+    }
+  }
+}
+
+// contiguous global -> LDS copy of nvec 16-B vectors, 4 loads per lane in flight
+__device__ __forceinline__ void copy_vec16(unsigned char* __restrict__ dst, const uint4* __restrict__ src, int nvec,
+                                           int tid) {
+  for (int base = 0; base < nvec; base += 1024) {
+    uint4 r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + tid + u * 256;
+      r[u] = src[i < nvec ? i : nvec - 1];   // unconditional (clamped) load keeps r[] in registers
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + tid + u * 256;
+      if (i < nvec) ((uint4*)dst)[i] = r[u];
+    }
+  }
+}
+
+__device__ __forceinline__ bf16x8 lds_frag(const unsigned char* p) {
+  return __builtin_bit_cast(bf16x8, *(const uint4*)p);
+}
+
+template <int PF>
+struct XPre {
+  float v[PF][4][8];
+  bool inb[PF];
+};
+
+template <int PF>
+__device__ __forceinline__ void xpre_issue(XPre<PF>& pre, const pcuda_src& x, int n, int cin, int chunk, int in_h,
+                                           int in_w, int in_shift, int in_row, int oy0, int ox0, int tw, int npix,
+                                           int ngroups, int tid) {
+  const int cbase = chunk * 32;
+  unsigned voff[PF];
+#pragma unroll
+  for (int s = 0; s < PF; ++s) {
+    const int pix = min(tid + s * 256, npix - 1);
+    const int iy = pix / tw, ix = pix - iy * tw;
+    const int gy = oy0 + iy, gx = ox0 + ix;
+    pre.inb[s] = (tid + s * 256 < npix) & ((unsigned)gy < (unsigned)in_h) & ((unsigned)gx < (unsigned)in_w);
+    const int cy = min(max(gy, 0), in_h - 1), cx = min(max(gx, 0), in_w - 1);
+    voff[s] = (unsigned)((cy >> in_shift) * in_row + (cx >> in_shift)) * 4u;
+  }
+  const char* b1 = (const char*)(x.p1 + (long long)n * x.sn1);
+  const char* b2 = (const char*)(x.p2 + (long long)n * x.sn2);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (g < ngroups) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = min(cbase + g * 8 + j, cin - 1);   // wave-uniform, clamped
+        const char* chan = src_chan(x, b1, b2, c);
+#pragma unroll
+        for (int s = 0; s < PF; ++s) pre.v[s][g][j] = *(const float*)(chan + voff[s]);
+      }
+    }
+  }
+}
+
+template <bool X3, int PF>
+__device__ __forceinline__ void xpre_commit(XPre<PF>& pre, unsigned char* __restrict__ xhi,
+                                            unsigned char* __restrict__ xlo, const pcuda_src& x, int cin, int chunk,
+                                            int npix, int ngroups, int nwrite, int tid) {
+  const int cbase = chunk * 32;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (g >= ngroups && g < nwrite) {   // channels past cin inside a 16-wide k-step: zeros, not LDS garbage
+#pragma unroll
+      for (int s = 0; s < PF; ++s)
+        if (tid + s * 256 < npix) {
+          *(uint4*)(xhi + (size_t)(tid + s * 256) * IG_REC_BYTES + g * 16) = make_uint4(0, 0, 0, 0);
+          if (X3) *(uint4*)(xlo + (size_t)(tid + s * 256) * IG_REC_BYTES + g * 16) = make_uint4(0, 0, 0, 0);
+        }
+    }
+    if (g < ngroups) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = cbase + g * 8 + j;
+        const bool cok = c < cin;
+        float sc, sh;
+        src_affine(x, min(c, cin - 1), sc, sh);
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+          const float t = fmaf(pre.v[s][g][j], sc, sh);
+          pre.v[s][g][j] = (pre.inb[s] & cok) ? t : 0.f;
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < PF; ++s)
+        if (tid + s * 256 < npix) stage_write<X3>(xhi, xlo, pre.v[s][g], tid + s * 256, g);
+    }
+  }
+}
+

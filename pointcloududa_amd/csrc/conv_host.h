@@ -1,0 +1,108 @@
+// Host-side geometry helpers shared by conv_igemm.hip and conv_wgrad.hip.
+#pragma once
+#include <stdlib.h>
+#include <string.h>
+#include "conv_igemm.h"
+
+static const int LDS_HARD = 160 * 1024;
+
+static inline bool geom_ok(const pcuda_conv_geom* g) {
+  if (!g || g->n <= 0 || g->cin <= 0 || g->cout <= 0 || g->k <= 0 || g->stride <= 0 || g->dil <= 0 || g->pad < 0)
+    return false;
+  if (g->k * g->k > IG_MAX_TAPS) return false;
+  const int oh = (g->in_h + 2 * g->pad - g->dil * (g->k - 1) - 1) / g->stride + 1;
+  const int ow = (g->in_w + 2 * g->pad - g->dil * (g->k - 1) - 1) / g->stride + 1;
+  if (oh != g->out_h || ow != g->out_w || oh <= 0 || ow <= 0) return false;
+  if (g->in_up && ((g->in_h & 1) || (g->in_w & 1))) return false;
+  return true;
+}
+
+static inline bool src_ok(const pcuda_src* s, int c) {
+  if (!s || !s->p1 || s->c1 <= 0 || s->c1 > c) return false;
+  if (s->c1 < c && !s->p2) return false;
+  return true;
+}
+static inline bool dst_ok(const pcuda_dst* d, int c) {
+  if (!d || !d->p1 || d->c1 <= 0 || d->c1 > c) return false;
+  if (d->c1 < c && !d->p2) return false;
+  return true;
+}
+
+struct TapSet {
+  int n;
+  signed char dy[IG_MAX_TAPS], dx[IG_MAX_TAPS], src[IG_MAX_TAPS];
+  int dy_min, dy_max, dx_min, dx_max;
+  void finish() {
+    dy_min = dx_min = 127; dy_max = dx_max = -127;
+    for (int i = 0; i < n; ++i) {
+      if (dy[i] < dy_min) dy_min = dy[i];
+      if (dy[i] > dy_max) dy_max = dy[i];
+      if (dx[i] < dx_min) dx_min = dx[i];
+      if (dx[i] > dx_max) dx_max = dx[i];
+    }
+    if (n == 0) dy_min = dy_max = dx_min = dx_max = 0;
+  }
+};
+
+static inline TapSet fwd_taps(const pcuda_conv_geom* g) {
+  TapSet t; t.n = 0;
+  for (int ky = 0; ky < g->k; ++ky)
+    for (int kx = 0; kx < g->k; ++kx) {
+      t.dy[t.n] = (signed char)(ky * g->dil - g->pad);
+      t.dx[t.n] = (signed char)(kx * g->dil - g->pad);
+      t.src[t.n] = (signed char)(ky * g->k + kx);
+      ++t.n;
+    }
+  t.finish();
+  return t;
+}
+
+static inline int posmod(int a, int m) { return ((a % m) + m) % m; }
+
+// taps of the dgrad parity class (ry, rx): dX[s*m + ry] = sum_ky dY[m + (ry + pad - ky*dil)/s] w[ky]
+static inline TapSet dgrad_taps(const pcuda_conv_geom* g, int ry, int rx) {
+  TapSet t; t.n = 0;
+  const int s = g->stride;
+  for (int ky = 0; ky < g->k; ++ky) {
+    const int vy = ry + g->pad - ky * g->dil;
+    if (posmod(vy, s) != 0) continue;
+    for (int kx = 0; kx < g->k; ++kx) {
+      const int vx = rx + g->pad - kx * g->dil;
+      if (posmod(vx, s) != 0) continue;
+      t.dy[t.n] = (signed char)(vy / s);
+      t.dx[t.n] = (signed char)(vx / s);
+      t.src[t.n] = (signed char)(ky * g->k + kx);
+      ++t.n;
+    }
+  }
+  t.finish();
+  return t;
+}
+
+// candidate output-tile widths: powers of two plus even splits of the row (so a 17- or 33-wide map is
+// not padded to 32 / 64)
+static inline int tile_width_candidates(int lw, int tile_px, int* out) {
+  int n = 0;
+  for (int t = 8; t <= 256 && t <= tile_px; t <<= 1) out[n++] = t;
+  for (int parts = 1; parts <= 4; ++parts) {
+    const int t = (lw + parts - 1) / parts;
+    if (t >= 4 && t <= 256 && t <= tile_px) {
+      bool dup = false;
+      for (int i = 0; i < n; ++i) dup |= out[i] == t;
+      if (!dup) out[n++] = t;
+    }
+  }
+  return n;
+}
+
+
+// fast (buffer-load) staging preconditions of the software-pipelined kernels: a 32-channel chunk lies
+// in ONE source and every source image spans < 2^30 bytes (32-bit offsets, out-of-bounds marker)
+static inline bool fast_src_ok(const pcuda_src* x, int cin) {
+  const long long lim = 1ll << 30;
+  const int c1 = x->c1 < cin ? x->c1 : cin;
+  if (c1 < cin && (c1 & 31)) return false;
+  if ((long long)(c1 + 32) * x->sc1 * 4 >= lim) return false;
+  if (c1 < cin && (long long)(cin - c1 + 32) * x->sc2 * 4 >= lim) return false;
+  return true;
+}

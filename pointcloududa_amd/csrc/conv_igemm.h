@@ -59,8 +59,11 @@ struct WgradParams {
   int n_co_tiles, n_chunks;
   float* partial;          // [ksplit][cout][cin][ntaps_total] fp32
   int aligned4;            // dz rows can be read with float4
+  int tw16;                // TW % 16 == 0 and TW*TH == 128: a k-step's 16 pixel slots share one tile row
   int dbg;                 // PCUDA_DBG bits (timing experiments only): 16 no X staging, 32 no dZ staging, 64 no MFMA
 };
+
+#define WG_ZROW 272   // wgrad: bytes per dZ row in LDS, 128 px bf16 + 16 pad (17*16: conflict-free b128)
 
 struct PackParams {
   const float* w;

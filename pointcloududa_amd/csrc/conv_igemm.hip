@@ -12,7 +12,8 @@
 //                     ds_read_b64_tr_b16, split-K partial slabs + deterministic reduce)
 #include <stdlib.h>
 
-#include "conv_igemm.h"
+#include "conv_device.h"
+#include "conv_host.h"
 
 // ------------------------------------------------------------------------------------------
 // weight repack: fp32 [rows][red][taps] (any strides) -> bf16 [co_tile][chunk][tap][CO_TILE][40]
@@ -39,138 +40,6 @@ __global__ void pack_kernel(const PackParams p) {
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// stage one 32-channel chunk of a haloed input tile into LDS, pixel-major, bf16 hi (+ lo)
-// ------------------------------------------------------------------------------------------
-template <bool X3>
-__device__ __forceinline__ void stage_write(unsigned char* __restrict__ xhi, unsigned char* __restrict__ xlo,
-                                            const float (&v)[8], int pix, int g) {
-  uint4 hi, lo;
-  if (X3) {
-    split2(v[0], v[1], hi.x, lo.x); split2(v[2], v[3], hi.y, lo.y);
-    split2(v[4], v[5], hi.z, lo.z); split2(v[6], v[7], hi.w, lo.w);
-    *(uint4*)(xlo + (size_t)pix * IG_REC_BYTES + g * 16) = lo;
-  } else {
-    hi.x = pack_bf16x2(v[0], v[1]); hi.y = pack_bf16x2(v[2], v[3]);
-    hi.z = pack_bf16x2(v[4], v[5]); hi.w = pack_bf16x2(v[6], v[7]);
-  }
-  *(uint4*)(xhi + (size_t)pix * IG_REC_BYTES + g * 16) = hi;
-}
-
-// PF pixels per thread (npix <= PF*256), everything unrolled.  Instruction-lean by construction:
-//  * the channel plane base (p + n*sn + c*sc) is wave-uniform -> SGPR pair; each lane adds ONE 32-bit
-//    byte offset computed once per pixel slot -> `global_load_dword v, v_off, s[base]`, no 64-bit VALU;
-//  * loads are UNCONDITIONAL on clamped (always valid) addresses and the padding zeros are selected
-//    afterwards: a per-lane `if (inb) load` makes hipcc branch around every load and wait for it
-//    (cdna_hip_programming.md, "Three .s-level traps" (c));
-//  * the lazy-BatchNorm scale/shift are read in uniform control flow (scalar loads), one fma per value.
-// Phase 1 issues all 32*PF loads of the chunk, phase 2 applies the affine, splits and writes LDS.
-template <bool X3, int PF>
-__device__ __forceinline__ void stage_x_chunk_mlp(unsigned char* __restrict__ xhi, unsigned char* __restrict__ xlo,
-                                                  const pcuda_src& x, int n, int cin, int chunk, int in_h, int in_w,
-                                                  int in_shift, int in_row, int oy0, int ox0, int th, int tw,
-                                                  int ngroups, int nwrite, int tid0) {
-  const int npix = th * tw;
-  const int cbase = chunk * 32;
-  const int tid = tid0;   // first pixel slot of this lane (callers may offset it to walk big tiles)
-  unsigned voff[PF];
-  bool inb[PF];
-#pragma unroll
-  for (int s = 0; s < PF; ++s) {
-    const int pix = min(tid + s * 256, npix - 1);
-    const int iy = pix / tw, ix = pix - iy * tw;
-    const int gy = oy0 + iy, gx = ox0 + ix;
-    inb[s] = (tid + s * 256 < npix) & ((unsigned)gy < (unsigned)in_h) & ((unsigned)gx < (unsigned)in_w);
-    const int cy = min(max(gy, 0), in_h - 1), cx = min(max(gx, 0), in_w - 1);
-    voff[s] = (unsigned)((cy >> in_shift) * in_row + (cx >> in_shift)) * 4u;
-  }
-  const char* b1 = (const char*)(x.p1 + (long long)n * x.sn1);
-  const char* b2 = (const char*)(x.p2 + (long long)n * x.sn2);
-  float v[PF][4][8];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    if (g < ngroups) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int c = min(cbase + g * 8 + j, cin - 1);   // wave-uniform, clamped
-        const char* chan = (c < x.c1) ? b1 + (long long)c * x.sc1 * 4 : b2 + (long long)(c - x.c1) * x.sc2 * 4;
-#pragma unroll
-        for (int s = 0; s < PF; ++s) v[s][g][j] = *(const float*)(chan + voff[s]);
-      }
-    }
-  }
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    if (g >= ngroups && g < nwrite) {   // k-step channels past cin: zeros, not LDS garbage
-#pragma unroll
-      for (int s = 0; s < PF; ++s)
-        if (tid + s * 256 < npix) {
-          *(uint4*)(xhi + (size_t)(tid + s * 256) * IG_REC_BYTES + g * 16) = make_uint4(0, 0, 0, 0);
-          if (X3) *(uint4*)(xlo + (size_t)(tid + s * 256) * IG_REC_BYTES + g * 16) = make_uint4(0, 0, 0, 0);
-        }
-    }
-    if (g < ngroups) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int c = cbase + g * 8 + j;
-        const bool cok = c < cin;
-        float sc = 1.f, sh = 0.f;
-        if (cok) {
-          if (c < x.c1) { if (x.scale1) { sc = x.scale1[c]; sh = x.shift1[c]; } }
-          else { if (x.scale2) { sc = x.scale2[c - x.c1]; sh = x.shift2[c - x.c1]; } }
-        }
-#pragma unroll
-        for (int s = 0; s < PF; ++s) {
-          const float t = fmaf(v[s][g][j], sc, sh);
-          v[s][g][j] = (inb[s] & cok) ? t : 0.f;
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < PF; ++s)
-        if (tid + s * 256 < npix) stage_write<X3>(xhi, xlo, v[s][g], tid + s * 256, g);
-    }
-  }
-}
-
-template <bool X3, int MAXPF = 3>
-__device__ __forceinline__ void stage_x_chunk(unsigned char* __restrict__ xhi, unsigned char* __restrict__ xlo,
-                                              const pcuda_src& x, int n, int cin, int chunk, int in_h, int in_w,
-                                              int in_shift, int in_row, int oy0, int ox0, int th, int tw,
-                                              int ngroups, int nwrite, int tid) {
-  const int npix = th * tw;
-  if (MAXPF == 1) {   // register-tight callers (wgrad: 80+ accumulator registers): 32 loads in flight per lane
-    for (int pix0 = 0; pix0 < npix; pix0 += 256)
-      stage_x_chunk_mlp<X3, 1>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, nwrite, tid + pix0);
-    return;
-  }
-  if (npix <= 256) { stage_x_chunk_mlp<X3, 1>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, nwrite, tid); return; }
-  if (npix <= 512) { stage_x_chunk_mlp<X3, 2>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, nwrite, tid); return; }
-  if (npix <= 768) { stage_x_chunk_mlp<X3, 3>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, nwrite, tid); return; }
-  for (int pix0 = 0; pix0 < npix; pix0 += 512)   // big tiles: 512 pixels at a time
-    stage_x_chunk_mlp<X3, 2>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, nwrite, tid + pix0);
-}
-
-// contiguous global -> LDS copy of nvec 16-B vectors, 4 loads per lane in flight
-__device__ __forceinline__ void copy_vec16(unsigned char* __restrict__ dst, const uint4* __restrict__ src, int nvec,
-                                           int tid) {
-  for (int base = 0; base < nvec; base += 1024) {
-    uint4 r[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = base + tid + u * 256;
-      r[u] = src[i < nvec ? i : nvec - 1];   // unconditional (clamped) load keeps r[] in registers
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = base + tid + u * 256;
-      if (i < nvec) ((uint4*)dst)[i] = r[u];
-    }
-  }
-}
-
-__device__ __forceinline__ bf16x8 lds_frag(const unsigned char* p) {
-  return __builtin_bit_cast(bf16x8, *(const uint4*)p);
-}
 
 // ------------------------------------------------------------------------------------------
 // forward / dgrad kernel.  256 threads = 4 waves; tile = CO_TILE rows x (128*NPB) logical pixels;
@@ -393,81 +262,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p, const i
 // weights, runs its MFMAs and stores its outputs.  With only 1-2 workgroups per CU (LDS-limited) the
 // unpipelined kernel left HBM idle during compute and the matrix cores idle during staging.
 // ------------------------------------------------------------------------------------------
-template <int PF>
-struct XPre {
-  float v[PF][4][8];
-  bool inb[PF];
-};
-
-template <int PF>
-__device__ __forceinline__ void xpre_issue(XPre<PF>& pre, const pcuda_src& x, int n, int cin, int chunk, int in_h,
-                                           int in_w, int in_shift, int in_row, int oy0, int ox0, int tw, int npix,
-                                           int ngroups, int tid) {
-  const int cbase = chunk * 32;
-  unsigned voff[PF];
-#pragma unroll
-  for (int s = 0; s < PF; ++s) {
-    const int pix = min(tid + s * 256, npix - 1);
-    const int iy = pix / tw, ix = pix - iy * tw;
-    const int gy = oy0 + iy, gx = ox0 + ix;
-    pre.inb[s] = (tid + s * 256 < npix) & ((unsigned)gy < (unsigned)in_h) & ((unsigned)gx < (unsigned)in_w);
-    const int cy = min(max(gy, 0), in_h - 1), cx = min(max(gx, 0), in_w - 1);
-    voff[s] = (unsigned)((cy >> in_shift) * in_row + (cx >> in_shift)) * 4u;
-  }
-  const char* b1 = (const char*)(x.p1 + (long long)n * x.sn1);
-  const char* b2 = (const char*)(x.p2 + (long long)n * x.sn2);
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    if (g < ngroups) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int c = min(cbase + g * 8 + j, cin - 1);   // wave-uniform, clamped
-        const char* chan = (c < x.c1) ? b1 + (long long)c * x.sc1 * 4 : b2 + (long long)(c - x.c1) * x.sc2 * 4;
-#pragma unroll
-        for (int s = 0; s < PF; ++s) pre.v[s][g][j] = *(const float*)(chan + voff[s]);
-      }
-    }
-  }
-}
-
-template <bool X3, int PF>
-__device__ __forceinline__ void xpre_commit(XPre<PF>& pre, unsigned char* __restrict__ xhi,
-                                            unsigned char* __restrict__ xlo, const pcuda_src& x, int cin, int chunk,
-                                            int npix, int ngroups, int nwrite, int tid) {
-  const int cbase = chunk * 32;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    if (g >= ngroups && g < nwrite) {   // channels past cin inside a 16-wide k-step: zeros, not LDS garbage
-#pragma unroll
-      for (int s = 0; s < PF; ++s)
-        if (tid + s * 256 < npix) {
-          *(uint4*)(xhi + (size_t)(tid + s * 256) * IG_REC_BYTES + g * 16) = make_uint4(0, 0, 0, 0);
-          if (X3) *(uint4*)(xlo + (size_t)(tid + s * 256) * IG_REC_BYTES + g * 16) = make_uint4(0, 0, 0, 0);
-        }
-    }
-    if (g < ngroups) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int c = cbase + g * 8 + j;
-        const bool cok = c < cin;
-        float sc = 1.f, sh = 0.f;
-        if (cok) {
-          if (c < x.c1) { if (x.scale1) { sc = x.scale1[c]; sh = x.shift1[c]; } }
-          else { if (x.scale2) { sc = x.scale2[c - x.c1]; sh = x.shift2[c - x.c1]; } }
-        }
-#pragma unroll
-        for (int s = 0; s < PF; ++s) {
-          const float t = fmaf(pre.v[s][g][j], sc, sh);
-          pre.v[s][g][j] = (pre.inb[s] & cok) ? t : 0.f;
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < PF; ++s)
-        if (tid + s * 256 < npix) stage_write<X3>(xhi, xlo, pre.v[s][g], tid + s * 256, g);
-    }
-  }
-}
-
 struct TileGeom {
   int cot, pt, n, y0, x0, oy0, ox0, th, tw, npix;
 };
@@ -706,328 +500,10 @@ __global__ __launch_bounds__(256, 2) void igemm_pipe_kernel(const IgemmParams p,
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// wgrad kernel.  Block = (co-tile, 32-channel chunk, tap group) x split-K slice; loops over its
-// 128-pixel tiles, keeping dW tiles [32 rows][32 ci] per tap in the accumulators.
-// ------------------------------------------------------------------------------------------
-#define WG_ZROW 272   // bytes per dZ row in LDS: 128 px bf16 + 16 pad (17*16: conflict-free b128)
-
-__device__ __forceinline__ bf16x8 lds_tr_frag(const unsigned char* p0, const unsigned char* p1) {
-  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)p0);
-  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)p1);
-  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-
-template <bool X3, int CO_BLKS, bool CLAMP, int TAPS_MAX>
-__global__ __launch_bounds__(256, (TAPS_MAX <= 9 ? 2 : 1)) void wgrad_kernel(const WgradParams p, const int x_cap, float* db_partial) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int CO_TILE = 32 * CO_BLKS;
-  constexpr int NWT = 4 / CO_BLKS;             // waves sharing one row block
-  constexpr int MAXT = (TAPS_MAX + NWT - 1) / NWT;   // taps per wave (block handles <= TAPS_MAX taps)
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
-
-  const int bx = blockIdx.x;
-  const int tgidx = bx % p.tap_groups;
-  const int chunk = (bx / p.tap_groups) % p.n_chunks;
-  const int cot = bx / (p.tap_groups * p.n_chunks);
-  const int kslice = blockIdx.y;
-  const int t_begin = tgidx * p.ntaps;
-  const int tcount = min(p.ntaps, p.ntaps_total - t_begin);
-  const int cb = w % CO_BLKS, wsub = w / CO_BLKS;
-  const int share = (tcount + NWT - 1) / NWT;
-  const int my_t0 = t_begin + wsub * share;
-  const int my_cnt = max(0, min(share, tcount - wsub * share));
-
-  unsigned char* Xhi = smem;
-  unsigned char* Xlo = smem + (size_t)x_cap * IG_REC_BYTES;
-  unsigned char* Zhi = smem + (size_t)(X3 ? 2 : 1) * x_cap * IG_REC_BYTES;
-  unsigned char* Zlo = Zhi + (size_t)CO_TILE * WG_ZROW;
-
-  const int TW = p.tw, TH = p.th, TPIX = TW * TH;
-  const int ntiles = p.n * p.tiles_y * p.tiles_x;
-  const int tile_lo = (int)((long long)kslice * ntiles / p.ksplit);
-  const int tile_hi = (int)((long long)(kslice + 1) * ntiles / p.ksplit);
-  const bool do_db = (db_partial != nullptr) && chunk == 0 && tgidx == 0;
-
-  f32x16 acc[MAXT];
-#pragma unroll
-  for (int ti = 0; ti < MAXT; ++ti)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[ti][i] = 0.f;
-  float dbacc[CO_TILE / 16];
-#pragma unroll
-  for (int j = 0; j < CO_TILE / 16; ++j) dbacc[j] = 0.f;
-
-  // transposed-read lane roles: 16-lane group g -> k half (g>>1), column block (g&1)
-  const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-  const int cvalid = min(32, p.cin - chunk * 32);
-
-  for (int tile = tile_lo; tile < tile_hi; ++tile) {
-    const int txi = tile % p.tiles_x;
-    const int tmp = tile / p.tiles_x;
-    const int tyi = tmp % p.tiles_y;
-    const int n = tmp / p.tiles_y;
-    const int y0 = tyi * TH, x0 = txi * TW;
-    int oy0 = y0 * p.stride + p.dy_min, ox0 = x0 * p.stride + p.dx_min;
-    int th = p.ih_t, tw = p.iw_t;
-    if (CLAMP) {   // LDS tile = halo tile clipped to the image (+ one zero record), as in igemm_kernel
-      const int y1 = min(oy0 + th, p.in_h), x1 = min(ox0 + tw, p.in_w);
-      oy0 = max(oy0, 0); ox0 = max(ox0, 0);
-      th = max(y1 - oy0, 0); tw = max(x1 - ox0, 0);
-    }
-    const int npix = th * tw;
-    __syncthreads();
-    if (!(p.dbg & 16))
-      stage_x_chunk<X3, 1>(Xhi, Xlo, p.x, n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row, oy0, ox0, th, tw,
-                           (cvalid + 7) >> 3, 4, tid);
-    if (CLAMP && tid < 5) {
-      *(uint4*)(Xhi + (size_t)npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
-      if (X3) *(uint4*)(Xlo + (size_t)npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
-    }
-    // dZ tile [CO_TILE][128 px] in natural (pixel-contiguous) order; all loads first, then the writes
-    float zv[CO_TILE / 16][8];
-    if (p.dbg & 32) {
-#pragma unroll
-      for (int j = 0; j < CO_TILE / 16; ++j)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) zv[j][e] = 1.f;
-    } else
-#pragma unroll
-    for (int j = 0; j < CO_TILE / 16; ++j) {
-      const int item = tid + 256 * j;
-      const int row = item >> 4, oct = item & 15;
-      const int co = cot * CO_TILE + row;
-      const int pl = oct * 8;
-      const int cco = min(co, p.cout - 1);
-      const float* planep = p.dz + (long long)n * p.dz_sn + (long long)cco * p.dz_sc;
-      if (p.aligned4) {   // wave-uniform: TW % 8 == 0 and out_w % 8 == 0 -> an octet is inside or outside a row as a whole
-        const int ty = IG_TY(pl, p.tmagic), tx = pl - ty * TW;
-        const int oy = y0 + ty, ox = x0 + tx;
-        const bool ok = (co < p.cout) & (pl < TPIX) & (oy < p.out_h) & (ox + 8 <= p.out_w);
-        const float* rowp = planep + (long long)min(oy, p.out_h - 1) * p.out_w + min(ox, p.out_w - 8);
-        const float4 a = *(const float4*)rowp, b = *(const float4*)(rowp + 4);
-        zv[j][0] = ok ? a.x : 0.f; zv[j][1] = ok ? a.y : 0.f; zv[j][2] = ok ? a.z : 0.f; zv[j][3] = ok ? a.w : 0.f;
-        zv[j][4] = ok ? b.x : 0.f; zv[j][5] = ok ? b.y : 0.f; zv[j][6] = ok ? b.z : 0.f; zv[j][7] = ok ? b.w : 0.f;
-      } else {            // any tile width: the 8 pixels of an octet may wrap to the next tile row
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int ple = min(pl + e, TPIX - 1);
-          const int ty = IG_TY(ple, p.tmagic), tx = ple - ty * TW;
-          const int oy = y0 + ty, ox = x0 + tx;
-          const float t = planep[(long long)min(oy, p.out_h - 1) * p.out_w + min(ox, p.out_w - 1)];
-          zv[j][e] = ((co < p.cout) & (pl + e < TPIX) & (oy < p.out_h) & (ox < p.out_w)) ? t : 0.f;
-        }
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < CO_TILE / 16; ++j) {
-      const int item = tid + 256 * j;
-      const int row = item >> 4, oct = item & 15;
-      const float(&v)[8] = zv[j];
-      if (do_db) dbacc[j] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-      uint4 hi, lo;
-      if (X3) {
-        split2(v[0], v[1], hi.x, lo.x); split2(v[2], v[3], hi.y, lo.y);
-        split2(v[4], v[5], hi.z, lo.z); split2(v[6], v[7], hi.w, lo.w);
-        *(uint4*)(Zlo + row * WG_ZROW + oct * 16) = lo;
-      } else {
-        hi.x = pack_bf16x2(v[0], v[1]); hi.y = pack_bf16x2(v[2], v[3]);
-        hi.z = pack_bf16x2(v[4], v[5]); hi.w = pack_bf16x2(v[6], v[7]);
-      }
-      *(uint4*)(Zhi + row * WG_ZROW + oct * 16) = hi;
-    }
-    __syncthreads();
-
-#pragma unroll 1
-    for (int ks = 0; ks < ((p.dbg & 64) ? 0 : 8); ++ks) {
-      const int aoff = (cb * 32 + r) * WG_ZROW + ks * 32 + h * 16;
-      const bf16x8 ah = lds_frag(Zhi + aoff);
-      bf16x8 al;
-      if (X3) al = lds_frag(Zlo + aoff);
-      int rowb[2], rty[2], rtx[2];
-      const int colb = ((g & 1) * 16 + 4 * tp) * 2;
-#pragma unroll
-      for (int sel = 0; sel < 2; ++sel) {
-        const int pl = min(ks * 16 + 8 * (g >> 1) + 4 * sel + tq, TPIX - 1);   // idle slots carry dZ = 0
-        rty[sel] = IG_TY(pl, p.tmagic); rtx[sel] = pl - rty[sel] * TW;
-        rowb[sel] = ((rty[sel] * p.stride) * p.iw_t + rtx[sel] * p.stride) * IG_REC_BYTES + colb;
-      }
-#pragma unroll
-      for (int ti = 0; ti < MAXT; ++ti) {
-        if (ti < my_cnt) {   // wave-uniform: EXEC stays all ones for the transposed reads
-          const int t = my_t0 + ti;
-          int r0, r1;
-          if (CLAMP) {
-            int ra[2];
-#pragma unroll
-            for (int sel = 0; sel < 2; ++sel) {
-              const int gy = (y0 + rty[sel]) * p.stride + p.dy[t], gx = (x0 + rtx[sel]) * p.stride + p.dx[t];
-              const bool ok = ((unsigned)gy < (unsigned)p.in_h) & ((unsigned)gx < (unsigned)p.in_w);
-              ra[sel] = (ok ? (gy - oy0) * tw + (gx - ox0) : npix) * IG_REC_BYTES + colb;
-            }
-            r0 = ra[0]; r1 = ra[1];
-          } else {
-            const int toff = ((p.dy[t] - p.dy_min) * p.iw_t + (p.dx[t] - p.dx_min)) * IG_REC_BYTES;
-            r0 = rowb[0] + toff; r1 = rowb[1] + toff;
-          }
-          const bf16x8 bh = lds_tr_frag(Xhi + r0, Xhi + r1);
-          if (X3) {
-            const bf16x8 bl = lds_tr_frag(Xlo + r0, Xlo + r1);
-            acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[ti], 0, 0, 0);
-            acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[ti], 0, 0, 0);
-          }
-          acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[ti], 0, 0, 0);
-        }
-      }
-    }
-  }
-
-  // partial slabs: partial[kslice][tap][co][ci] -- ci (the lane index) innermost, so every accumulator
-  // register stores two 128-B segments; the OIHW transpose happens once, in the reduce kernel
-#pragma unroll
-  for (int ti = 0; ti < MAXT; ++ti) {
-    if (ti < my_cnt) {
-      const int t = my_t0 + ti;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int co = cot * CO_TILE + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        const int ci = chunk * 32 + r;
-        if (co < p.cout && ci < p.cin)
-          p.partial[(((long long)kslice * p.ntaps_total + t) * p.cout + co) * p.cin + ci] = acc[ti][i];
-      }
-    }
-  }
-  if (do_db) {
-#pragma unroll
-    for (int j = 0; j < CO_TILE / 16; ++j) {
-      float s = dbacc[j];
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-      const int row = (tid + 256 * j) >> 4;
-      const int co = cot * CO_TILE + row;
-      if ((tid & 15) == 0 && co < p.cout) db_partial[(long long)kslice * p.cout + co] = s;
-    }
-  }
-}
-
-// dw[i] (+)= sum_k partial[k][i], deterministic.  A workgroup owns 64 consecutive outputs; its
-// blockDim/64 k-groups each sum a strided subset of the slices (8 loads in flight per lane), and the
-// k-group partials are combined in a fixed order through LDS.  (One thread per output with a serial
-// loop over up to 1024 slices was latency-bound: 0.5 ms for a 9K-weight layer.)
-// ntaps > 1: partial is [k][tap][co*cin] and dw is [co*cin][tap] (OIHW): coalesced reads, the
-// transpose costs one scattered write per weight.
-__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ partial, long long numel,
-                                                           int ksplit, float* __restrict__ dw, int accumulate,
-                                                           int ntaps) {
-  __shared__ float sh[16][64];
-  const int lane = threadIdx.x & 63, kg = threadIdx.x >> 6, nkg = blockDim.x >> 6;
-  const long long i = (long long)blockIdx.x * 64 + lane;
-  float s = 0.f;
-  if (i < numel) {
-    int k = kg;
-    for (; k + 7 * nkg < ksplit; k += 8 * nkg) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = partial[(long long)(k + u * nkg) * numel + i];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += v[u];
-    }
-    for (; k < ksplit; k += nkg) s += partial[(long long)k * numel + i];
-  }
-  sh[kg][lane] = s;
-  __syncthreads();
-  if (kg == 0 && i < numel) {
-    float t = 0.f;
-    for (int q = 0; q < nkg; ++q) t += sh[q][lane];
-    long long o = i;
-    if (ntaps > 1) {
-      const long long cc = numel / ntaps;          // cout * cin
-      const long long tt = i / cc, r = i - tt * cc;
-      o = r * ntaps + tt;
-    }
-    dw[o] = accumulate ? dw[o] + t : t;
-  }
-}
-
 // ==========================================================================================
 // host side
 // ==========================================================================================
 namespace {
-
-const int LDS_HARD = 160 * 1024;
-
-bool geom_ok(const pcuda_conv_geom* g) {
-  if (!g || g->n <= 0 || g->cin <= 0 || g->cout <= 0 || g->k <= 0 || g->stride <= 0 || g->dil <= 0 || g->pad < 0)
-    return false;
-  if (g->k * g->k > IG_MAX_TAPS) return false;
-  const int oh = (g->in_h + 2 * g->pad - g->dil * (g->k - 1) - 1) / g->stride + 1;
-  const int ow = (g->in_w + 2 * g->pad - g->dil * (g->k - 1) - 1) / g->stride + 1;
-  if (oh != g->out_h || ow != g->out_w || oh <= 0 || ow <= 0) return false;
-  if (g->in_up && ((g->in_h & 1) || (g->in_w & 1))) return false;
-  return true;
-}
-
-bool src_ok(const pcuda_src* s, int c) {
-  if (!s || !s->p1 || s->c1 <= 0 || s->c1 > c) return false;
-  if (s->c1 < c && !s->p2) return false;
-  return true;
-}
-bool dst_ok(const pcuda_dst* d, int c) {
-  if (!d || !d->p1 || d->c1 <= 0 || d->c1 > c) return false;
-  if (d->c1 < c && !d->p2) return false;
-  return true;
-}
-
-struct TapSet {
-  int n;
-  signed char dy[IG_MAX_TAPS], dx[IG_MAX_TAPS], src[IG_MAX_TAPS];
-  int dy_min, dy_max, dx_min, dx_max;
-  void finish() {
-    dy_min = dx_min = 127; dy_max = dx_max = -127;
-    for (int i = 0; i < n; ++i) {
-      if (dy[i] < dy_min) dy_min = dy[i];
-      if (dy[i] > dy_max) dy_max = dy[i];
-      if (dx[i] < dx_min) dx_min = dx[i];
-      if (dx[i] > dx_max) dx_max = dx[i];
-    }
-    if (n == 0) dy_min = dy_max = dx_min = dx_max = 0;
-  }
-};
-
-TapSet fwd_taps(const pcuda_conv_geom* g) {
-  TapSet t; t.n = 0;
-  for (int ky = 0; ky < g->k; ++ky)
-    for (int kx = 0; kx < g->k; ++kx) {
-      t.dy[t.n] = (signed char)(ky * g->dil - g->pad);
-      t.dx[t.n] = (signed char)(kx * g->dil - g->pad);
-      t.src[t.n] = (signed char)(ky * g->k + kx);
-      ++t.n;
-    }
-  t.finish();
-  return t;
-}
-
-inline int posmod(int a, int m) { return ((a % m) + m) % m; }
-
-// taps of the dgrad parity class (ry, rx): dX[s*m + ry] = sum_ky dY[m + (ry + pad - ky*dil)/s] w[ky]
-TapSet dgrad_taps(const pcuda_conv_geom* g, int ry, int rx) {
-  TapSet t; t.n = 0;
-  const int s = g->stride;
-  for (int ky = 0; ky < g->k; ++ky) {
-    const int vy = ry + g->pad - ky * g->dil;
-    if (posmod(vy, s) != 0) continue;
-    for (int kx = 0; kx < g->k; ++kx) {
-      const int vx = rx + g->pad - kx * g->dil;
-      if (posmod(vx, s) != 0) continue;
-      t.dy[t.n] = (signed char)(vy / s);
-      t.dx[t.n] = (signed char)(vx / s);
-      t.src[t.n] = (signed char)(ky * g->k + kx);
-      ++t.n;
-    }
-  }
-  t.finish();
-  return t;
-}
 
 size_t packed_elems(int rows, int red, int ntaps) {   // bf16 elements of ONE plane (hi)
   const int co_tile = 32 * ig_co_blks(rows);
@@ -1081,22 +557,6 @@ struct IgemmPlan {
   int npb, tw, th, tiles_x, tiles_y, ih_t, iw_t, clamp, x_cap, tg;
   size_t lds;
 };
-
-// candidate output-tile widths: powers of two plus even splits of the row (so a 17- or 33-wide map is
-// not padded to 32 / 64)
-int tile_width_candidates(int lw, int tile_px, int* out) {
-  int n = 0;
-  for (int t = 8; t <= 256 && t <= tile_px; t <<= 1) out[n++] = t;
-  for (int parts = 1; parts <= 4; ++parts) {
-    const int t = (lw + parts - 1) / parts;
-    if (t >= 4 && t <= 256 && t <= tile_px) {
-      bool dup = false;
-      for (int i = 0; i < n; ++i) dup |= out[i] == t;
-      if (!dup) out[n++] = t;
-    }
-  }
-  return n;
-}
 
 // tile shape / LDS plan of one generic launch: depends only on geometry, taps and precision.
 // Minimises the number of MFMA pixel slots (tiles x slots per tile); ties prefer 32-pixel-aligned rows
@@ -1246,53 +706,6 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
   return co_blks == 2 ? launch_igemm_c<false, 2>(p, pl, s) : launch_igemm_c<false, 1>(p, pl, s);
 }
 
-struct WgradPlan {
-  int co_blks, co_tile, n_co_tiles, n_chunks, tap_groups, taps_per_group, tw, th, tiles_x, tiles_y, ksplit;
-  int ih_t, iw_t;
-};
-
-WgradPlan plan_wgrad(const pcuda_conv_geom* g) {
-  WgradPlan w;
-  w.co_blks = ig_co_blks(g->cout);
-  w.co_tile = 32 * w.co_blks;
-  w.n_co_tiles = cdiv(g->cout, w.co_tile);
-  w.n_chunks = cdiv(g->cin, 32);
-  const int ntaps = g->k * g->k;
-  w.tap_groups = ntaps <= 16 ? 1 : cdiv(ntaps, 9);   // 4x4 kernels keep all 16 taps in one block: X and dZ staged once
-  w.taps_per_group = cdiv(ntaps, w.tap_groups);
-  {   // 128-slot tile with the fewest tiles; ties prefer widths that keep the float4 dZ path (TW % 8 == 0)
-    int cand[16];
-    const int nc = tile_width_candidates(g->out_w, 128, cand);
-    long long best_key = -1;
-    w.tw = 32; w.th = 4;
-    for (int ci = 0; ci < nc; ++ci) {
-      const int tw = cand[ci], th = 128 / tw;
-      if (th < 1) continue;
-      const int span = (g->k - 1) * g->dil;
-      const long long halo = (long long)((th - 1) * g->stride + span + 1) * ((tw - 1) * g->stride + span + 1);
-      const long long key = ((long long)cdiv(g->out_w, tw) * cdiv(g->out_h, th) << 24) + ((tw & 31) ? (1ll << 20) : 0) + halo;
-      if (best_key < 0 || key < best_key) { best_key = key; w.tw = tw; w.th = th; }
-    }
-  }
-  const int TW = w.tw, TH = w.th;
-  w.tiles_x = cdiv(g->out_w, TW);
-  w.tiles_y = cdiv(g->out_h, TH);
-  const int span = (g->k - 1) * g->dil;
-  w.ih_t = (TH - 1) * g->stride + span + 1;
-  w.iw_t = (TW - 1) * g->stride + span + 1;
-  const long long ntiles = (long long)g->n * w.tiles_x * w.tiles_y;
-  const int base = w.n_co_tiles * w.n_chunks * w.tap_groups;
-  long long ks = 1024 / base;
-  if (ks < 1) ks = 1;
-  if (ks > ntiles) ks = ntiles;
-  // keep the partial slabs (written once, re-read once by the reduce kernel) below ~64 MB (measured:
-  // 32 MB costs the wgrad kernels more parallelism than the reduce kernel saves)
-  const long long welems = (long long)g->cout * g->cin * ntaps;
-  while (ks > 1 && ks * welems * 4 > (64ll << 20)) ks >>= 1;
-  w.ksplit = (int)ks;
-  return w;
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -1395,102 +808,5 @@ extern "C" int pcuda_conv2d_dgrad(const pcuda_conv_geom* g, int prec, const pcud
       }
       wp += plane * (prec == PCUDA_PREC_BF16X3 ? 2 : 1);
     }
-  return PCUDA_OK;
-}
-
-extern "C" size_t pcuda_conv2d_wgrad_workspace_size(const pcuda_conv_geom* g) {
-  if (!geom_ok(g)) return 0;
-  WgradPlan w = plan_wgrad(g);
-  return ((size_t)w.ksplit * g->cout * g->cin * g->k * g->k + (size_t)w.ksplit * g->cout) * sizeof(float) + 256;
-}
-
-template <bool X3, int CO_BLKS, bool CLAMP, int TAPS_MAX>
-static int launch_wgrad_t(const WgradParams& p, int x_cap, size_t lds, float* dbp, dim3 grid, hipStream_t s) {
-  auto kern = wgrad_kernel<X3, CO_BLKS, CLAMP, TAPS_MAX>;
-  static size_t lds_set = 0;
-  if (lds > 32 * 1024 && lds > lds_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HARD);
-    if (e != hipSuccess) PCUDA_FAIL(PCUDA_E_LAUNCH, "wgrad: cannot raise dynamic LDS: %s", hipGetErrorString(e));
-    lds_set = LDS_HARD;
-  }
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p, x_cap, dbp);
-  PCUDA_CHECK_LAUNCH("wgrad_kernel");
-  return PCUDA_OK;
-}
-
-extern "C" int pcuda_conv2d_wgrad(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const float* dy,
-                                  long long dy_sn, long long dy_sc, float* dw, float* db, int accumulate,
-                                  void* workspace, size_t workspace_bytes, pcuda_stream_t s_) {
-  hipStream_t s = (hipStream_t)s_;
-  if (!geom_ok(g)) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_wgrad: inconsistent geometry");
-  if (!src_ok(x, g->cin) || !dy || !dw) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_wgrad: bad tensors");
-  if (prec != PCUDA_PREC_BF16X3 && prec != PCUDA_PREC_BF16) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_wgrad: bad precision");
-  if (!workspace || workspace_bytes < pcuda_conv2d_wgrad_workspace_size(g))
-    PCUDA_FAIL(PCUDA_E_WORKSPACE, "conv2d_wgrad: workspace too small (%zu < %zu)", workspace_bytes,
-               pcuda_conv2d_wgrad_workspace_size(g));
-  const bool x3 = prec == PCUDA_PREC_BF16X3;
-  WgradPlan w = plan_wgrad(g);
-  TapSet t = fwd_taps(g);
-  WgradParams p;
-  memset(&p, 0, sizeof(p));
-  p.x = *x; p.cin = g->cin;
-  p.in_h = g->in_h; p.in_w = g->in_w; p.in_shift = g->in_up ? 1 : 0; p.in_row = g->in_w >> p.in_shift;
-  p.dz = dy; p.dz_sn = dy_sn; p.dz_sc = dy_sc;
-  p.cout = g->cout; p.out_h = g->out_h; p.out_w = g->out_w;
-  p.stride = g->stride;
-  p.ntaps = w.taps_per_group; p.ntaps_total = t.n; p.tap_groups = w.tap_groups;
-  memcpy(p.dy, t.dy, sizeof(p.dy));
-  memcpy(p.dx, t.dx, sizeof(p.dx));
-  p.dy_min = t.dy_min; p.dx_min = t.dx_min;
-  p.ih_t = w.ih_t; p.iw_t = w.iw_t;
-  p.tw = w.tw; p.th = w.th; p.tmagic = 65536 / w.tw + 1; p.tiles_x = w.tiles_x; p.tiles_y = w.tiles_y; p.n = g->n;
-  p.ksplit = w.ksplit; p.n_co_tiles = w.n_co_tiles; p.n_chunks = w.n_chunks;
-  p.partial = (float*)workspace;
-  {
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("PCUDA_DBG"); dbg = e ? atoi(e) : 0; }
-    p.dbg = dbg;
-  }
-  p.aligned4 = ((g->out_w & 7) == 0 && (w.tw & 7) == 0 && (dy_sn & 3) == 0 && (dy_sc & 3) == 0 && (((uintptr_t)dy) & 15) == 0) ? 1 : 0;
-  const long long welems = (long long)g->cout * g->cin * t.n;
-  float* dbp = db ? (float*)workspace + (size_t)w.ksplit * welems : nullptr;
-
-  const int full = w.ih_t * w.iw_t;
-  const int clipped = (w.ih_t < g->in_h ? w.ih_t : g->in_h) * (w.iw_t < g->in_w ? w.iw_t : g->in_w) + 1;
-  const size_t mul = x3 ? 2 : 1;
-  const size_t zb = (size_t)w.co_tile * WG_ZROW * mul;
-  bool clamp = clipped * 2 <= full;
-  if (!clamp && (size_t)full * IG_REC_BYTES * mul + zb > (size_t)LDS_HARD) clamp = true;
-  const int x_cap = clamp ? clipped : full;
-  const size_t lds = (size_t)x_cap * IG_REC_BYTES * mul + zb;
-  if (lds > (size_t)LDS_HARD) PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv2d_wgrad: tile %dx%d does not fit LDS", w.ih_t, w.iw_t);
-  const dim3 grid(w.n_co_tiles * w.n_chunks * w.tap_groups, w.ksplit);
-  {
-    const double flops = 2.0 * g->n * (double)g->out_h * g->out_w * g->cout * (double)g->cin * t.n;
-    char tag[160];
-    snprintf(tag, sizeof(tag), "wgrad n%d cin%d cout%d %dx%d k%d s%d d%d ksplit%d clamp%d lds%zu", g->n, g->cin, g->cout,
-             g->out_h, g->out_w, g->k, g->stride, g->dil, w.ksplit, clamp ? 1 : 0, lds);
-    ProfScope prof(PCUDA_FAM_CONV_WGRAD, flops, s, tag);
-    int rc;
-#define WG_GO2(X3_, CB_, CL_) (w.taps_per_group > 9 ? launch_wgrad_t<X3_, CB_, CL_, 16>(p, x_cap, lds, dbp, grid, s) : launch_wgrad_t<X3_, CB_, CL_, 9>(p, x_cap, lds, dbp, grid, s))
-#define WG_GO(X3_, CB_) (clamp ? WG_GO2(X3_, CB_, true) : WG_GO2(X3_, CB_, false))
-    if (x3) rc = w.co_blks == 2 ? WG_GO(true, 2) : WG_GO(true, 1);
-    else rc = w.co_blks == 2 ? WG_GO(false, 2) : WG_GO(false, 1);
-#undef WG_GO
-#undef WG_GO2
-    if (rc) return rc;
-  }
-  {
-    int nkg = 1;
-    while (nkg < 16 && nkg * 2 <= w.ksplit) nkg <<= 1;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(welems, 64)), dim3(64 * nkg), 0, s,
-                       (const float*)workspace, welems, w.ksplit, dw, accumulate, t.n);
-    PCUDA_CHECK_LAUNCH("wgrad_reduce_kernel");
-    if (db) {
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(g->cout, 64)), dim3(64 * nkg), 0, s, (const float*)dbp,
-                         (long long)g->cout, w.ksplit, db, accumulate, 1);
-      PCUDA_CHECK_LAUNCH("wgrad_reduce_kernel(db)");
-    }
-  }
   return PCUDA_OK;
 }

@@ -1,0 +1,185 @@
+// Weight-gradient kernels of the implicit-GEMM convolution (see conv_igemm.hip for the layout).
+#include "conv_igemm.h"
+#include "conv_host.h"
+
+// dw[i] (+)= sum_k partial[k][i], deterministic.  A workgroup owns 64 consecutive outputs; its
+// blockDim/64 k-groups each sum a strided subset of the slices (8 loads in flight per lane), and the
+// k-group partials are combined in a fixed order through LDS.  (One thread per output with a serial
+// loop over up to 1024 slices was latency-bound: 0.5 ms for a 9K-weight layer.)
+// ntaps > 1: partial is [k][tap][co*cin] and dw is [co*cin][tap] (OIHW): coalesced reads, the
+// transpose costs one scattered write per weight.
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ partial, long long numel,
+                                                           int ksplit, float* __restrict__ dw, int accumulate,
+                                                           int ntaps) {
+  __shared__ float sh[16][64];
+  const int lane = threadIdx.x & 63, kg = threadIdx.x >> 6, nkg = blockDim.x >> 6;
+  const long long i = (long long)blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (i < numel) {
+    int k = kg;
+    for (; k + 7 * nkg < ksplit; k += 8 * nkg) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partial[(long long)(k + u * nkg) * numel + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < ksplit; k += nkg) s += partial[(long long)k * numel + i];
+  }
+  sh[kg][lane] = s;
+  __syncthreads();
+  if (kg == 0 && i < numel) {
+    float t = 0.f;
+    for (int q = 0; q < nkg; ++q) t += sh[q][lane];
+    long long o = i;
+    if (ntaps > 1) {
+      const long long cc = numel / ntaps;          // cout * cin
+      const long long tt = i / cc, r = i - tt * cc;
+      o = r * ntaps + tt;
+    }
+    dw[o] = accumulate ? dw[o] + t : t;
+  }
+}
+
+namespace {
+
+struct WgradPlan {
+  int co_blks, co_tile, n_co_tiles, n_chunks, tap_groups, taps_per_group, tw, th, tiles_x, tiles_y, ksplit;
+  int ih_t, iw_t;
+};
+
+WgradPlan plan_wgrad(const pcuda_conv_geom* g) {
+  WgradPlan w;
+  w.co_blks = ig_co_blks(g->cout);
+  w.co_tile = 32 * w.co_blks;
+  w.n_co_tiles = cdiv(g->cout, w.co_tile);
+  w.n_chunks = cdiv(g->cin, 32);
+  const int ntaps = g->k * g->k;
+  w.tap_groups = ntaps <= 16 ? 1 : cdiv(ntaps, 9);   // 4x4 kernels keep all 16 taps in one block: X and dZ staged once
+  w.taps_per_group = cdiv(ntaps, w.tap_groups);
+  {   // 128-slot tile with the fewest tiles; ties prefer widths that keep the float4 dZ path (TW % 8 == 0)
+    int cand[16];
+    const int nc = tile_width_candidates(g->out_w, 128, cand);
+    long long best_key = -1;
+    w.tw = 32; w.th = 4;
+    for (int ci = 0; ci < nc; ++ci) {
+      const int tw = cand[ci], th = 128 / tw;
+      if (th < 1) continue;
+      const int span = (g->k - 1) * g->dil;
+      const long long halo = (long long)((th - 1) * g->stride + span + 1) * ((tw - 1) * g->stride + span + 1);
+      const long long key = ((long long)cdiv(g->out_w, tw) * cdiv(g->out_h, th) << 24) + ((tw & 31) ? (1ll << 20) : 0) + halo;
+      if (best_key < 0 || key < best_key) { best_key = key; w.tw = tw; w.th = th; }
+    }
+  }
+  const int TW = w.tw, TH = w.th;
+  w.tiles_x = cdiv(g->out_w, TW);
+  w.tiles_y = cdiv(g->out_h, TH);
+  const int span = (g->k - 1) * g->dil;
+  w.ih_t = (TH - 1) * g->stride + span + 1;
+  w.iw_t = (TW - 1) * g->stride + span + 1;
+  const long long ntiles = (long long)g->n * w.tiles_x * w.tiles_y;
+  const int base = w.n_co_tiles * w.n_chunks * w.tap_groups;
+  long long ks = 1024 / base;
+  if (ks < 1) ks = 1;
+  if (ks > ntiles) ks = ntiles;
+  // keep the partial slabs (written once, re-read once by the reduce kernel) below ~64 MB (measured:
+  // 32 MB costs the wgrad kernels more parallelism than the reduce kernel saves)
+  const long long welems = (long long)g->cout * g->cin * ntaps;
+  while (ks > 1 && ks * welems * 4 > (64ll << 20)) ks >>= 1;
+  w.ksplit = (int)ks;
+  return w;
+}
+
+}  // namespace
+
+extern "C" size_t pcuda_conv2d_wgrad_workspace_size(const pcuda_conv_geom* g) {
+  if (!geom_ok(g)) return 0;
+  WgradPlan w = plan_wgrad(g);
+  return ((size_t)w.ksplit * g->cout * g->cin * g->k * g->k + (size_t)w.ksplit * g->cout) * sizeof(float) + 256;
+}
+
+int wgrad_dispatch_x3(const WgradParams& p, int co_blks, bool clamp, int taps_max, int pf, int x_cap, size_t lds,
+                      float* dbp, dim3 grid, hipStream_t s);
+int wgrad_dispatch_bf16(const WgradParams& p, int co_blks, bool clamp, int taps_max, int pf, int x_cap, size_t lds,
+                        float* dbp, dim3 grid, hipStream_t s);
+
+extern "C" int pcuda_conv2d_wgrad(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const float* dy,
+                                  long long dy_sn, long long dy_sc, float* dw, float* db, int accumulate,
+                                  void* workspace, size_t workspace_bytes, pcuda_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (!geom_ok(g)) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_wgrad: inconsistent geometry");
+  if (!src_ok(x, g->cin) || !dy || !dw) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_wgrad: bad tensors");
+  if (prec != PCUDA_PREC_BF16X3 && prec != PCUDA_PREC_BF16) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_wgrad: bad precision");
+  if (!workspace || workspace_bytes < pcuda_conv2d_wgrad_workspace_size(g))
+    PCUDA_FAIL(PCUDA_E_WORKSPACE, "conv2d_wgrad: workspace too small (%zu < %zu)", workspace_bytes,
+               pcuda_conv2d_wgrad_workspace_size(g));
+  const bool x3 = prec == PCUDA_PREC_BF16X3;
+  WgradPlan w = plan_wgrad(g);
+  TapSet t = fwd_taps(g);
+  WgradParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = *x; p.cin = g->cin;
+  p.in_h = g->in_h; p.in_w = g->in_w; p.in_shift = g->in_up ? 1 : 0; p.in_row = g->in_w >> p.in_shift;
+  p.dz = dy; p.dz_sn = dy_sn; p.dz_sc = dy_sc;
+  p.cout = g->cout; p.out_h = g->out_h; p.out_w = g->out_w;
+  p.stride = g->stride;
+  p.ntaps = w.taps_per_group; p.ntaps_total = t.n; p.tap_groups = w.tap_groups;
+  memcpy(p.dy, t.dy, sizeof(p.dy));
+  memcpy(p.dx, t.dx, sizeof(p.dx));
+  p.dy_min = t.dy_min; p.dx_min = t.dx_min;
+  p.ih_t = w.ih_t; p.iw_t = w.iw_t;
+  p.tw = w.tw; p.th = w.th; p.tmagic = 65536 / w.tw + 1; p.tiles_x = w.tiles_x; p.tiles_y = w.tiles_y; p.n = g->n;
+  p.ksplit = w.ksplit; p.n_co_tiles = w.n_co_tiles; p.n_chunks = w.n_chunks;
+  p.partial = (float*)workspace;
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("PCUDA_DBG"); dbg = e ? atoi(e) : 0; }
+    p.dbg = dbg;
+  }
+  p.tw16 = ((w.tw & 15) == 0 && w.tw * w.th == 128) ? 1 : 0;
+  p.aligned4 = ((g->out_w & 7) == 0 && (w.tw & 7) == 0 && (dy_sn & 3) == 0 && (dy_sc & 3) == 0 && (((uintptr_t)dy) & 15) == 0 &&
+                ((long long)g->cout * dy_sc + (long long)g->out_h * g->out_w) * 4 < (1ll << 30)) ? 1 : 0;
+  const long long welems = (long long)g->cout * g->cin * t.n;
+  float* dbp = db ? (float*)workspace + (size_t)w.ksplit * welems : nullptr;
+
+  const int full = w.ih_t * w.iw_t;
+  const int clipped = (w.ih_t < g->in_h ? w.ih_t : g->in_h) * (w.iw_t < g->in_w ? w.iw_t : g->in_w) + 1;
+  const size_t mul = x3 ? 2 : 1;
+  const size_t zb = (size_t)w.co_tile * WG_ZROW * mul;
+  bool clamp = clipped * 2 <= full;
+  if (!clamp && (size_t)full * IG_REC_BYTES * mul + zb > (size_t)LDS_HARD) clamp = true;
+  const int x_cap = clamp ? clipped : full;
+  const size_t lds = (size_t)x_cap * IG_REC_BYTES * mul + zb;
+  if (lds > (size_t)LDS_HARD) PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv2d_wgrad: tile %dx%d does not fit LDS", w.ih_t, w.iw_t);
+  const dim3 grid(w.n_co_tiles * w.n_chunks * w.tap_groups, w.ksplit);
+  {
+    const double flops = 2.0 * g->n * (double)g->out_h * g->out_w * g->cout * (double)g->cin * t.n;
+    char tag[160];
+    // software-pipelined variants hold the next tile's loads in registers: input tiles <= 256*PF pixels
+    static int nopipe = -1;
+    if (nopipe < 0) { const char* e = getenv("PCUDA_NOPIPE"); nopipe = (e && atoi(e)) ? 1 : 0; }
+    const int pf = (nopipe || !fast_src_ok(x, g->cin)) ? 0 : (x_cap <= 256 ? 1 : (x_cap <= 768 ? 3 : 0));
+    snprintf(tag, sizeof(tag), "wgrad n%d cin%d cout%d %dx%d k%d s%d d%d ksplit%d clamp%d pf%d lds%zu", g->n, g->cin,
+             g->cout, g->out_h, g->out_w, g->k, g->stride, g->dil, w.ksplit, clamp ? 1 : 0, pf, lds);
+    ProfScope prof(PCUDA_FAM_CONV_WGRAD, flops, s, tag);
+    int rc;
+    const int taps_max = w.taps_per_group <= 1 ? 1 : w.taps_per_group <= 9 ? 9 : 16;
+    rc = x3 ? wgrad_dispatch_x3(p, w.co_blks, clamp, taps_max, pf, x_cap, lds, dbp, grid, s)
+            : wgrad_dispatch_bf16(p, w.co_blks, clamp, taps_max, pf, x_cap, lds, dbp, grid, s);
+    if (rc) return rc;
+  }
+  {
+    int nkg = 1;
+    while (nkg < 16 && nkg * 2 <= w.ksplit) nkg <<= 1;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(welems, 64)), dim3(64 * nkg), 0, s,
+                       (const float*)workspace, welems, w.ksplit, dw, accumulate, t.n);
+    PCUDA_CHECK_LAUNCH("wgrad_reduce_kernel");
+    if (db) {
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(g->cout, 64)), dim3(64 * nkg), 0, s, (const float*)dbp,
+                         (long long)g->cout, w.ksplit, db, accumulate, 1);
+      PCUDA_CHECK_LAUNCH("wgrad_reduce_kernel(db)");
+    }
+  }
+  return PCUDA_OK;
+}
+
