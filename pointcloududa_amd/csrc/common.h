@@ -64,6 +64,20 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// sum over the 32 lanes that share (lane >> 5), on the DPP path (no LDS crossbar, no waits): the total
+// lands in lanes 16..31 of each half (lanes 0..15 hold their 16-lane row's sum only)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov0(float v) {   // lanes outside ROW_MASK (and invalid sources) read 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float half_wave_sum_hi16(float v) {
+  v += dpp_mov0<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov0<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov0<0x141, 0xF>(v);   // row_half_mirror
+  v += dpp_mov0<0x140, 0xF>(v);   // row_mirror: every lane of a 16-lane row holds the row's sum
+  v += dpp_mov0<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3: lanes 16..31 / 48..63 hold the 32-lane sum
+  return v;
+}
 // sum over the 32 lanes that share (lane >> 5)
 __device__ __forceinline__ float half_wave_sum(float v) {
 #pragma unroll

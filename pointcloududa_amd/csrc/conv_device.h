@@ -166,18 +166,15 @@ __device__ __forceinline__ void xfast_issue(XFast<PF>& pre, const pcuda_src& x, 
     pre.inb[s] = (pix < npix) & ((unsigned)gy < (unsigned)in_h) & ((unsigned)gx < (unsigned)in_w);
     voff[s] = pre.inb[s] ? (unsigned)((gy >> in_shift) * in_row + (gx >> in_shift)) * 4u : IG_OOB;
   }
+  // always 32 loads per slot, no branches (channels past the source read 0 through the range check): a
+  // conditional load would make every later counted wait on OLDER loads collapse to vmcnt(0)
   unsigned soff = (unsigned)cl0 * plane;
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    if (g < ngroups) {
+  for (int j = 0; j < 32; ++j) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-#pragma unroll
-        for (int s = 0; s < PF; ++s)
-          pre.v[s][g * 8 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[s], soff, 0));
-        soff += plane;
-      }
-    }
+    for (int s = 0; s < PF; ++s)
+      pre.v[s][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[s], soff, 0));
+    soff += plane;
   }
 }
 
@@ -237,21 +234,134 @@ __device__ __forceinline__ void xfast_commit(XFast<PF>& pre, unsigned char* __re
   }
 }
 
-// contiguous global -> LDS copy of nvec 16-B vectors, 4 loads per lane in flight
-__device__ __forceinline__ void copy_vec16(unsigned char* __restrict__ dst, const uint4* __restrict__ src, int nvec,
-                                           int tid) {
-  for (int base = 0; base < nvec; base += 1024) {
-    uint4 r[4];
+// ------------------------------------------------------------------------------------------
+// Quad staging path (input rows of 4k pixels, no upsampling fold): one float4 load brings 4 consecutive
+// pixels of one channel, so a 32-channel chunk of a 340-pixel halo tile is 16 loads per lane instead of
+// 64.  (A wave can have at most 64 vector-memory instructions outstanding -- vmcnt is 6 bits -- so the
+// dword path stalled in its own issue loop as soon as the weight loads shared the queue.)
+// Wave w stages channel group w (8 channels: scale/shift stay scalar); lane + 64*s walks the
+// (row, quad) grid of the tile.  Quads are aligned to the IMAGE (x = 4k), hence entirely inside or
+// outside it; `lead` = pixels of the first quad left of the tile.
+// ------------------------------------------------------------------------------------------
+// (register image shared with the dword path: v[s][4*j + e] = pixel e of the quad, channel j of the group)
+template <int PF>
+__device__ __forceinline__ void xq_issue(XFast<PF>& pre, const pcuda_src& x, int n, int cin, int chunk, int in_h, int in_w,
+                                         int oy0, int ox0, int th, int tw, int tid) {
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int c0 = chunk * 32;
+  const bool first = c0 < x.c1;
+  const float* base = first ? x.p1 + (long long)n * x.sn1 : x.p2 + (long long)n * x.sn2;
+  const int csrc = first ? min(x.c1, cin) : cin - x.c1;
+  const int cl0 = (first ? c0 : c0 - x.c1) + w * 8;
+  const long long sc = first ? x.sc1 : x.sc2;
+  const int lead = ox0 & 3, nq = (tw + lead + 3) >> 2, nitems = th * nq;
+  const int qmagic = (1 << 16) / nq + 1;   // exact for item < 1024, nq <= 80
+  unsigned off[PF];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = base + tid + u * 256;
-      r[u] = src[i < nvec ? i : nvec - 1];   // unconditional (clamped) load keeps r[] in registers
+  for (int s = 0; s < PF; ++s) {
+    const int item = lane + 64 * s;
+    const int iy = (item * qmagic) >> 16, q = item - iy * nq;
+    const int gy = oy0 + iy, gx = ox0 - lead + 4 * q;
+    pre.inb[s] = (item < nitems) & ((unsigned)gy < (unsigned)in_h) & ((unsigned)gx < (unsigned)in_w);
+    off[s] = pre.inb[s] ? (unsigned)(gy * in_w + gx) * 4u : 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const char* plane = (const char*)(base + (long long)min(cl0 + j, csrc - 1) * sc);   // wave-uniform, clamped
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+      const float4 t = *(const float4*)(plane + off[s]);
+      pre.v[s][4 * j + 0] = t.x; pre.v[s][4 * j + 1] = t.y; pre.v[s][4 * j + 2] = t.z; pre.v[s][4 * j + 3] = t.w;
+    }
+  }
+}
+
+template <bool X3, int PF>
+__device__ __forceinline__ void xq_commit(XFast<PF>& pre, unsigned char* __restrict__ xhi, unsigned char* __restrict__ xlo,
+                                          const pcuda_src& x, int cin, int chunk, int ox0, int th, int tw, int nwrite,
+                                          int tid) {
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  if (w >= nwrite) return;   // channel groups past the k-steps this chunk runs
+  const int c0 = chunk * 32;
+  const bool first = c0 < x.c1;
+  const float* scp = first ? x.scale1 : x.scale2;
+  const float* shp = first ? x.shift1 : x.shift2;
+  const int csrc = first ? min(x.c1, cin) : cin - x.c1;
+  const int cl0 = (first ? c0 : c0 - x.c1) + w * 8;
+  const int lead = ox0 & 3, nq = (tw + lead + 3) >> 2, nitems = th * nq;
+  const int qmagic = (1 << 16) / nq + 1;
+  float sc[8], sh[8];
+  bool cok[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    cok[j] = cl0 + j < csrc;
+    sc[j] = 1.f; sh[j] = 0.f;
+    if (scp) { sc[j] = scp[min(cl0 + j, csrc - 1)]; sh[j] = shp[min(cl0 + j, csrc - 1)]; }
+  }
+#pragma unroll
+  for (int s = 0; s < PF; ++s) {
+    const int item = lane + 64 * s;
+    const int iy = (item * qmagic) >> 16, q = item - iy * nq;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool ok = pre.inb[s] & cok[j];   // zero padding is applied AFTER the affine
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = pre.v[s][4 * j + e];
+        if (scp) t = fmaf(t, sc[j], sh[j]);
+        pre.v[s][4 * j + e] = ok ? t : 0.f;
+      }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = base + tid + u * 256;
-      if (i < nvec) ((uint4*)dst)[i] = r[u];
+    for (int e = 0; e < 4; ++e) {
+      const int ix = 4 * q + e - lead;
+      if ((item < nitems) & ((unsigned)ix < (unsigned)tw)) {
+        const float vv[8] = {pre.v[s][e], pre.v[s][4 + e], pre.v[s][8 + e], pre.v[s][12 + e],
+                             pre.v[s][16 + e], pre.v[s][20 + e], pre.v[s][24 + e], pre.v[s][28 + e]};
+        stage_write<X3>(xhi, xlo, vv, iy * tw + ix, w);
+      }
     }
+  }
+}
+
+// contiguous global -> LDS copy of nvec 16-B vectors (packed weights: the global image IS the LDS image).
+// Branch-free: lanes past the end re-copy the last vector (same bytes to the same address), so the
+// loads of a pass are issued back to back and no wait sits between them.  (With a guarded store the
+// compiler sank every load into its store's branch and waited vmcnt(0) after each one.)
+template <bool X3, int WV>
+struct WPass {
+  uint4 hi[WV], lo[X3 ? WV : 1];
+};
+template <bool X3, int WV>
+__device__ __forceinline__ void wcopy_issue(WPass<X3, WV>& wp, const uint4* __restrict__ hi,
+                                            const uint4* __restrict__ lo, int nvec, int base, int tid) {
+#pragma unroll
+  for (int u = 0; u < WV; ++u) {
+    const int i = min(base + tid + u * 256, nvec - 1);
+    wp.hi[u] = hi[i];
+    if (X3) wp.lo[u] = lo[i];
+  }
+}
+template <bool X3, int WV>
+__device__ __forceinline__ void wcopy_commit(const WPass<X3, WV>& wp, unsigned char* __restrict__ dhi,
+                                             unsigned char* __restrict__ dlo, int nvec, int base, int tid) {
+#pragma unroll
+  for (int u = 0; u < WV; ++u) {
+    const int i = min(base + tid + u * 256, nvec - 1);
+    ((uint4*)dhi)[i] = wp.hi[u];
+    if (X3) ((uint4*)dlo)[i] = wp.lo[u];
+  }
+}
+template <bool X3, int WV>
+__device__ __forceinline__ void wcopy(unsigned char* __restrict__ dhi, unsigned char* __restrict__ dlo,
+                                      const uint4* __restrict__ hi, const uint4* __restrict__ lo, int nvec, int base0,
+                                      int tid) {
+  for (int base = base0; base < nvec; base += 256 * WV) {
+    WPass<X3, WV> wp;
+    wcopy_issue<X3, WV>(wp, hi, lo, nvec, base, tid);
+    __builtin_amdgcn_sched_barrier(0);   // keep the pass's loads together (the scheduler, short of registers,
+    wcopy_commit<X3, WV>(wp, dhi, dlo, nvec, base, tid);   // otherwise emits load / wait / store one vector at a time)
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 

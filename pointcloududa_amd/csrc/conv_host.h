@@ -106,3 +106,22 @@ static inline bool fast_src_ok(const pcuda_src* x, int cin) {
   if (c1 < cin && (long long)(cin - c1 + 32) * x->sc2 * 4 >= lim) return false;
   return true;
 }
+
+// fast epilogue (buffer stores): an 8-row register group never straddles the two destinations and every
+// destination image spans < 2^30 bytes
+static inline bool fast_dst_ok(const pcuda_dst* y, int cout) {
+  const long long lim = 1ll << 30;
+  const int c1 = y->c1 < cout ? y->c1 : cout;
+  if (c1 < cout && (c1 & 7)) return false;
+  if ((long long)(c1 + 64) * y->sc1 * 4 >= lim) return false;
+  if (c1 < cout && (long long)(cout - c1 + 64) * y->sc2 * 4 >= lim) return false;
+  return true;
+}
+
+// tile / LDS plan of one forward or dgrad launch (conv_igemm.hip plans, conv_igemm_impl.h launches)
+struct IgemmPlan {
+  int npb, tw, th, tiles_x, tiles_y, ih_t, iw_t, clamp, x_cap, tg;
+  size_t lds;
+  int fat;   // one workgroup per CU, every (or many) taps of weights resident
+};
+

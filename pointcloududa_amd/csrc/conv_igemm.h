@@ -38,6 +38,8 @@ struct IgemmParams {
   int n_co_tiles;
   int clamp;               // 1: LDS tile = tile clipped to the image (+ one zero record)
   int dbg;                 // PCUDA_DBG bits (timing experiments only): 1 no X loads, 2 no MFMA, 4 no epilogue, 8 no W copy
+  unsigned long long* dbg_clk;   // PCUDA_DBG bit 128: 8 per-phase cycle sums
+  int xq;                  // 1: quad (float4) input staging (in_w % 4 == 0, no upsampling fold)
 };
 
 // wgrad: dW[r][c][tap] = sum_{n,oy,ox} dZ[r][oy,ox] * X[c][oy*stride + dy[t]][ox*stride + dx[t]]

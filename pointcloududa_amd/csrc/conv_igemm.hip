@@ -12,7 +12,7 @@
 //                     ds_read_b64_tr_b16, split-K partial slabs + deterministic reduce)
 #include <stdlib.h>
 
-#include "conv_device.h"
+#include "conv_igemm.h"
 #include "conv_host.h"
 
 // ------------------------------------------------------------------------------------------
@@ -41,469 +41,21 @@ __global__ void pack_kernel(const PackParams p) {
 }
 
 
-// ------------------------------------------------------------------------------------------
-// forward / dgrad kernel.  256 threads = 4 waves; tile = CO_TILE rows x (128*NPB) logical pixels;
-// wave w owns pixels [32*NPB*w, +32*NPB) (NPB 32-pixel MFMA column blocks) for all CO_BLKS row blocks.
-// ------------------------------------------------------------------------------------------
-template <bool X3, int CO_BLKS, bool CLAMP, int NPB>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p, const int x_cap) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int CO_TILE = 32 * CO_BLKS;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
-
-  // XCD-aware block order: blocks that share an XCD (bid % 8) walk adjacent tiles, and the
-  // co-tiles of one pixel tile are adjacent, so the haloed input tile is fetched once per L2.
-  const unsigned bid = blockIdx.x, nwg = gridDim.x;
-  const unsigned xcd = bid & 7, q = nwg >> 3, rem = nwg & 7;
-  const unsigned L = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
-  const int cot = L % p.n_co_tiles;
-  const int pt = L / p.n_co_tiles;
-  const int txi = pt % p.tiles_x;
-  const int tmp = pt / p.tiles_x;
-  const int tyi = tmp % p.tiles_y;
-  const int n = tmp / p.tiles_y;
-  const int TW = p.tw, TH = p.th, TPIX = TW * TH;
-  const int y0 = tyi * TH, x0 = txi * TW;
-
-  int oy0 = y0 * p.in_step + p.dy_min, ox0 = x0 * p.in_step + p.dx_min;
-  int th = p.ih_t, tw = p.iw_t;
-  if (CLAMP) {
-    const int y1 = min(oy0 + th, p.in_h), x1 = min(ox0 + tw, p.in_w);
-    oy0 = max(oy0, 0); ox0 = max(ox0, 0);
-    th = max(y1 - oy0, 0); tw = max(x1 - ox0, 0);
-  }
-  const int npix = th * tw;
-
-  unsigned char* Xhi = smem;
-  unsigned char* Xlo = smem + (size_t)x_cap * IG_REC_BYTES;
-  unsigned char* Whi = smem + (size_t)(X3 ? 2 : 1) * x_cap * IG_REC_BYTES;
-  unsigned char* Wlo = Whi + (size_t)p.tg * CO_TILE * IG_REC_BYTES;
-
-  // per-lane pixel of each MFMA column block
-  int pty[NPB], ptx[NPB], bbase[NPB];
-  bool pvalid[NPB];
-#pragma unroll
-  for (int pb = 0; pb < NPB; ++pb) {
-    const int plr = w * (32 * NPB) + pb * 32 + r;
-    pvalid[pb] = plr < TPIX;
-    const int pl = min(plr, TPIX - 1);          // idle slots of a non-power-of-two tile read a valid pixel
-    pty[pb] = IG_TY(pl, p.tmagic);
-    ptx[pb] = pl - pty[pb] * TW;
-    bbase[pb] = ((pty[pb] * p.in_step) * tw + ptx[pb] * p.in_step) * IG_REC_BYTES + h * 16;
-  }
-
-  f32x16 acc[CO_BLKS][NPB];
-#pragma unroll
-  for (int cb = 0; cb < CO_BLKS; ++cb)
-#pragma unroll
-    for (int pb = 0; pb < NPB; ++pb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[cb][pb][i] = 0.f;
-
-  for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-    const int cvalid = min(32, p.cin - chunk * 32);
-    const int nks = cvalid > 16 ? 2 : 1;
-    __syncthreads();   // every wave is done reading the previous chunk's X / W
-    if (!(p.dbg & 1))
-      stage_x_chunk<X3>(Xhi, Xlo, p.x, n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row, oy0, ox0, th, tw,
-                        (cvalid + 7) >> 3, nks * 2, tid);
-    if (CLAMP && tid < 5) {   // the all-zero record that out-of-image taps read
-      *(uint4*)(Xhi + (size_t)npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
-      if (X3) *(uint4*)(Xlo + (size_t)npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
-    }
-    for (int t0 = 0; t0 < p.ntaps; t0 += p.tg) {
-      if (t0 > 0) __syncthreads();
-      const int tgc = min(p.tg, p.ntaps - t0);
-      {
-        const long long slab = (long long)CO_TILE * IG_REC;   // bf16 elements per tap
-        const uint16_t* src = p.wpack + (((long long)cot * p.nchunks + chunk) * p.ntaps + t0) * slab;
-        const int nvec = tgc * CO_TILE * 5;                  // 16-B vectors
-        if (!(p.dbg & 8)) {
-          copy_vec16(Whi, (const uint4*)src, nvec, tid);
-          if (X3) copy_vec16(Wlo, (const uint4*)(src + p.w_lo_off), nvec, tid);
-        }
-      }
-      __syncthreads();
-      for (int tl = 0; tl < ((p.dbg & 2) ? 0 : tgc); ++tl) {
-        const int t = t0 + tl;
-        int baddr[NPB];
-        if (CLAMP) {
-#pragma unroll
-          for (int pb = 0; pb < NPB; ++pb) {
-            const int gy = (y0 + pty[pb]) * p.in_step + p.dy[t];
-            const int gx = (x0 + ptx[pb]) * p.in_step + p.dx[t];
-            const bool ok = ((unsigned)gy < (unsigned)p.in_h) & ((unsigned)gx < (unsigned)p.in_w);
-            const int idx = ok ? (gy - oy0) * tw + (gx - ox0) : npix;
-            baddr[pb] = idx * IG_REC_BYTES + h * 16;
-          }
-        } else {
-          const int toff = ((p.dy[t] - p.dy_min) * tw + (p.dx[t] - p.dx_min)) * IG_REC_BYTES;
-#pragma unroll
-          for (int pb = 0; pb < NPB; ++pb) baddr[pb] = bbase[pb] + toff;
-        }
-        const int abase = (tl * CO_TILE + r) * IG_REC_BYTES + h * 16;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          if (ks < nks) {
-            bf16x8 ah[CO_BLKS], al[CO_BLKS], bh[NPB], bl[NPB];
-#pragma unroll
-            for (int cb = 0; cb < CO_BLKS; ++cb) {
-              ah[cb] = lds_frag(Whi + abase + cb * 32 * IG_REC_BYTES + ks * 32);
-              if (X3) al[cb] = lds_frag(Wlo + abase + cb * 32 * IG_REC_BYTES + ks * 32);
-            }
-#pragma unroll
-            for (int pb = 0; pb < NPB; ++pb) {
-              bh[pb] = lds_frag(Xhi + baddr[pb] + ks * 32);
-              if (X3) bl[pb] = lds_frag(Xlo + baddr[pb] + ks * 32);
-            }
-#pragma unroll
-            for (int cb = 0; cb < CO_BLKS; ++cb)
-#pragma unroll
-              for (int pb = 0; pb < NPB; ++pb) {
-                if (X3) {
-                  acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cb], bh[pb], acc[cb][pb], 0, 0, 0);
-                  acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb], bl[pb], acc[cb][pb], 0, 0, 0);
-                }
-                acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb], bh[pb], acc[cb][pb], 0, 0, 0);
-              }
-          }
-        }
-      }
-    }
-  }
-
-  // ---- epilogue: bias + LeakyReLU, NCHW store (register i = one output channel, the 32 lanes of
-  // a half-wave = 32 consecutive pixels), optional per-tile BatchNorm partial sums.
-  __syncthreads();
-  if (p.dbg & 4) {
-    if (acc[0][0][0] == 123.456f) p.y.p1[0] = 1.f;   // keep the accumulators live
-    return;
-  }
-  float* sred = (float*)smem;   // [4 waves][CO_TILE][2]
-  // per-lane output pixel offsets (elements within a plane), computed once
-  int poff[NPB];
-  bool pok[NPB];
-#pragma unroll
-  for (int pb = 0; pb < NPB; ++pb) {
-    const int ly = y0 + pty[pb], lx = x0 + ptx[pb];
-    pok[pb] = pvalid[pb] & (ly < p.lh) & (lx < p.lw);
-    poff[pb] = (ly * p.oy_mul + p.oy_off) * p.out_w + (lx * p.ox_mul + p.ox_off);
-  }
-  const int co0 = cot * CO_TILE;
-  // fast path: the two half-waves (rows r0 and r0+4) of every register land in the same destination
-  // tensor -> the plane base of row r0 is wave-uniform (SGPR) and lanes add a 32-bit offset
-  const bool uni = (p.y.c1 >= p.cout) | ((p.y.c1 & 7) == 0);
-  float* const yb1 = p.y.p1 + (long long)n * p.y.sn1;
-  float* const yb2 = p.y.p2 + (long long)n * p.y.sn2;
-#pragma unroll
-  for (int cb = 0; cb < CO_BLKS; ++cb) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row0 = cb * 32 + (i & 3) + 8 * (i >> 2);   // wave-uniform
-      const int row = row0 + 4 * h;
-      const int co = co0 + row;
-      const bool cok = co < p.cout;
-      const float b = (cok && p.bias) ? p.bias[co] : 0.f;
-      float* plane;
-      if (uni) {
-        const int cu = min(co0 + row0, p.cout - 1);
-        float* base = (cu < p.y.c1) ? yb1 + (long long)cu * p.y.sc1 : yb2 + (long long)(cu - p.y.c1) * p.y.sc2;
-        const long long hs = (cu < p.y.c1) ? p.y.sc1 : p.y.sc2;
-        plane = base + (h ? 4 * hs : 0);
-      } else {
-        const int cc = min(co, p.cout - 1);
-        plane = (cc < p.y.c1) ? yb1 + (long long)cc * p.y.sc1 : yb2 + (long long)(cc - p.y.c1) * p.y.sc2;
-      }
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int pb = 0; pb < NPB; ++pb) {
-        float v = acc[cb][pb][i] + b;
-        v = v > 0.f ? v : v * p.slope;
-        float* dst = plane + poff[pb];
-        if (cok & pok[pb]) {
-          if (p.accumulate) v += *dst;
-          *dst = v;
-          s1 += v;
-          s2 += v * v;
-        }
-      }
-      if (p.stats) {
-        s1 = half_wave_sum(s1);
-        s2 = half_wave_sum(s2);
-        if (r == 0) {
-          sred[(w * CO_TILE + row) * 2 + 0] = s1;
-          sred[(w * CO_TILE + row) * 2 + 1] = s2;
-        }
-      }
-    }
-  }
-  if (p.stats) {
-    __syncthreads();
-    if (tid < CO_TILE) {
-      const int co = cot * CO_TILE + tid;
-      if (co < p.cout) {
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int ww = 0; ww < 4; ++ww) {   // fixed order: deterministic
-          s1 += sred[(ww * CO_TILE + tid) * 2 + 0];
-          s2 += sred[(ww * CO_TILE + tid) * 2 + 1];
-        }
-        p.stats[((long long)pt * p.cout + co) * 2 + 0] = s1;
-        p.stats[((long long)pt * p.cout + co) * 2 + 1] = s2;
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Persistent, software-pipelined forward / dgrad kernel (the default).  Same tiling as igemm_kernel,
-// but a workgroup walks a strided list of (tile, 32-channel chunk) stages and keeps the NEXT stage's
-// input loads in flight (32*PF dwords per lane, in registers) while the current stage copies its
-// weights, runs its MFMAs and stores its outputs.  With only 1-2 workgroups per CU (LDS-limited) the
-// unpipelined kernel left HBM idle during compute and the matrix cores idle during staging.
-// ------------------------------------------------------------------------------------------
-struct TileGeom {
-  int cot, pt, n, y0, x0, oy0, ox0, th, tw, npix;
-};
-
-template <bool CLAMP, int NPB>
-__device__ __forceinline__ TileGeom tile_decode(const IgemmParams& p, int L) {
-  TileGeom g;
-  g.cot = L % p.n_co_tiles;
-  g.pt = L / p.n_co_tiles;
-  const int txi = g.pt % p.tiles_x;
-  const int tmp = g.pt / p.tiles_x;
-  const int tyi = tmp % p.tiles_y;
-  g.n = tmp / p.tiles_y;
-  const int TW = p.tw, TH = p.th;
-  g.y0 = tyi * TH; g.x0 = txi * TW;
-  g.oy0 = g.y0 * p.in_step + p.dy_min; g.ox0 = g.x0 * p.in_step + p.dx_min;
-  g.th = p.ih_t; g.tw = p.iw_t;
-  if (CLAMP) {
-    const int y1 = min(g.oy0 + g.th, p.in_h), x1 = min(g.ox0 + g.tw, p.in_w);
-    g.oy0 = max(g.oy0, 0); g.ox0 = max(g.ox0, 0);
-    g.th = max(y1 - g.oy0, 0); g.tw = max(x1 - g.ox0, 0);
-  }
-  g.npix = g.th * g.tw;
-  return g;
-}
-
-template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF>
-__global__ __launch_bounds__(256, 2) void igemm_pipe_kernel(const IgemmParams p, const int x_cap, const int total) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int CO_TILE = 32 * CO_BLKS;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
-  const int TW = p.tw, TPIX = p.tw * p.th;
-
-  // XCD-aware persistent schedule: the 8 XCDs own contiguous eighths of the (pixel tile, co tile) list;
-  // the workgroups of one XCD (blockIdx % 8) interleave over it, so concurrent workgroups touch
-  // adjacent tiles (shared halo rows and weights hit that XCD's L2).
-  const int nx = min(8, (int)gridDim.x);                          // XCD groups that actually have workgroups
-  const int xcd = blockIdx.x % nx, slot = blockIdx.x / nx;
-  const int gx = ((int)gridDim.x - xcd + nx - 1) / nx;            // workgroups in this group
-  const int lo = (int)((long long)total * xcd / nx), hi = (int)((long long)total * (xcd + 1) / nx);
-
-  unsigned char* Xhi = smem;
-  unsigned char* Xlo = smem + (size_t)x_cap * IG_REC_BYTES;
-  unsigned char* Whi = smem + (size_t)(X3 ? 2 : 1) * x_cap * IG_REC_BYTES;
-  unsigned char* Wlo = Whi + (size_t)p.tg * CO_TILE * IG_REC_BYTES;
-  float* sred = (float*)smem;   // [4 waves][CO_TILE][2], reused between a tile's last MFMA and the next commit
-
-  int pty[NPB], ptx[NPB];
-  bool pvalid[NPB];
-#pragma unroll
-  for (int pb = 0; pb < NPB; ++pb) {
-    const int plr = w * (32 * NPB) + pb * 32 + r;
-    pvalid[pb] = plr < TPIX;
-    const int pl = min(plr, TPIX - 1);
-    pty[pb] = IG_TY(pl, p.tmagic);
-    ptx[pb] = pl - pty[pb] * TW;
-  }
-
-  f32x16 acc[CO_BLKS][NPB];
-  XPre<PF> pre;
-
-  int L = lo + slot, chunk = 0;
-  bool have = L < hi;
-  TileGeom g;
-  if (have) {
-    g = tile_decode<CLAMP, NPB>(p, L);
-    xpre_issue<PF>(pre, p.x, g.n, p.cin, 0, p.in_h, p.in_w, p.in_shift, p.in_row, g.oy0, g.ox0, g.tw, g.npix,
-                   (min(32, p.cin) + 7) >> 3, tid);
-  }
-  while (have) {
-    const int cvalid = min(32, p.cin - chunk * 32);
-    const int nks = cvalid > 16 ? 2 : 1;
-    __syncthreads();   // every wave is done with the previous stage's X / W / reduction scratch
-    xpre_commit<X3, PF>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.npix, (cvalid + 7) >> 3, nks * 2, tid);
-    if (CLAMP && tid < 5) {
-      *(uint4*)(Xhi + (size_t)g.npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
-      if (X3) *(uint4*)(Xlo + (size_t)g.npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
-    }
-    // next stage: its loads stay in flight through everything below
-    int nL = L, nchunk = chunk + 1;
-    if (nchunk == p.nchunks) { nchunk = 0; nL = L + gx; }
-    const bool nhave = nL < hi;
-    TileGeom ng = g;
-    if (nhave) {
-      if (nL != L) ng = tile_decode<CLAMP, NPB>(p, nL);
-      xpre_issue<PF>(pre, p.x, ng.n, p.cin, nchunk, p.in_h, p.in_w, p.in_shift, p.in_row, ng.oy0, ng.ox0, ng.tw,
-                     ng.npix, (min(32, p.cin - nchunk * 32) + 7) >> 3, tid);
-    }
-
-    if (chunk == 0) {
-#pragma unroll
-      for (int cb = 0; cb < CO_BLKS; ++cb)
-#pragma unroll
-        for (int pb = 0; pb < NPB; ++pb)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) acc[cb][pb][i] = 0.f;
-    }
-    int bbase[NPB];
-#pragma unroll
-    for (int pb = 0; pb < NPB; ++pb)
-      bbase[pb] = ((pty[pb] * p.in_step) * g.tw + ptx[pb] * p.in_step) * IG_REC_BYTES + h * 16;
-
-    for (int t0 = 0; t0 < p.ntaps; t0 += p.tg) {
-      if (t0 > 0) __syncthreads();
-      const int tgc = min(p.tg, p.ntaps - t0);
-      {
-        const long long slab = (long long)CO_TILE * IG_REC;
-        const uint16_t* src = p.wpack + (((long long)g.cot * p.nchunks + chunk) * p.ntaps + t0) * slab;
-        const int nvec = tgc * CO_TILE * 5;
-        copy_vec16(Whi, (const uint4*)src, nvec, tid);
-        if (X3) copy_vec16(Wlo, (const uint4*)(src + p.w_lo_off), nvec, tid);
-      }
-      __syncthreads();
-      for (int tl = 0; tl < tgc; ++tl) {
-        const int t = t0 + tl;
-        int baddr[NPB];
-        if (CLAMP) {
-#pragma unroll
-          for (int pb = 0; pb < NPB; ++pb) {
-            const int gy = (g.y0 + pty[pb]) * p.in_step + p.dy[t];
-            const int gxx = (g.x0 + ptx[pb]) * p.in_step + p.dx[t];
-            const bool ok = ((unsigned)gy < (unsigned)p.in_h) & ((unsigned)gxx < (unsigned)p.in_w);
-            const int idx = ok ? (gy - g.oy0) * g.tw + (gxx - g.ox0) : g.npix;
-            baddr[pb] = idx * IG_REC_BYTES + h * 16;
-          }
-        } else {
-          const int toff = ((p.dy[t] - p.dy_min) * g.tw + (p.dx[t] - p.dx_min)) * IG_REC_BYTES;
-#pragma unroll
-          for (int pb = 0; pb < NPB; ++pb) baddr[pb] = bbase[pb] + toff;
-        }
-        const int abase = (tl * CO_TILE + r) * IG_REC_BYTES + h * 16;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          if (ks < nks) {
-            bf16x8 ah[CO_BLKS], al[CO_BLKS], bh[NPB], bl[NPB];
-#pragma unroll
-            for (int cb = 0; cb < CO_BLKS; ++cb) {
-              ah[cb] = lds_frag(Whi + abase + cb * 32 * IG_REC_BYTES + ks * 32);
-              if (X3) al[cb] = lds_frag(Wlo + abase + cb * 32 * IG_REC_BYTES + ks * 32);
-            }
-#pragma unroll
-            for (int pb = 0; pb < NPB; ++pb) {
-              bh[pb] = lds_frag(Xhi + baddr[pb] + ks * 32);
-              if (X3) bl[pb] = lds_frag(Xlo + baddr[pb] + ks * 32);
-            }
-#pragma unroll
-            for (int cb = 0; cb < CO_BLKS; ++cb)
-#pragma unroll
-              for (int pb = 0; pb < NPB; ++pb) {
-                if (X3) {
-                  acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cb], bh[pb], acc[cb][pb], 0, 0, 0);
-                  acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb], bl[pb], acc[cb][pb], 0, 0, 0);
-                }
-                acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb], bh[pb], acc[cb][pb], 0, 0, 0);
-              }
-          }
-        }
-      }
-    }
-
-    if (chunk == p.nchunks - 1) {
-      // ---- epilogue of this tile (see igemm_kernel)
-      if (p.stats) __syncthreads();   // sred aliases the X tile: wait for every wave's last fragment reads
-      int poff[NPB];
-      bool pok[NPB];
-#pragma unroll
-      for (int pb = 0; pb < NPB; ++pb) {
-        const int ly = g.y0 + pty[pb], lx = g.x0 + ptx[pb];
-        pok[pb] = pvalid[pb] & (ly < p.lh) & (lx < p.lw);
-        poff[pb] = (ly * p.oy_mul + p.oy_off) * p.out_w + (lx * p.ox_mul + p.ox_off);
-      }
-      const int co0 = g.cot * CO_TILE;
-      const bool uni = (p.y.c1 >= p.cout) | ((p.y.c1 & 7) == 0);
-      float* const yb1 = p.y.p1 + (long long)g.n * p.y.sn1;
-      float* const yb2 = p.y.p2 + (long long)g.n * p.y.sn2;
-#pragma unroll
-      for (int cb = 0; cb < CO_BLKS; ++cb) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int row0 = cb * 32 + (i & 3) + 8 * (i >> 2);
-          const int row = row0 + 4 * h;
-          const int co = co0 + row;
-          const bool cok = co < p.cout;
-          const float b = (cok && p.bias) ? p.bias[co] : 0.f;
-          float* plane;
-          if (uni) {
-            const int cu = min(co0 + row0, p.cout - 1);
-            float* base = (cu < p.y.c1) ? yb1 + (long long)cu * p.y.sc1 : yb2 + (long long)(cu - p.y.c1) * p.y.sc2;
-            const long long hs = (cu < p.y.c1) ? p.y.sc1 : p.y.sc2;
-            plane = base + (h ? 4 * hs : 0);
-          } else {
-            const int cc = min(co, p.cout - 1);
-            plane = (cc < p.y.c1) ? yb1 + (long long)cc * p.y.sc1 : yb2 + (long long)(cc - p.y.c1) * p.y.sc2;
-          }
-          float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-          for (int pb = 0; pb < NPB; ++pb) {
-            float v = acc[cb][pb][i] + b;
-            v = v > 0.f ? v : v * p.slope;
-            float* dst = plane + poff[pb];
-            if (cok & pok[pb]) {
-              if (p.accumulate) v += *dst;
-              *dst = v;
-              s1 += v;
-              s2 += v * v;
-            }
-          }
-          if (p.stats) {
-            s1 = half_wave_sum(s1);
-            s2 = half_wave_sum(s2);
-            if (r == 0) {
-              sred[(w * CO_TILE + row) * 2 + 0] = s1;
-              sred[(w * CO_TILE + row) * 2 + 1] = s2;
-            }
-          }
-        }
-      }
-      if (p.stats) {
-        __syncthreads();
-        if (tid < CO_TILE) {
-          const int co = g.cot * CO_TILE + tid;
-          if (co < p.cout) {
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int ww = 0; ww < 4; ++ww) {
-              s1 += sred[(ww * CO_TILE + tid) * 2 + 0];
-              s2 += sred[(ww * CO_TILE + tid) * 2 + 1];
-            }
-            p.stats[((long long)g.pt * p.cout + co) * 2 + 0] = s1;
-            p.stats[((long long)g.pt * p.cout + co) * 2 + 1] = s2;
-          }
-        }
-      }
-    }
-    L = nL; chunk = nchunk; g = ng; have = nhave;
-  }
-}
-
 // ==========================================================================================
 // host side
 // ==========================================================================================
+int igemm_dispatch_x3(const IgemmParams& p, const IgemmPlan& pl, int co_blks, int pf, bool pipe, hipStream_t s);
+int igemm_dispatch_bf16(const IgemmParams& p, const IgemmPlan& pl, int co_blks, int pf, bool pipe, hipStream_t s);
+
 namespace {
+
+// PCUDA_FAT=1 plans one workgroup per CU with all taps resident (experimental: the weight stash spills)
+unsigned long long* g_dbg_clk_host = nullptr;
+bool ig_fat_mode() {
+  static int fat = -1;
+  if (fat < 0) { const char* e = getenv("PCUDA_FAT"); fat = e ? (atoi(e) ? 1 : 0) : 0; }
+  return fat != 0;
+}
 
 size_t packed_elems(int rows, int red, int ntaps) {   // bf16 elements of ONE plane (hi)
   const int co_tile = 32 * ig_co_blks(rows);
@@ -530,22 +82,27 @@ int launch_pack(const float* w, uint16_t* out, int prec, int rows, int red, long
   return PCUDA_OK;
 }
 
-// pick taps-per-group and LDS size; returns <0 when nothing fits
-int plan_lds(bool x3, int co_tile, int x_cap, int ntaps, int* tg_out, size_t* lds_out) {
+// pick taps-per-group and LDS size; returns <0 when nothing fits.  fat: one workgroup per CU (160 KiB),
+// as many taps resident as one 256*WV-vector copy pass holds.
+static inline int ig_wv(int co_tile, bool fat) { return fat ? (co_tile == 64 ? 12 : 6) : 3; }
+int plan_lds(bool x3, int co_tile, int x_cap, int ntaps, bool fat, int* tg_out, size_t* lds_out) {
   const size_t mul = x3 ? 2 : 1;
   const size_t xb = (size_t)x_cap * IG_REC_BYTES * mul;
   const size_t wtap = (size_t)co_tile * IG_REC_BYTES * mul;
   const size_t epi = 4 * (size_t)co_tile * 2 * sizeof(float);
+  const size_t tab = 512;   // per-tap offset table + the epilogue's bias slice, behind the weight slabs
   if (ntaps < 1) ntaps = 1;
+  const int cap = ig_wv(co_tile, fat) * 256 / (co_tile * 5);   // one copy pass per group
   // budgets: 3, 2, 1 workgroups per CU (160 KiB LDS)
   const size_t budgets[3] = {54528, 81920, 163840};
-  for (int b = 0; b < 3; ++b) {
-    if (xb >= budgets[b]) continue;
-    const int fit = (int)((budgets[b] - xb) / wtap);
+  for (int b = fat ? 2 : 0; b < 3; ++b) {
+    if (xb + tab >= budgets[b]) continue;
+    int fit = (int)((budgets[b] - xb - tab) / wtap);
+    if (fit > cap) fit = cap;
     const int need = b == 0 ? (ntaps < 3 ? ntaps : 3) : 1;
     if (fit < need) continue;
     const int tg = fit > ntaps ? ntaps : fit;
-    size_t total = xb + (size_t)tg * wtap;
+    size_t total = xb + (size_t)tg * wtap + tab;
     if (total < epi) total = epi;
     *tg_out = tg; *lds_out = total;
     return 0;
@@ -553,10 +110,6 @@ int plan_lds(bool x3, int co_tile, int x_cap, int ntaps, int* tg_out, size_t* ld
   return -1;
 }
 
-struct IgemmPlan {
-  int npb, tw, th, tiles_x, tiles_y, ih_t, iw_t, clamp, x_cap, tg;
-  size_t lds;
-};
 
 // tile shape / LDS plan of one generic launch: depends only on geometry, taps and precision.
 // Minimises the number of MFMA pixel slots (tiles x slots per tile); ties prefer 32-pixel-aligned rows
@@ -564,6 +117,7 @@ struct IgemmPlan {
 int plan_igemm(int rows, int lh, int lw, int in_h, int in_w, int in_step, const TapSet& taps, bool x3,
                IgemmPlan* best) {
   const int co_tile = 32 * ig_co_blks(rows);
+  const bool fat = ig_fat_mode();
   long long best_key = -1;
   for (int npb = 2; npb >= 1; --npb) {
     const int TP = 128 * npb;
@@ -584,7 +138,8 @@ int plan_igemm(int rows, int lh, int lw, int in_h, int in_w, int in_step, const 
       for (int attempt = 0; attempt < 2 && !ok; ++attempt) {
         pl.clamp = attempt == 0 ? ((clipped * 2 <= full) ? 1 : 0) : 1;
         pl.x_cap = pl.clamp ? clipped : full;
-        ok = plan_lds(x3, co_tile, pl.x_cap, taps.n, &pl.tg, &pl.lds) == 0;
+        pl.fat = fat ? 1 : 0;
+        ok = plan_lds(x3, co_tile, pl.x_cap, taps.n, fat, &pl.tg, &pl.lds) == 0;
         if (pl.clamp) break;
       }
       if (!ok) continue;
@@ -598,73 +153,6 @@ int plan_igemm(int rows, int lh, int lw, int in_h, int in_w, int in_step, const 
     }
   }
   return best_key < 0 ? -1 : 0;
-}
-
-template <bool X3, int CO_BLKS, bool CLAMP, int NPB>
-int launch_igemm_t(const IgemmParams& p, int x_cap, size_t lds, hipStream_t s) {
-  auto kern = igemm_kernel<X3, CO_BLKS, CLAMP, NPB>;
-  static size_t lds_set = 0;
-  if (lds > 32 * 1024 && lds > lds_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HARD);
-    if (e != hipSuccess) PCUDA_FAIL(PCUDA_E_LAUNCH, "igemm: cannot raise dynamic LDS to %d: %s", LDS_HARD, hipGetErrorString(e));
-    lds_set = LDS_HARD;
-  }
-  const int grid = p.n_co_tiles * p.n * p.tiles_x * p.tiles_y;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, p, x_cap);
-  PCUDA_CHECK_LAUNCH("igemm_kernel");
-  return PCUDA_OK;
-}
-
-template <bool X3, int CO_BLKS>
-int launch_igemm_c(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
-  if (pl.clamp) return pl.npb == 2 ? launch_igemm_t<X3, CO_BLKS, true, 2>(p, pl.x_cap, pl.lds, s)
-                                   : launch_igemm_t<X3, CO_BLKS, true, 1>(p, pl.x_cap, pl.lds, s);
-  return pl.npb == 2 ? launch_igemm_t<X3, CO_BLKS, false, 2>(p, pl.x_cap, pl.lds, s)
-                     : launch_igemm_t<X3, CO_BLKS, false, 1>(p, pl.x_cap, pl.lds, s);
-}
-
-template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF>
-int launch_pipe_t(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
-  auto kern = igemm_pipe_kernel<X3, CO_BLKS, CLAMP, NPB, PF>;
-  static size_t lds_set = 0;
-  if (pl.lds > 32 * 1024 && pl.lds > lds_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HARD);
-    if (e != hipSuccess) PCUDA_FAIL(PCUDA_E_LAUNCH, "igemm_pipe: cannot raise dynamic LDS: %s", hipGetErrorString(e));
-    lds_set = LDS_HARD;
-  }
-  const int total = p.n_co_tiles * p.n * p.tiles_x * p.tiles_y;
-  // persistent grid = what is resident at once (registers and LDS both limit it)
-  static int occ_cache[4] = {0, 0, 0, 0};   // by LDS class: <=53K, <=80K, <=160K
-  const int cls = pl.lds <= 54528 ? 0 : (pl.lds <= 81920 ? 1 : 2);
-  if (occ_cache[cls] == 0) {
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, pl.lds) != hipSuccess || nb < 1) nb = 1;
-    const int lds_lim = (int)((size_t)LDS_HARD / pl.lds);
-    if (nb > lds_lim) nb = lds_lim;
-    if (nb > 4) nb = 4;
-    if (nb < 1) nb = 1;
-    occ_cache[cls] = nb;
-  }
-  int grid = occ_cache[cls] * 256;
-  if (grid > total) grid = total;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), pl.lds, s, p, pl.x_cap, total);
-  PCUDA_CHECK_LAUNCH("igemm_pipe_kernel");
-  return PCUDA_OK;
-}
-
-template <bool X3, int CO_BLKS, bool CLAMP, int NPB>
-int launch_pipe_pf(const IgemmParams& p, const IgemmPlan& pl, int pf, hipStream_t s) {
-  if (pf == 1) return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 1>(p, pl, s);
-  if (pf == 2) return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 2>(p, pl, s);
-  return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 3>(p, pl, s);
-}
-
-template <bool X3, int CO_BLKS>
-int launch_pipe_c(const IgemmParams& p, const IgemmPlan& pl, int pf, hipStream_t s) {
-  if (pl.clamp) return pl.npb == 2 ? launch_pipe_pf<X3, CO_BLKS, true, 2>(p, pl, pf, s)
-                                   : launch_pipe_pf<X3, CO_BLKS, true, 1>(p, pl, pf, s);
-  return pl.npb == 2 ? launch_pipe_pf<X3, CO_BLKS, false, 2>(p, pl, pf, s)
-                     : launch_pipe_pf<X3, CO_BLKS, false, 1>(p, pl, pf, s);
 }
 
 int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
@@ -687,6 +175,10 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("PCUDA_DBG"); dbg = e ? atoi(e) : 0; }
     p.dbg = dbg;
+    static unsigned long long* clkbuf = nullptr;
+    if ((dbg & 128) && !clkbuf && hipMalloc((void**)&clkbuf, 64) == hipSuccess) (void)hipMemset(clkbuf, 0, 64);
+    p.dbg_clk = clkbuf;
+    g_dbg_clk_host = clkbuf;
   }
   const double flops = 2.0 * p.n * (double)p.lh * p.lw * p.cout * (double)p.cin * taps.n;
   char tag[160];
@@ -696,14 +188,22 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
   static int nopipe = -1;
   if (nopipe < 0) { const char* e = getenv("PCUDA_NOPIPE"); nopipe = e ? atoi(e) : 0; }
   const int max_pix = pl.clamp ? pl.x_cap - 1 : pl.ih_t * pl.iw_t;     // largest LDS tile of this launch
-  const int pf = (max_pix + 255) / 256;
-  // PF = 3 keeps 96 prefetch registers live next to the accumulators: only with one pixel block per wave
-  if (!nopipe && p.ntaps > 0 && (pf <= 2 || (pf == 3 && pl.npb == 1))) {
-    if (x3) return co_blks == 2 ? launch_pipe_c<true, 2>(p, pl, pf, s) : launch_pipe_c<true, 1>(p, pl, pf, s);
-    return co_blks == 2 ? launch_pipe_c<false, 2>(p, pl, pf, s) : launch_pipe_c<false, 1>(p, pl, pf, s);
+  int pf = (max_pix + 255) / 256;
+  {   // quad staging: rows of 4k pixels, no upsampling fold, (rows x quads) of a tile in <= 3 x 64 lanes
+    static int noxq = -1;
+    if (noxq < 0) { const char* e = getenv("PCUDA_NOXQ"); noxq = e ? atoi(e) : 0; }
+    const int ih = pl.ih_t < p.in_h ? pl.ih_t : p.in_h;
+    const int pfq = (ih * ((pl.iw_t + 6) / 4) + 63) / 64;
+    p.xq = (!noxq && (p.in_w & 3) == 0 && p.in_shift == 0 && pfq <= 3) ? 1 : 0;
+    if (p.xq) pf = pfq;
   }
-  if (x3) return co_blks == 2 ? launch_igemm_c<true, 2>(p, pl, s) : launch_igemm_c<true, 1>(p, pl, s);
-  return co_blks == 2 ? launch_igemm_c<false, 2>(p, pl, s) : launch_igemm_c<false, 1>(p, pl, s);
+  // PF = 3 keeps 96 prefetch registers live next to the accumulators: only with one pixel block per wave
+  // (one workgroup per CU has 512 registers per lane: PF = 3 next to two pixel blocks fits there)
+  const bool pipe = !nopipe && p.ntaps > 0 && fast_src_ok(&p.x, p.cin) && fast_dst_ok(&p.y, p.cout) &&
+                    (pf <= 2 || (pf == 3 && (pl.npb == 1 || pl.fat)));
+  if (!pipe && pl.fat) {   // the unpipelined kernel copies its weight groups in 512-vector passes: any tg works
+  }
+  return x3 ? igemm_dispatch_x3(p, pl, co_blks, pf, pipe, s) : igemm_dispatch_bf16(p, pl, co_blks, pf, pipe, s);
 }
 
 }  // namespace
@@ -809,4 +309,13 @@ extern "C" int pcuda_conv2d_dgrad(const pcuda_conv_geom* g, int prec, const pcud
       wp += plane * (prec == PCUDA_PREC_BF16X3 ? 2 : 1);
     }
   return PCUDA_OK;
+}
+
+// timing experiments (PCUDA_DBG bit 128): per-phase cycle sums of igemm_pipe_kernel, read and reset
+extern "C" int pcuda_debug_read_clocks(unsigned long long* out8) {
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (!g_dbg_clk_host) { memcpy(out8, z, sizeof(z)); return 0; }
+  if (hipMemcpy(out8, g_dbg_clk_host, sizeof(z), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (hipMemcpy(g_dbg_clk_host, z, sizeof(z), hipMemcpyHostToDevice) != hipSuccess) return -1;
+  return 0;
 }

@@ -1,0 +1,619 @@
+// Device side (and the templated launchers) of the forward / dgrad kernels; instantiated once per
+// precision (conv_igemm_x3.hip, conv_igemm_bf16.hip) so the two halves compile in parallel.
+#pragma once
+#include "conv_device.h"
+#include "conv_host.h"
+
+// ------------------------------------------------------------------------------------------
+// forward / dgrad kernel.  256 threads = 4 waves; tile = CO_TILE rows x (128*NPB) logical pixels;
+// wave w owns pixels [32*NPB*w, +32*NPB) (NPB 32-pixel MFMA column blocks) for all CO_BLKS row blocks.
+// ------------------------------------------------------------------------------------------
+template <bool X3, int CO_BLKS, bool CLAMP, int NPB>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p, const int x_cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int CO_TILE = 32 * CO_BLKS;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+
+  // XCD-aware block order: blocks that share an XCD (bid % 8) walk adjacent tiles, and the
+  // co-tiles of one pixel tile are adjacent, so the haloed input tile is fetched once per L2.
+  const unsigned bid = blockIdx.x, nwg = gridDim.x;
+  const unsigned xcd = bid & 7, q = nwg >> 3, rem = nwg & 7;
+  const unsigned L = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+  const int cot = L % p.n_co_tiles;
+  const int pt = L / p.n_co_tiles;
+  const int txi = pt % p.tiles_x;
+  const int tmp = pt / p.tiles_x;
+  const int tyi = tmp % p.tiles_y;
+  const int n = tmp / p.tiles_y;
+  const int TW = p.tw, TH = p.th, TPIX = TW * TH;
+  const int y0 = tyi * TH, x0 = txi * TW;
+
+  int oy0 = y0 * p.in_step + p.dy_min, ox0 = x0 * p.in_step + p.dx_min;
+  int th = p.ih_t, tw = p.iw_t;
+  if (CLAMP) {
+    const int y1 = min(oy0 + th, p.in_h), x1 = min(ox0 + tw, p.in_w);
+    oy0 = max(oy0, 0); ox0 = max(ox0, 0);
+    th = max(y1 - oy0, 0); tw = max(x1 - ox0, 0);
+  }
+  const int npix = th * tw;
+
+  unsigned char* Xhi = smem;
+  unsigned char* Xlo = smem + (size_t)x_cap * IG_REC_BYTES;
+  unsigned char* Whi = smem + (size_t)(X3 ? 2 : 1) * x_cap * IG_REC_BYTES;
+  unsigned char* Wlo = Whi + (size_t)p.tg * CO_TILE * IG_REC_BYTES;
+
+  // per-lane pixel of each MFMA column block
+  int pty[NPB], ptx[NPB], bbase[NPB];
+  bool pvalid[NPB];
+#pragma unroll
+  for (int pb = 0; pb < NPB; ++pb) {
+    const int plr = w * (32 * NPB) + pb * 32 + r;
+    pvalid[pb] = plr < TPIX;
+    const int pl = min(plr, TPIX - 1);          // idle slots of a non-power-of-two tile read a valid pixel
+    pty[pb] = IG_TY(pl, p.tmagic);
+    ptx[pb] = pl - pty[pb] * TW;
+    bbase[pb] = ((pty[pb] * p.in_step) * tw + ptx[pb] * p.in_step) * IG_REC_BYTES + h * 16;
+  }
+
+  f32x16 acc[CO_BLKS][NPB];
+#pragma unroll
+  for (int cb = 0; cb < CO_BLKS; ++cb)
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[cb][pb][i] = 0.f;
+
+  for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+    const int cvalid = min(32, p.cin - chunk * 32);
+    const int nks = cvalid > 16 ? 2 : 1;
+    __syncthreads();   // every wave is done reading the previous chunk's X / W
+    if (!(p.dbg & 1))
+      stage_x_chunk<X3>(Xhi, Xlo, p.x, n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row, oy0, ox0, th, tw,
+                        (cvalid + 7) >> 3, nks * 2, tid);
+    if (CLAMP && tid < 5) {   // the all-zero record that out-of-image taps read
+      *(uint4*)(Xhi + (size_t)npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
+      if (X3) *(uint4*)(Xlo + (size_t)npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
+    }
+    for (int t0 = 0; t0 < p.ntaps; t0 += p.tg) {
+      if (t0 > 0) __syncthreads();
+      const int tgc = min(p.tg, p.ntaps - t0);
+      {
+        const long long slab = (long long)CO_TILE * IG_REC;   // bf16 elements per tap
+        const uint16_t* src = p.wpack + (((long long)cot * p.nchunks + chunk) * p.ntaps + t0) * slab;
+        const int nvec = tgc * CO_TILE * 5;                  // 16-B vectors
+        if (!(p.dbg & 8)) {
+          wcopy<X3, 2>(Whi, Wlo, (const uint4*)src, (const uint4*)(src + p.w_lo_off), nvec, 0, tid);
+        }
+      }
+      __syncthreads();
+      for (int tl = 0; tl < ((p.dbg & 2) ? 0 : tgc); ++tl) {
+        const int t = t0 + tl;
+        int baddr[NPB];
+        if (CLAMP) {
+#pragma unroll
+          for (int pb = 0; pb < NPB; ++pb) {
+            const int gy = (y0 + pty[pb]) * p.in_step + p.dy[t];
+            const int gx = (x0 + ptx[pb]) * p.in_step + p.dx[t];
+            const bool ok = ((unsigned)gy < (unsigned)p.in_h) & ((unsigned)gx < (unsigned)p.in_w);
+            const int idx = ok ? (gy - oy0) * tw + (gx - ox0) : npix;
+            baddr[pb] = idx * IG_REC_BYTES + h * 16;
+          }
+        } else {
+          const int toff = ((p.dy[t] - p.dy_min) * tw + (p.dx[t] - p.dx_min)) * IG_REC_BYTES;
+#pragma unroll
+          for (int pb = 0; pb < NPB; ++pb) baddr[pb] = bbase[pb] + toff;
+        }
+        const int abase = (tl * CO_TILE + r) * IG_REC_BYTES + h * 16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          if (ks < nks) {
+            bf16x8 ah[CO_BLKS], al[CO_BLKS], bh[NPB], bl[NPB];
+#pragma unroll
+            for (int cb = 0; cb < CO_BLKS; ++cb) {
+              ah[cb] = lds_frag(Whi + abase + cb * 32 * IG_REC_BYTES + ks * 32);
+              if (X3) al[cb] = lds_frag(Wlo + abase + cb * 32 * IG_REC_BYTES + ks * 32);
+            }
+#pragma unroll
+            for (int pb = 0; pb < NPB; ++pb) {
+              bh[pb] = lds_frag(Xhi + baddr[pb] + ks * 32);
+              if (X3) bl[pb] = lds_frag(Xlo + baddr[pb] + ks * 32);
+            }
+#pragma unroll
+            for (int cb = 0; cb < CO_BLKS; ++cb)
+#pragma unroll
+              for (int pb = 0; pb < NPB; ++pb) {
+                if (X3) {
+                  acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cb], bh[pb], acc[cb][pb], 0, 0, 0);
+                  acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb], bl[pb], acc[cb][pb], 0, 0, 0);
+                }
+                acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb], bh[pb], acc[cb][pb], 0, 0, 0);
+              }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: bias + LeakyReLU, NCHW store (register i = one output channel, the 32 lanes of
+  // a half-wave = 32 consecutive pixels), optional per-tile BatchNorm partial sums.
+  __syncthreads();
+  if (p.dbg & 4) {
+    if (acc[0][0][0] == 123.456f) p.y.p1[0] = 1.f;   // keep the accumulators live
+    return;
+  }
+  float* sred = (float*)smem;   // [4 waves][CO_TILE][2]
+  // per-lane output pixel offsets (elements within a plane), computed once
+  int poff[NPB];
+  bool pok[NPB];
+#pragma unroll
+  for (int pb = 0; pb < NPB; ++pb) {
+    const int ly = y0 + pty[pb], lx = x0 + ptx[pb];
+    pok[pb] = pvalid[pb] & (ly < p.lh) & (lx < p.lw);
+    poff[pb] = (ly * p.oy_mul + p.oy_off) * p.out_w + (lx * p.ox_mul + p.ox_off);
+  }
+  const int co0 = cot * CO_TILE;
+  // fast path: the two half-waves (rows r0 and r0+4) of every register land in the same destination
+  // tensor -> the plane base of row r0 is wave-uniform (SGPR) and lanes add a 32-bit offset
+  const bool uni = (p.y.c1 >= p.cout) | ((p.y.c1 & 7) == 0);
+  float* const yb1 = p.y.p1 + (long long)n * p.y.sn1;
+  float* const yb2 = p.y.p2 + (long long)n * p.y.sn2;
+#pragma unroll
+  for (int cb = 0; cb < CO_BLKS; ++cb) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row0 = cb * 32 + (i & 3) + 8 * (i >> 2);   // wave-uniform
+      const int row = row0 + 4 * h;
+      const int co = co0 + row;
+      const bool cok = co < p.cout;
+      const float b = (cok && p.bias) ? p.bias[co] : 0.f;
+      float* plane;
+      if (uni) {
+        const int cu = min(co0 + row0, p.cout - 1);
+        float* base = (cu < p.y.c1) ? yb1 + (long long)cu * p.y.sc1 : yb2 + (long long)(cu - p.y.c1) * p.y.sc2;
+        const long long hs = (cu < p.y.c1) ? p.y.sc1 : p.y.sc2;
+        plane = base + (h ? 4 * hs : 0);
+      } else {
+        const int cc = min(co, p.cout - 1);
+        plane = (cc < p.y.c1) ? yb1 + (long long)cc * p.y.sc1 : yb2 + (long long)(cc - p.y.c1) * p.y.sc2;
+      }
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int pb = 0; pb < NPB; ++pb) {
+        float v = acc[cb][pb][i] + b;
+        v = v > 0.f ? v : v * p.slope;
+        float* dst = plane + poff[pb];
+        if (cok & pok[pb]) {
+          if (p.accumulate) v += *dst;
+          *dst = v;
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+      if (p.stats) {
+        s1 = half_wave_sum(s1);
+        s2 = half_wave_sum(s2);
+        if (r == 0) {
+          sred[(w * CO_TILE + row) * 2 + 0] = s1;
+          sred[(w * CO_TILE + row) * 2 + 1] = s2;
+        }
+      }
+    }
+  }
+  if (p.stats) {
+    __syncthreads();
+    if (tid < CO_TILE) {
+      const int co = cot * CO_TILE + tid;
+      if (co < p.cout) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {   // fixed order: deterministic
+          s1 += sred[(ww * CO_TILE + tid) * 2 + 0];
+          s2 += sred[(ww * CO_TILE + tid) * 2 + 1];
+        }
+        p.stats[((long long)pt * p.cout + co) * 2 + 0] = s1;
+        p.stats[((long long)pt * p.cout + co) * 2 + 1] = s2;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Persistent, software-pipelined forward / dgrad kernel (the default).  Same tiling as igemm_kernel,
+// but a workgroup walks a strided list of (tile, 32-channel chunk) stages and keeps the NEXT stage's
+// input loads in flight (32*PF dwords per lane, in registers) while the current stage copies its
+// weights, runs its MFMAs and stores its outputs.  With only 1-2 workgroups per CU (LDS-limited) the
+// unpipelined kernel left HBM idle during compute and the matrix cores idle during staging.
+// ------------------------------------------------------------------------------------------
+struct TileGeom {
+  int cot, pt, n, y0, x0, oy0, ox0, th, tw, npix;
+};
+
+template <bool CLAMP, int NPB>
+__device__ __forceinline__ TileGeom tile_decode(const IgemmParams& p, int L) {
+  TileGeom g;
+  g.cot = L % p.n_co_tiles;
+  g.pt = L / p.n_co_tiles;
+  const int txi = g.pt % p.tiles_x;
+  const int tmp = g.pt / p.tiles_x;
+  const int tyi = tmp % p.tiles_y;
+  g.n = tmp / p.tiles_y;
+  const int TW = p.tw, TH = p.th;
+  g.y0 = tyi * TH; g.x0 = txi * TW;
+  g.oy0 = g.y0 * p.in_step + p.dy_min; g.ox0 = g.x0 * p.in_step + p.dx_min;
+  g.th = p.ih_t; g.tw = p.iw_t;
+  if (CLAMP) {
+    const int y1 = min(g.oy0 + g.th, p.in_h), x1 = min(g.ox0 + g.tw, p.in_w);
+    g.oy0 = max(g.oy0, 0); g.ox0 = max(g.ox0, 0);
+    g.th = max(y1 - g.oy0, 0); g.tw = max(x1 - g.ox0, 0);
+  }
+  g.npix = g.th * g.tw;
+  return g;
+}
+
+// PCUDA_DBG bit 128: per-phase cycle sums of wave 0 of every workgroup (timing experiments only)
+#define DBG_CLK(i)                                                                  \
+  __builtin_amdgcn_sched_barrier(0);                                                \
+  if (p.dbg & 128) {                                                                \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                              \
+    const unsigned long long now_ = __builtin_readcyclecounter();                   \
+    clk[i] += now_ - tlast; tlast = now_;                                           \
+  }                                                                                 \
+  __builtin_amdgcn_sched_barrier(0);
+// same, after forcing the accumulators (the MFMAs issued so far) to complete
+#define DBG_CLK_ACC(i)                                                              \
+  __builtin_amdgcn_sched_barrier(0);                                                \
+  if (p.dbg & 128) {                                                                \
+    asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[CO_BLKS - 1][NPB - 1][15]));  \
+    const unsigned long long now_ = __builtin_readcyclecounter();                   \
+    clk[i] += now_ - tlast; tlast = now_;                                           \
+  }                                                                                 \
+  __builtin_amdgcn_sched_barrier(0);
+
+// WV = weight-copy register slots per lane and plane.  WV = 2: weight groups of <= 512 vectors, two
+// workgroups per CU.  WV = 6 / 12 (CO_TILE 32 / 64): ONE workgroup per CU with up to nine taps of weights
+// resident (512 VGPRs per lane: the whole group sits in registers between its loads and its LDS
+// write) -- a stage then has one weight round trip, issued in front of the X prefetch, and no barrier
+// inside its MFMA phase.
+template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV>
+__global__ __launch_bounds__(256, (WV > 3 ? 1 : 2)) void igemm_pipe_kernel(const IgemmParams p, const int x_cap, const int total) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int CO_TILE = 32 * CO_BLKS;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int TW = p.tw, TPIX = p.tw * p.th;
+
+  // XCD-aware persistent schedule: the 8 XCDs own contiguous eighths of the (pixel tile, co tile) list;
+  // the workgroups of one XCD (blockIdx % 8) interleave over it, so concurrent workgroups touch
+  // adjacent tiles (shared halo rows and weights hit that XCD's L2).
+  const int nx = min(8, (int)gridDim.x);                          // XCD groups that actually have workgroups
+  const int xcd = blockIdx.x % nx, slot = blockIdx.x / nx;
+  const int gx = ((int)gridDim.x - xcd + nx - 1) / nx;            // workgroups in this group
+  const int lo = (int)((long long)total * xcd / nx), hi = (int)((long long)total * (xcd + 1) / nx);
+
+  unsigned char* Xhi = smem;
+  unsigned char* Xlo = smem + (size_t)x_cap * IG_REC_BYTES;
+  unsigned char* Whi = smem + (size_t)(X3 ? 2 : 1) * x_cap * IG_REC_BYTES;
+  unsigned char* Wlo = Whi + (size_t)p.tg * CO_TILE * IG_REC_BYTES;
+  int* taptab = (int*)(Whi + (size_t)(X3 ? 2 : 1) * p.tg * CO_TILE * IG_REC_BYTES);   // [ntaps], behind the weight slabs
+  float* sbias = (float*)(taptab + 64);   // [CO_TILE] bias of the tile being finished (host adds 512 B in all)
+  float* sred = (float*)smem;   // [4 waves][CO_TILE][2], reused between a tile's last MFMA and the next commit
+
+  // per-tap LDS offset (or packed dy/dx in clamp mode), read back with one broadcast ds_read per tap:
+  // indexing the signed-char tables of the kernel argument compiled to two global loads per tap, and
+  // waiting for those (vmcnt is in order) drained the whole X prefetch at the first tap of every stage
+  for (int t = 0; t < p.ntaps; ++t) {   // uniform index: a per-lane index would copy the tables to scratch
+    const int dy = p.dy[t], dx = p.dx[t];
+    if (tid == 0)
+      taptab[t] = CLAMP ? ((dy & 0xffff) | (dx << 16)) : ((dy - p.dy_min) * p.iw_t + (dx - p.dx_min)) * IG_REC_BYTES;
+  }
+
+  int pty[NPB], ptx[NPB];
+  bool pvalid[NPB];
+#pragma unroll
+  for (int pb = 0; pb < NPB; ++pb) {
+    const int plr = w * (32 * NPB) + pb * 32 + r;
+    pvalid[pb] = plr < TPIX;
+    const int pl = min(plr, TPIX - 1);
+    pty[pb] = IG_TY(pl, p.tmagic);
+    ptx[pb] = pl - pty[pb] * TW;
+  }
+
+  f32x16 acc[CO_BLKS][NPB];
+  XFast<PF> pre;
+  unsigned long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+
+  int L = lo + slot, chunk = 0;
+  bool have = L < hi;
+  TileGeom g;
+  if (have) {
+    g = tile_decode<CLAMP, NPB>(p, L);
+    if (p.xq) xq_issue<PF>(pre, p.x, g.n, p.cin, 0, p.in_h, p.in_w, g.oy0, g.ox0, g.th, g.tw, tid);
+    else xfast_issue<PF>(pre, p.x, g.n, p.cin, 0, p.in_h, p.in_w, p.in_shift, p.in_row, g.oy0, g.ox0, g.tw, g.npix,
+                         (min(32, p.cin) + 7) >> 3, tid);
+  }
+  while (have) {
+    const int cvalid = min(32, p.cin - chunk * 32);
+    const int nks = cvalid > 16 ? 2 : 1;
+    DBG_CLK(7)
+    __syncthreads();   // every wave is done with the previous stage's X / W / reduction scratch
+    DBG_CLK(0)
+    if (p.xq) xq_commit<X3, PF>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.ox0, g.th, g.tw, nks * 2, tid);
+    else xfast_commit<X3, PF>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.npix, (cvalid + 7) >> 3, nks * 2, tid);
+    DBG_CLK(1)
+    if (CLAMP && tid < 5) {
+      *(uint4*)(Xhi + (size_t)g.npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
+      if (X3) *(uint4*)(Xlo + (size_t)g.npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
+    }
+    // bias of this tile's rows (consumed by the epilogue after the last chunk): fetched here, in front of the
+    // stage's other loads, so its wait never drains them
+    float bias_r = 0.f;
+    if (chunk == p.nchunks - 1 && p.bias && tid < CO_TILE) bias_r = p.bias[min(g.cot * CO_TILE + tid, p.cout - 1)];
+    // first weight group: its loads go out BEFORE the next stage's input prefetch (vmcnt retires in order:
+    // behind the prefetch they would not be usable until all of it has landed)
+    const long long slab = (long long)CO_TILE * IG_REC;
+    const uint16_t* wsrc = p.wpack + ((long long)g.cot * p.nchunks + chunk) * p.ntaps * slab;
+    WPass<X3, WV> wp0;
+    const int nvec0 = min(p.tg, p.ntaps) * CO_TILE * 5;
+    wcopy_issue<X3, WV>(wp0, (const uint4*)wsrc, (const uint4*)(wsrc + p.w_lo_off), nvec0, 0, tid);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // next stage: its loads stay in flight through everything below
+    int nL = L, nchunk = chunk + 1;
+    if (nchunk == p.nchunks) { nchunk = 0; nL = L + gx; }
+    const bool nhave = nL < hi;
+    TileGeom ng = g;
+    if (nhave && nL != L) ng = tile_decode<CLAMP, NPB>(p, nL);
+    // unconditional (no stage left: zero pixels, every lane out of range -> no memory traffic)
+    if (p.xq) xq_issue<PF>(pre, p.x, ng.n, p.cin, nhave ? nchunk : 0, p.in_h, p.in_w, ng.oy0, ng.ox0, nhave ? ng.th : 0,
+                           ng.tw, tid);
+    else xfast_issue<PF>(pre, p.x, ng.n, p.cin, nhave ? nchunk : 0, p.in_h, p.in_w, p.in_shift, p.in_row, ng.oy0, ng.ox0,
+                         ng.tw, nhave ? ng.npix : 0, 4, tid);
+    DBG_CLK(2)
+
+    if (chunk == 0) {
+#pragma unroll
+      for (int cb = 0; cb < CO_BLKS; ++cb)
+#pragma unroll
+        for (int pb = 0; pb < NPB; ++pb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[cb][pb][i] = 0.f;
+    }
+    int bbase[NPB];
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb)
+      bbase[pb] = ((pty[pb] * p.in_step) * g.tw + ptx[pb] * p.in_step) * IG_REC_BYTES + h * 16;
+
+    // weight groups of p.tg taps (<= 256*WV vectors per plane: one copy pass)
+    wcopy_commit<X3, WV>(wp0, Whi, Wlo, nvec0, 0, tid);
+    DBG_CLK(3)
+    __syncthreads();
+    DBG_CLK(4)
+    for (int t0 = 0; t0 < p.ntaps; t0 += p.tg) {
+      const int tgc = min(p.tg, p.ntaps - t0);
+      if (t0 > 0) {   // later groups (more taps than fit): loaded behind the X prefetch, latency exposed
+        __syncthreads();
+        const uint16_t* src = wsrc + (long long)t0 * slab;
+        wcopy<X3, WV>(Whi, Wlo, (const uint4*)src, (const uint4*)(src + p.w_lo_off), tgc * CO_TILE * 5, 0, tid);
+        DBG_CLK(3)
+        __syncthreads();
+        DBG_CLK(4)
+      }
+      const unsigned char* Wh = Whi;
+      const unsigned char* Wl = Wlo;
+      int tv = taptab[t0];
+      for (int tl = 0; tl < tgc; ++tl) {
+        const int tcur = tv;
+        tv = taptab[min(t0 + tl + 1, p.ntaps - 1)];   // next tap's entry: its LDS latency hides behind this tap
+        int baddr[NPB];
+        if (CLAMP) {
+          const int dy = (tcur << 16) >> 16, dx = tcur >> 16;
+#pragma unroll
+          for (int pb = 0; pb < NPB; ++pb) {
+            const int gy = (g.y0 + pty[pb]) * p.in_step + dy;
+            const int gxx = (g.x0 + ptx[pb]) * p.in_step + dx;
+            const bool ok = ((unsigned)gy < (unsigned)p.in_h) & ((unsigned)gxx < (unsigned)p.in_w);
+            const int idx = ok ? (gy - g.oy0) * g.tw + (gxx - g.ox0) : g.npix;
+            baddr[pb] = idx * IG_REC_BYTES + h * 16;
+          }
+        } else {
+#pragma unroll
+          for (int pb = 0; pb < NPB; ++pb) baddr[pb] = bbase[pb] + tcur;
+        }
+        const int abase = (tl * CO_TILE + r) * IG_REC_BYTES + h * 16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          if (ks < nks) {
+            bf16x8 ah[CO_BLKS], al[CO_BLKS], bh[NPB], bl[NPB];
+#pragma unroll
+            for (int cb = 0; cb < CO_BLKS; ++cb) {
+              ah[cb] = lds_frag(Wh + abase + cb * 32 * IG_REC_BYTES + ks * 32);
+              if (X3) al[cb] = lds_frag(Wl + abase + cb * 32 * IG_REC_BYTES + ks * 32);
+            }
+#pragma unroll
+            for (int pb = 0; pb < NPB; ++pb) {
+              bh[pb] = lds_frag(Xhi + baddr[pb] + ks * 32);
+              if (X3) bl[pb] = lds_frag(Xlo + baddr[pb] + ks * 32);
+            }
+#pragma unroll
+            for (int cb = 0; cb < CO_BLKS; ++cb)
+#pragma unroll
+              for (int pb = 0; pb < NPB; ++pb) {
+                if (X3) {
+                  acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cb], bh[pb], acc[cb][pb], 0, 0, 0);
+                  acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb], bl[pb], acc[cb][pb], 0, 0, 0);
+                }
+                acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb], bh[pb], acc[cb][pb], 0, 0, 0);
+              }
+          }
+        }
+      }
+      DBG_CLK_ACC(5)
+    }
+
+    DBG_CLK(6)
+    if (chunk == p.nchunks - 1) {
+      // ---- epilogue of this tile.  No flat global access in here: a lane-indexed bias load in front of every
+      // store made each store wait (vmcnt(0), in order) for the previous one AND for the whole X prefetch.
+      // Bias comes through LDS (fetched at the top of the stage), stores go through buffer resources:
+      // 32-bit offsets, rows past cout / pixels outside the output dropped by the range check.
+      const int co0 = g.cot * CO_TILE;
+      if (tid < CO_TILE) sbias[tid] = bias_r;
+      __syncthreads();   // sbias visible; sred aliases the X tile: every wave's last fragment reads are done
+      unsigned pixo[NPB];
+      bool pok[NPB];
+#pragma unroll
+      for (int pb = 0; pb < NPB; ++pb) {
+        const int ly = g.y0 + pty[pb], lx = g.x0 + ptx[pb];
+        pok[pb] = pvalid[pb] & (ly < p.lh) & (lx < p.lw);
+        pixo[pb] = pok[pb] ? (unsigned)((ly * p.oy_mul + p.oy_off) * p.out_w + (lx * p.ox_mul + p.ox_off)) * 4u : IG_OOB;
+      }
+      const int c1 = min(p.y.c1, p.cout);
+      float* const yb1 = p.y.p1 + (long long)g.n * p.y.sn1;
+      float* const yb2 = p.y.p2 + (long long)g.n * p.y.sn2;
+      const unsigned pl1 = (unsigned)p.y.sc1 * 4u, pl2 = (unsigned)p.y.sc2 * 4u;
+#pragma unroll
+      for (int cb = 0; cb < CO_BLKS; ++cb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row0 = cb * 32 + (i & 3) + 8 * (i >> 2);   // this register's row for h = 0; h = 1 is 4 rows on
+          const int row = row0 + 4 * h;
+          const int cu = co0 + row0;                            // uniform; rows cu and cu + 4 lie in one destination
+          const bool first = cu < c1;
+          const unsigned plane = first ? pl1 : pl2;
+          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+              (void*)(first ? yb1 : yb2), 0, (int)((first ? c1 : p.cout - c1) * plane), 0x00020000);
+          const unsigned soff = (unsigned)(first ? cu : cu - c1) * plane;
+          const unsigned hoff = h ? 4u * plane : 0u;
+          const float b = sbias[row];
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int pb = 0; pb < NPB; ++pb) {
+            float v = acc[cb][pb][i] + b;
+            v = v > 0.f ? v : v * p.slope;
+            const unsigned vo = pixo[pb] + hoff;
+            if (p.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, soff, 0));
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, vo, soff, 0);
+            if (p.stats) {
+              const float vs = (pok[pb] & (co0 + row < p.cout)) ? v : 0.f;
+              s1 += vs;
+              s2 += vs * vs;
+            }
+          }
+          if (p.stats) {
+            s1 = half_wave_sum_hi16(s1);
+            s2 = half_wave_sum_hi16(s2);
+            if (r == 31) {
+              sred[(w * CO_TILE + row) * 2 + 0] = s1;
+              sred[(w * CO_TILE + row) * 2 + 1] = s2;
+            }
+          }
+        }
+      }
+      if (p.stats) {
+        __syncthreads();
+        if (tid < CO_TILE) {
+          const int co = g.cot * CO_TILE + tid;
+          if (co < p.cout) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) {
+              s1 += sred[(ww * CO_TILE + tid) * 2 + 0];
+              s2 += sred[(ww * CO_TILE + tid) * 2 + 1];
+            }
+            p.stats[((long long)g.pt * p.cout + co) * 2 + 0] = s1;
+            p.stats[((long long)g.pt * p.cout + co) * 2 + 1] = s2;
+          }
+        }
+      }
+    }
+    DBG_CLK(6)
+    L = nL; chunk = nchunk; g = ng; have = nhave;
+  }
+  if ((p.dbg & 128) && p.dbg_clk && tid == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(&p.dbg_clk[i], clk[i]);
+  }
+}
+
+
+
+
+template <bool X3, int CO_BLKS, bool CLAMP, int NPB>
+static int launch_igemm_t(const IgemmParams& p, int x_cap, size_t lds, hipStream_t s) {
+  auto kern = igemm_kernel<X3, CO_BLKS, CLAMP, NPB>;
+  static size_t lds_set = 0;
+  if (lds > 32 * 1024 && lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HARD);
+    if (e != hipSuccess) PCUDA_FAIL(PCUDA_E_LAUNCH, "igemm: cannot raise dynamic LDS to %d: %s", LDS_HARD, hipGetErrorString(e));
+    lds_set = LDS_HARD;
+  }
+  const int grid = p.n_co_tiles * p.n * p.tiles_x * p.tiles_y;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, p, x_cap);
+  PCUDA_CHECK_LAUNCH("igemm_kernel");
+  return PCUDA_OK;
+}
+
+template <bool X3, int CO_BLKS>
+static int launch_igemm_c(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
+  if (pl.clamp) return pl.npb == 2 ? launch_igemm_t<X3, CO_BLKS, true, 2>(p, pl.x_cap, pl.lds, s)
+                                   : launch_igemm_t<X3, CO_BLKS, true, 1>(p, pl.x_cap, pl.lds, s);
+  return pl.npb == 2 ? launch_igemm_t<X3, CO_BLKS, false, 2>(p, pl.x_cap, pl.lds, s)
+                     : launch_igemm_t<X3, CO_BLKS, false, 1>(p, pl.x_cap, pl.lds, s);
+}
+
+template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV>
+static int launch_pipe_t(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
+  auto kern = igemm_pipe_kernel<X3, CO_BLKS, CLAMP, NPB, PF, WV>;
+  static size_t lds_set = 0;
+  if (pl.lds > 32 * 1024 && pl.lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HARD);
+    if (e != hipSuccess) PCUDA_FAIL(PCUDA_E_LAUNCH, "igemm_pipe: cannot raise dynamic LDS: %s", hipGetErrorString(e));
+    lds_set = LDS_HARD;
+  }
+  const int total = p.n_co_tiles * p.n * p.tiles_x * p.tiles_y;
+  // persistent grid = what is resident at once (registers and LDS both limit it)
+  static int occ_cache[4] = {0, 0, 0, 0};   // by LDS class: <=53K, <=80K, <=160K
+  const int cls = pl.lds <= 54528 ? 0 : (pl.lds <= 81920 ? 1 : 2);
+  if (occ_cache[cls] == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, pl.lds) != hipSuccess || nb < 1) nb = 1;
+    const int lds_lim = (int)((size_t)LDS_HARD / pl.lds);
+    if (nb > lds_lim) nb = lds_lim;
+    if (nb > 4) nb = 4;
+    if (nb < 1) nb = 1;
+    occ_cache[cls] = nb;
+  }
+  int grid = occ_cache[cls] * 256;
+  if (grid > total) grid = total;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), pl.lds, s, p, pl.x_cap, total);
+  PCUDA_CHECK_LAUNCH("igemm_pipe_kernel");
+  return PCUDA_OK;
+}
+
+template <bool X3, int CO_BLKS, bool CLAMP, int NPB>
+static int launch_pipe_pf(const IgemmParams& p, const IgemmPlan& pl, int pf, hipStream_t s) {
+  constexpr int WVF = CO_BLKS == 2 ? 12 : 6;
+  if (pl.fat) {
+    if (pf == 1) return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 1, WVF>(p, pl, s);
+    if (pf == 2) return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 2, WVF>(p, pl, s);
+    return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 3, WVF>(p, pl, s);
+  }
+  if (pf == 1) return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 1, 3>(p, pl, s);
+  if (pf == 2) return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 2, 3>(p, pl, s);
+  return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 3, 3>(p, pl, s);
+}
+
+template <bool X3, int CO_BLKS>
+static int launch_pipe_c(const IgemmParams& p, const IgemmPlan& pl, int pf, hipStream_t s) {
+  if (pl.clamp) return pl.npb == 2 ? launch_pipe_pf<X3, CO_BLKS, true, 2>(p, pl, pf, s)
+                                   : launch_pipe_pf<X3, CO_BLKS, true, 1>(p, pl, pf, s);
+  return pl.npb == 2 ? launch_pipe_pf<X3, CO_BLKS, false, 2>(p, pl, pf, s)
+                     : launch_pipe_pf<X3, CO_BLKS, false, 1>(p, pl, pf, s);
+}
+
+
+template <bool X3>
+static int igemm_dispatch(const IgemmParams& p, const IgemmPlan& pl, int co_blks, int pf, bool pipe, hipStream_t s) {
+  if (pipe) return co_blks == 2 ? launch_pipe_c<X3, 2>(p, pl, pf, s) : launch_pipe_c<X3, 1>(p, pl, pf, s);
+  return co_blks == 2 ? launch_igemm_c<X3, 2>(p, pl, s) : launch_igemm_c<X3, 1>(p, pl, s);
+}

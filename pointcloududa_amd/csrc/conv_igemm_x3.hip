@@ -1,0 +1,6 @@
+// bf16x3 (parity mode) instantiations of the forward / dgrad kernels.
+#include "conv_igemm_impl.h"
+
+int igemm_dispatch_x3(const IgemmParams& p, const IgemmPlan& pl, int co_blks, int pf, bool pipe, hipStream_t s) {
+  return igemm_dispatch<true>(p, pl, co_blks, pf, pipe, s);
+}

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256, ((TAPS_MAX <= 9 && PF <= 1) ? 2 : 1)) void wgr
     zpre_commit<X3, CO_TILE>(zv, p, cur, cot, tid, Zhi, Zlo, do_db, dbacc, false);
     __syncthreads();
     WTile nxt = cur;
-    if (PF > 0 && tile + 1 < tile_hi) {
+    if (PF > 0 && tile + 1 < tile_hi) {   // (the block's last tile skips the loads altogether)
       nxt = wtile_decode<CLAMP>(p, tile + 1);
       xfast_issue<XPF>(xpre, p.x, nxt.n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row, nxt.oy0, nxt.ox0, nxt.tw,
                        nxt.npix, ngroups, tid);
