@@ -146,7 +146,7 @@ struct XFast {
 };
 
 // issue: npix halo pixels x (8*ngroups) channels of chunk `chunk`, image n; values stay in registers
-template <int PF>
+template <int PF, int NT = 256>
 __device__ __forceinline__ void xfast_issue(XFast<PF>& pre, const pcuda_src& x, int n, int cin, int chunk, int in_h,
                                             int in_w, int in_shift, int in_row, int oy0, int ox0, int tw, int npix,
                                             int ngroups, int tid) {
@@ -160,7 +160,7 @@ __device__ __forceinline__ void xfast_issue(XFast<PF>& pre, const pcuda_src& x, 
   unsigned voff[PF];
 #pragma unroll
   for (int s = 0; s < PF; ++s) {
-    const int pix = tid + s * 256;
+    const int pix = tid + s * NT;
     const int iy = pix / tw, ix = pix - iy * tw;
     const int gy = oy0 + iy, gx = ox0 + ix;
     pre.inb[s] = (pix < npix) & ((unsigned)gy < (unsigned)in_h) & ((unsigned)gx < (unsigned)in_w);
@@ -179,7 +179,7 @@ __device__ __forceinline__ void xfast_issue(XFast<PF>& pre, const pcuda_src& x, 
 }
 
 // commit: lazy-BatchNorm affine (if the source has one), bf16 hi/lo split, LDS write
-template <bool X3, int PF>
+template <bool X3, int PF, int NT = 256>
 __device__ __forceinline__ void xfast_commit(XFast<PF>& pre, unsigned char* __restrict__ xhi,
                                              unsigned char* __restrict__ xlo, const pcuda_src& x, int cin, int chunk,
                                              int npix, int ngroups, int nwrite, int tid) {
@@ -194,9 +194,9 @@ __device__ __forceinline__ void xfast_commit(XFast<PF>& pre, unsigned char* __re
     if (g >= ngroups && g < nwrite) {   // channels past cin inside a 16-wide k-step: zeros, not LDS garbage
 #pragma unroll
       for (int s = 0; s < PF; ++s)
-        if (tid + s * 256 < npix) {
-          *(uint4*)(xhi + (size_t)(tid + s * 256) * IG_REC_BYTES + g * 16) = make_uint4(0, 0, 0, 0);
-          if (X3) *(uint4*)(xlo + (size_t)(tid + s * 256) * IG_REC_BYTES + g * 16) = make_uint4(0, 0, 0, 0);
+        if (tid + s * NT < npix) {
+          *(uint4*)(xhi + (size_t)(tid + s * NT) * IG_REC_BYTES + g * 16) = make_uint4(0, 0, 0, 0);
+          if (X3) *(uint4*)(xlo + (size_t)(tid + s * NT) * IG_REC_BYTES + g * 16) = make_uint4(0, 0, 0, 0);
         }
     }
     if (g < ngroups) {
@@ -224,11 +224,11 @@ __device__ __forceinline__ void xfast_commit(XFast<PF>& pre, unsigned char* __re
       }
 #pragma unroll
       for (int s = 0; s < PF; ++s)
-        if (tid + s * 256 < npix) {
+        if (tid + s * NT < npix) {
           float (&v)[32] = pre.v[s];
           const float vv[8] = {v[g * 8 + 0], v[g * 8 + 1], v[g * 8 + 2], v[g * 8 + 3],
                                v[g * 8 + 4], v[g * 8 + 5], v[g * 8 + 6], v[g * 8 + 7]};
-          stage_write<X3>(xhi, xlo, vv, tid + s * 256, g);
+          stage_write<X3>(xhi, xlo, vv, tid + s * NT, g);
         }
     }
   }
@@ -244,10 +244,12 @@ __device__ __forceinline__ void xfast_commit(XFast<PF>& pre, unsigned char* __re
 // outside it; `lead` = pixels of the first quad left of the tile.
 // ------------------------------------------------------------------------------------------
 // (register image shared with the dword path: v[s][4*j + e] = pixel e of the quad, channel j of the group)
-template <int PF>
+template <int PF, int NT = 256>
 __device__ __forceinline__ void xq_issue(XFast<PF>& pre, const pcuda_src& x, int n, int cin, int chunk, int in_h, int in_w,
                                          int oy0, int ox0, int th, int tw, int tid) {
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  // wave -> channel group (wv & 3); with 8 waves the two waves of a group split the (row, quad) items
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), w = wv & 3, lane = (tid & 63) + 64 * (wv >> 2);
+  constexpr int IS = NT / 4;   // items per slot and group
   const int c0 = chunk * 32;
   const bool first = c0 < x.c1;
   const float* base = first ? x.p1 + (long long)n * x.sn1 : x.p2 + (long long)n * x.sn2;
@@ -259,7 +261,7 @@ __device__ __forceinline__ void xq_issue(XFast<PF>& pre, const pcuda_src& x, int
   unsigned off[PF];
 #pragma unroll
   for (int s = 0; s < PF; ++s) {
-    const int item = lane + 64 * s;
+    const int item = lane + IS * s;
     const int iy = (item * qmagic) >> 16, q = item - iy * nq;
     const int gy = oy0 + iy, gx = ox0 - lead + 4 * q;
     pre.inb[s] = (item < nitems) & ((unsigned)gy < (unsigned)in_h) & ((unsigned)gx < (unsigned)in_w);
@@ -276,11 +278,13 @@ __device__ __forceinline__ void xq_issue(XFast<PF>& pre, const pcuda_src& x, int
   }
 }
 
-template <bool X3, int PF>
+template <bool X3, int PF, int NT = 256>
 __device__ __forceinline__ void xq_commit(XFast<PF>& pre, unsigned char* __restrict__ xhi, unsigned char* __restrict__ xlo,
                                           const pcuda_src& x, int cin, int chunk, int ox0, int th, int tw, int nwrite,
                                           int tid) {
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  // wave -> channel group (wv & 3); with 8 waves the two waves of a group split the (row, quad) items
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), w = wv & 3, lane = (tid & 63) + 64 * (wv >> 2);
+  constexpr int IS = NT / 4;   // items per slot and group
   if (w >= nwrite) return;   // channel groups past the k-steps this chunk runs
   const int c0 = chunk * 32;
   const bool first = c0 < x.c1;
@@ -300,7 +304,7 @@ __device__ __forceinline__ void xq_commit(XFast<PF>& pre, unsigned char* __restr
   }
 #pragma unroll
   for (int s = 0; s < PF; ++s) {
-    const int item = lane + 64 * s;
+    const int item = lane + IS * s;
     const int iy = (item * qmagic) >> 16, q = item - iy * nq;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -328,39 +332,42 @@ __device__ __forceinline__ void xq_commit(XFast<PF>& pre, unsigned char* __restr
 // Branch-free: lanes past the end re-copy the last vector (same bytes to the same address), so the
 // loads of a pass are issued back to back and no wait sits between them.  (With a guarded store the
 // compiler sank every load into its store's branch and waited vmcnt(0) after each one.)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// (native vectors, not HIP's uint4 struct: an array of those inside a struct stayed in scratch memory, every
+// load followed by a wait and a scratch store)
 template <bool X3, int WV>
 struct WPass {
-  uint4 hi[WV], lo[X3 ? WV : 1];
+  u32x4 hi[WV], lo[WV];
 };
-template <bool X3, int WV>
+template <bool X3, int WV, int NT = 256>
 __device__ __forceinline__ void wcopy_issue(WPass<X3, WV>& wp, const uint4* __restrict__ hi,
                                             const uint4* __restrict__ lo, int nvec, int base, int tid) {
 #pragma unroll
   for (int u = 0; u < WV; ++u) {
-    const int i = min(base + tid + u * 256, nvec - 1);
-    wp.hi[u] = hi[i];
-    if (X3) wp.lo[u] = lo[i];
+    const int i = min(base + tid + u * NT, nvec - 1);
+    wp.hi[u] = ((const u32x4*)hi)[i];
+    if (X3) wp.lo[u] = ((const u32x4*)lo)[i];
   }
 }
-template <bool X3, int WV>
+template <bool X3, int WV, int NT = 256>
 __device__ __forceinline__ void wcopy_commit(const WPass<X3, WV>& wp, unsigned char* __restrict__ dhi,
                                              unsigned char* __restrict__ dlo, int nvec, int base, int tid) {
 #pragma unroll
   for (int u = 0; u < WV; ++u) {
-    const int i = min(base + tid + u * 256, nvec - 1);
-    ((uint4*)dhi)[i] = wp.hi[u];
-    if (X3) ((uint4*)dlo)[i] = wp.lo[u];
+    const int i = min(base + tid + u * NT, nvec - 1);
+    ((u32x4*)dhi)[i] = wp.hi[u];
+    if (X3) ((u32x4*)dlo)[i] = wp.lo[u];
   }
 }
-template <bool X3, int WV>
+template <bool X3, int WV, int NT = 256>
 __device__ __forceinline__ void wcopy(unsigned char* __restrict__ dhi, unsigned char* __restrict__ dlo,
                                       const uint4* __restrict__ hi, const uint4* __restrict__ lo, int nvec, int base0,
                                       int tid) {
-  for (int base = base0; base < nvec; base += 256 * WV) {
+  for (int base = base0; base < nvec; base += NT * WV) {
     WPass<X3, WV> wp;
-    wcopy_issue<X3, WV>(wp, hi, lo, nvec, base, tid);
+    wcopy_issue<X3, WV, NT>(wp, hi, lo, nvec, base, tid);
     __builtin_amdgcn_sched_barrier(0);   // keep the pass's loads together (the scheduler, short of registers,
-    wcopy_commit<X3, WV>(wp, dhi, dlo, nvec, base, tid);   // otherwise emits load / wait / store one vector at a time)
+    wcopy_commit<X3, WV, NT>(wp, dhi, dlo, nvec, base, tid);   // otherwise emits load / wait / store one vector at a time)
     __builtin_amdgcn_sched_barrier(0);
   }
 }

@@ -123,5 +123,6 @@ struct IgemmPlan {
   int npb, tw, th, tiles_x, tiles_y, ih_t, iw_t, clamp, x_cap, tg;
   size_t lds;
   int fat;   // one workgroup per CU, every (or many) taps of weights resident
+  int w8;    // eight-wave kernel (one 512-thread workgroup per CU)
 };
 

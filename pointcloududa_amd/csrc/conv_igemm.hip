@@ -51,10 +51,17 @@ namespace {
 
 // PCUDA_FAT=1 plans one workgroup per CU with all taps resident (experimental: the weight stash spills)
 unsigned long long* g_dbg_clk_host = nullptr;
-bool ig_fat_mode() {
-  static int fat = -1;
-  if (fat < 0) { const char* e = getenv("PCUDA_FAT"); fat = e ? (atoi(e) ? 1 : 0) : 0; }
-  return fat != 0;
+// LDS / workgroup plan: 0 = two (or three) 256-thread workgroups per CU with small weight groups,
+// 1 (PCUDA_FAT=1, experimental) = one 256-thread workgroup with two alternating weight buffers,
+// 2 (default; PCUDA_W8=0 turns it off) = one 512-thread workgroup with every tap resident where it fits
+int ig_plan_mode() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* f = getenv("PCUDA_FAT");
+    const char* w = getenv("PCUDA_W8");
+    mode = (f && atoi(f)) ? 1 : ((w && !atoi(w)) ? 0 : 2);
+  }
+  return mode;
 }
 
 size_t packed_elems(int rows, int red, int ntaps) {   // bf16 elements of ONE plane (hi)
@@ -84,25 +91,27 @@ int launch_pack(const float* w, uint16_t* out, int prec, int rows, int red, long
 
 // pick taps-per-group and LDS size; returns <0 when nothing fits.  fat: one workgroup per CU (160 KiB),
 // as many taps resident as one 256*WV-vector copy pass holds.
-static inline int ig_wv(int co_tile, bool fat) { return fat ? (co_tile == 64 ? 12 : 6) : 3; }
-int plan_lds(bool x3, int co_tile, int x_cap, int ntaps, bool fat, int* tg_out, size_t* lds_out) {
+int plan_lds(bool x3, int co_tile, int x_cap, int ntaps, int mode, int* tg_out, size_t* lds_out) {
+  const bool fat = mode != 0;
   const size_t mul = x3 ? 2 : 1;
   const size_t xb = (size_t)x_cap * IG_REC_BYTES * mul;
   const size_t wtap = (size_t)co_tile * IG_REC_BYTES * mul;
   const size_t epi = 4 * (size_t)co_tile * 2 * sizeof(float);
   const size_t tab = 512;   // per-tap offset table + the epilogue's bias slice, behind the weight slabs
   if (ntaps < 1) ntaps = 1;
-  const int cap = ig_wv(co_tile, fat) * 256 / (co_tile * 5);   // one copy pass per group
+  // one copy pass per group: 3 / 5 slots x 256 lanes, or 6 slots x 512 lanes
+  const int cap = (mode == 2 ? 6 * 512 : (mode == 1 ? 5 * 256 : 3 * 256)) / (co_tile * 5);
   // budgets: 3, 2, 1 workgroups per CU (160 KiB LDS)
   const size_t budgets[3] = {54528, 81920, 163840};
   for (int b = fat ? 2 : 0; b < 3; ++b) {
     if (xb + tab >= budgets[b]) continue;
-    int fit = (int)((budgets[b] - xb - tab) / wtap);
+    const int nbuf = mode == 1 ? 2 : 1;   // mode 1: two alternating weight buffers
+    int fit = (int)((budgets[b] - xb - tab) / (nbuf * wtap));
     if (fit > cap) fit = cap;
     const int need = b == 0 ? (ntaps < 3 ? ntaps : 3) : 1;
     if (fit < need) continue;
     const int tg = fit > ntaps ? ntaps : fit;
-    size_t total = xb + (size_t)tg * wtap + tab;
+    size_t total = xb + (size_t)nbuf * tg * wtap + tab;
     if (total < epi) total = epi;
     *tg_out = tg; *lds_out = total;
     return 0;
@@ -114,10 +123,9 @@ int plan_lds(bool x3, int co_tile, int x_cap, int ntaps, bool fat, int* tg_out, 
 // tile shape / LDS plan of one generic launch: depends only on geometry, taps and precision.
 // Minimises the number of MFMA pixel slots (tiles x slots per tile); ties prefer 32-pixel-aligned rows
 // (128-B output segments), two pixel blocks per wave, wider tiles.
-int plan_igemm(int rows, int lh, int lw, int in_h, int in_w, int in_step, const TapSet& taps, bool x3,
-               IgemmPlan* best) {
+int plan_igemm_mode(int rows, int lh, int lw, int in_h, int in_w, int in_step, const TapSet& taps, bool x3,
+                    int mode_env, IgemmPlan* best) {
   const int co_tile = 32 * ig_co_blks(rows);
-  const bool fat = ig_fat_mode();
   long long best_key = -1;
   for (int npb = 2; npb >= 1; --npb) {
     const int TP = 128 * npb;
@@ -138,8 +146,16 @@ int plan_igemm(int rows, int lh, int lw, int in_h, int in_w, int in_step, const 
       for (int attempt = 0; attempt < 2 && !ok; ++attempt) {
         pl.clamp = attempt == 0 ? ((clipped * 2 <= full) ? 1 : 0) : 1;
         pl.x_cap = pl.clamp ? clipped : full;
-        pl.fat = fat ? 1 : 0;
-        ok = plan_lds(x3, co_tile, pl.x_cap, taps.n, fat, &pl.tg, &pl.lds) == 0;
+        // the eight-wave kernel needs 8 or 16 MFMA tiles per stage and an input tile of <= 2 slots per lane
+        int mode = mode_env;
+        if (mode == 2) {
+          const int ihc = pl.ih_t < in_h ? pl.ih_t : in_h;
+          const bool fits = pl.x_cap <= 1024 && ihc * ((pl.iw_t + 6) / 4) <= 256;
+          if (!fits || (npb == 1 && co_tile == 32)) mode = 0;
+        }
+        pl.fat = mode == 1 ? 1 : 0;
+        pl.w8 = mode == 2 ? 1 : 0;
+        ok = plan_lds(x3, co_tile, pl.x_cap, taps.n, mode, &pl.tg, &pl.lds) == 0;
         if (pl.clamp) break;
       }
       if (!ok) continue;
@@ -155,12 +171,32 @@ int plan_igemm(int rows, int lh, int lw, int in_h, int in_w, int in_step, const 
   return best_key < 0 ? -1 : 0;
 }
 
+// Per layer: the eight-wave kernel (mode 2) where the ordinary plan would leave a CU with one 256-thread
+// workgroup anyway (its LDS tile > 80 KiB: the stride-2 4x4 layers) or where there are not enough
+// (tile, co-tile) items for two workgroups per CU (16x16 maps); measured slower elsewhere (3x3 layers at
+// 32x32 and up, the 4-tap dgrad classes), where two independent workgroups per CU overlap better.
+int plan_igemm(int rows, int n, int lh, int lw, int in_h, int in_w, int in_step, const TapSet& taps, bool x3,
+               IgemmPlan* best) {
+  const int mode_env = ig_plan_mode();
+  IgemmPlan p0;
+  const int rc0 = plan_igemm_mode(rows, lh, lw, in_h, in_w, in_step, taps, x3, mode_env == 2 ? 0 : mode_env, &p0);
+  if (mode_env != 2) { *best = p0; return rc0; }
+  IgemmPlan p8;
+  const int rc8 = plan_igemm_mode(rows, lh, lw, in_h, in_w, in_step, taps, x3, 2, &p8);
+  if (rc8 < 0 || !p8.w8) { *best = p0; return rc0; }
+  if (rc0 < 0) { *best = p8; return rc8; }
+  const long long items = (long long)n * p0.tiles_x * p0.tiles_y * cdiv(rows, 32 * ig_co_blks(rows));
+  const bool use8 = p0.lds > 81920 || items <= 320;
+  *best = use8 ? p8 : p0;
+  return 0;
+}
+
 int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
   const bool x3 = prec == PCUDA_PREC_BF16X3;
   const int co_blks = ig_co_blks(p.cout);
   const int co_tile = 32 * co_blks;
   IgemmPlan pl;
-  if (plan_igemm(p.cout, p.lh, p.lw, p.in_h, p.in_w, p.in_step, taps, x3, &pl) < 0)
+  if (plan_igemm(p.cout, p.n, p.lh, p.lw, p.in_h, p.in_w, p.in_step, taps, x3, &pl) < 0)
     PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "igemm: no tile of this convolution fits LDS (in_step %d, tap span %d)",
                p.in_step, taps.dy_max - taps.dy_min);
   p.n_co_tiles = cdiv(p.cout, co_tile);
@@ -182,8 +218,8 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
   }
   const double flops = 2.0 * p.n * (double)p.lh * p.lw * p.cout * (double)p.cin * taps.n;
   char tag[160];
-  snprintf(tag, sizeof(tag), "igemm n%d red%d rows%d %dx%d taps%d step%d up%d tw%d npb%d clamp%d tg%d lds%zu", p.n, p.cin,
-           p.cout, p.lh, p.lw, taps.n, p.in_step, p.in_shift, pl.tw, pl.npb, pl.clamp, pl.tg, pl.lds);
+  snprintf(tag, sizeof(tag), "igemm n%d red%d rows%d %dx%d taps%d step%d up%d tw%d npb%d clamp%d tg%d w8%d lds%zu", p.n,
+           p.cin, p.cout, p.lh, p.lw, taps.n, p.in_step, p.in_shift, pl.tw, pl.npb, pl.clamp, pl.tg, pl.w8, pl.lds);
   ProfScope prof(PCUDA_FAM_CONV_FWD, flops, s, tag);
   static int nopipe = -1;
   if (nopipe < 0) { const char* e = getenv("PCUDA_NOPIPE"); nopipe = e ? atoi(e) : 0; }
@@ -196,13 +232,13 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
     const int pfq = (ih * ((pl.iw_t + 6) / 4) + 63) / 64;
     p.xq = (!noxq && (p.in_w & 3) == 0 && p.in_shift == 0 && pfq <= 3) ? 1 : 0;
     if (p.xq) pf = pfq;
+    if (pl.w8) pf = p.xq ? (ih * ((pl.iw_t + 6) / 4) + 127) / 128 : (max_pix + 511) / 512;   // 512 lanes
   }
   // PF = 3 keeps 96 prefetch registers live next to the accumulators: only with one pixel block per wave
   // (one workgroup per CU has 512 registers per lane: PF = 3 next to two pixel blocks fits there)
+  // (the unpipelined fallback copies its weight groups in 512-vector passes: any tg of the plan works)
   const bool pipe = !nopipe && p.ntaps > 0 && fast_src_ok(&p.x, p.cin) && fast_dst_ok(&p.y, p.cout) &&
-                    (pf <= 2 || (pf == 3 && (pl.npb == 1 || pl.fat)));
-  if (!pipe && pl.fat) {   // the unpipelined kernel copies its weight groups in 512-vector passes: any tg works
-  }
+                    (pf <= 2 || (pf == 3 && !pl.w8 && (pl.npb == 1 || pl.fat)));
   return x3 ? igemm_dispatch_x3(p, pl, co_blks, pf, pipe, s) : igemm_dispatch_bf16(p, pl, co_blks, pf, pipe, s);
 }
 
@@ -252,7 +288,7 @@ extern "C" int pcuda_conv2d_fwd_tiles(const pcuda_conv_geom* g, int prec) {
   if (!geom_ok(g)) return 0;
   TapSet t = fwd_taps(g);
   IgemmPlan pl;
-  if (plan_igemm(g->cout, g->out_h, g->out_w, g->in_h, g->in_w, g->stride, t, prec == PCUDA_PREC_BF16X3, &pl) < 0)
+  if (plan_igemm(g->cout, g->n, g->out_h, g->out_w, g->in_h, g->in_w, g->stride, t, prec == PCUDA_PREC_BF16X3, &pl) < 0)
     return 0;
   return g->n * pl.tiles_x * pl.tiles_y;
 }

@@ -278,6 +278,10 @@ template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV>
 __global__ __launch_bounds__(256, (WV > 3 ? 1 : 2)) void igemm_pipe_kernel(const IgemmParams p, const int x_cap, const int total) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CO_TILE = 32 * CO_BLKS;
+  // DB (one workgroup per CU): weight groups alternate between two LDS buffers -- group i+1 is requested
+  // before group i's MFMAs and written behind them -- and the next stage's input is requested in front of
+  // the LAST group's MFMAs, so that no weight load ever queues behind the HBM-latency prefetch.
+  constexpr bool DB = WV > 3;
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int TW = p.tw, TPIX = p.tw * p.th;
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(256, (WV > 3 ? 1 : 2)) void igemm_pipe_kernel(const
   unsigned char* Xlo = smem + (size_t)x_cap * IG_REC_BYTES;
   unsigned char* Whi = smem + (size_t)(X3 ? 2 : 1) * x_cap * IG_REC_BYTES;
   unsigned char* Wlo = Whi + (size_t)p.tg * CO_TILE * IG_REC_BYTES;
-  int* taptab = (int*)(Whi + (size_t)(X3 ? 2 : 1) * p.tg * CO_TILE * IG_REC_BYTES);   // [ntaps], behind the weight slabs
+  int* taptab = (int*)(Whi + (size_t)(X3 ? 2 : 1) * (DB ? 2 : 1) * p.tg * CO_TILE * IG_REC_BYTES);   // [ntaps], behind the weight slabs
   float* sbias = (float*)(taptab + 64);   // [CO_TILE] bias of the tile being finished (host adds 512 B in all)
   float* sred = (float*)smem;   // [4 waves][CO_TILE][2], reused between a tile's last MFMA and the next commit
 
@@ -364,10 +368,13 @@ __global__ __launch_bounds__(256, (WV > 3 ? 1 : 2)) void igemm_pipe_kernel(const
     TileGeom ng = g;
     if (nhave && nL != L) ng = tile_decode<CLAMP, NPB>(p, nL);
     // unconditional (no stage left: zero pixels, every lane out of range -> no memory traffic)
-    if (p.xq) xq_issue<PF>(pre, p.x, ng.n, p.cin, nhave ? nchunk : 0, p.in_h, p.in_w, ng.oy0, ng.ox0, nhave ? ng.th : 0,
-                           ng.tw, tid);
-    else xfast_issue<PF>(pre, p.x, ng.n, p.cin, nhave ? nchunk : 0, p.in_h, p.in_w, p.in_shift, p.in_row, ng.oy0, ng.ox0,
-                         ng.tw, nhave ? ng.npix : 0, 4, tid);
+    auto issue_next = [&]() {
+      if (p.xq) xq_issue<PF>(pre, p.x, ng.n, p.cin, nhave ? nchunk : 0, p.in_h, p.in_w, ng.oy0, ng.ox0, nhave ? ng.th : 0,
+                             ng.tw, tid);
+      else xfast_issue<PF>(pre, p.x, ng.n, p.cin, nhave ? nchunk : 0, p.in_h, p.in_w, p.in_shift, p.in_row, ng.oy0,
+                           ng.ox0, ng.tw, nhave ? ng.npix : 0, 4, tid);
+    };
+    if (!DB) issue_next();
     DBG_CLK(2)
 
     if (chunk == 0) {
@@ -388,9 +395,12 @@ __global__ __launch_bounds__(256, (WV > 3 ? 1 : 2)) void igemm_pipe_kernel(const
     DBG_CLK(3)
     __syncthreads();
     DBG_CLK(4)
-    for (int t0 = 0; t0 < p.ntaps; t0 += p.tg) {
+    const size_t wbuf_bytes = (size_t)(X3 ? 2 : 1) * p.tg * CO_TILE * IG_REC_BYTES;
+    for (int t0 = 0, gi = 0; t0 < p.ntaps; t0 += p.tg, ++gi) {
       const int tgc = min(p.tg, p.ntaps - t0);
-      if (t0 > 0) {   // later groups (more taps than fit): loaded behind the X prefetch, latency exposed
+      const bool more = t0 + p.tg < p.ntaps;
+      const int nvecn = min(p.tg, p.ntaps - (t0 + p.tg)) * CO_TILE * 5;
+      if (!DB && t0 > 0) {   // later groups (more taps than fit): loaded behind the X prefetch, latency exposed
         __syncthreads();
         const uint16_t* src = wsrc + (long long)t0 * slab;
         wcopy<X3, WV>(Whi, Wlo, (const uint4*)src, (const uint4*)(src + p.w_lo_off), tgc * CO_TILE * 5, 0, tid);
@@ -398,8 +408,17 @@ __global__ __launch_bounds__(256, (WV > 3 ? 1 : 2)) void igemm_pipe_kernel(const
         __syncthreads();
         DBG_CLK(4)
       }
-      const unsigned char* Wh = Whi;
-      const unsigned char* Wl = Wlo;
+      if (DB) {
+        if (more) {
+          const uint16_t* src = wsrc + (long long)(t0 + p.tg) * slab;
+          wcopy_issue<X3, WV>(wp0, (const uint4*)src, (const uint4*)(src + p.w_lo_off), nvecn, 0, tid);
+        } else {
+          issue_next();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const unsigned char* Wh = Whi + (DB ? (gi & 1) * wbuf_bytes : 0);
+      const unsigned char* Wl = Wlo + (DB ? (gi & 1) * wbuf_bytes : 0);
       int tv = taptab[t0];
       for (int tl = 0; tl < tgc; ++tl) {
         const int tcur = tv;
@@ -448,6 +467,12 @@ __global__ __launch_bounds__(256, (WV > 3 ? 1 : 2)) void igemm_pipe_kernel(const
         }
       }
       DBG_CLK_ACC(5)
+      if (DB && more) {
+        wcopy_commit<X3, WV>(wp0, Whi + ((gi + 1) & 1) * wbuf_bytes, Wlo + ((gi + 1) & 1) * wbuf_bytes, nvecn, 0, tid);
+        DBG_CLK(3)
+        __syncthreads();
+        DBG_CLK(4)
+      }
     }
 
     DBG_CLK(6)
@@ -538,6 +563,249 @@ __global__ __launch_bounds__(256, (WV > 3 ? 1 : 2)) void igemm_pipe_kernel(const
 
 
 
+// ------------------------------------------------------------------------------------------
+// Eight-wave variant: ONE 512-thread workgroup per CU owning all 160 KiB of LDS, so that (for 3x3
+// layers) every tap of a chunk's weights is resident -- one weight round trip per stage, requested
+// ahead of the stage's X commit, and no barrier inside the MFMA phase -- while each SIMD still holds two
+// waves.  Per lane the staging work and its registers halve (512 threads share a tile).
+// Wave roles: NPBT = 32-pixel blocks per tile (8: 256-pixel tiles, every wave owns one pixel block and
+// all CO_BLKS row blocks; 4: 128-pixel tiles with CO_BLKS = 2, waves 0-3 take row block 0, 4-7 block 1).
+// ------------------------------------------------------------------------------------------
+#define IG8_WV 6   // weight-copy slots per lane and plane: 6 * 512 vectors >= 9 taps x 64 rows x 5
+template <bool X3, int CO_BLKS, bool CLAMP, int NPBT, int PF>
+__global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, const int x_cap, const int total) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int CO_TILE = 32 * CO_BLKS, NT = 512, WV = IG8_WV;
+  constexpr int CBW = CO_BLKS * NPBT / 8;   // row blocks per wave
+  static_assert(CBW >= 1 && CO_BLKS * NPBT % 8 == 0, "8 waves need 8 or 16 MFMA tiles per stage");
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pbw = w % NPBT, cb0 = (w / NPBT) * CBW;
+  const int TW = p.tw, TPIX = p.tw * p.th;
+
+  // one workgroup per CU; XCD-aware persistent schedule as in igemm_pipe_kernel
+  const int nx = min(8, (int)gridDim.x);
+  const int xcd = blockIdx.x % nx, slot = blockIdx.x / nx;
+  const int gx = ((int)gridDim.x - xcd + nx - 1) / nx;
+  const int lo = (int)((long long)total * xcd / nx), hi = (int)((long long)total * (xcd + 1) / nx);
+
+  unsigned char* Xhi = smem;
+  unsigned char* Xlo = smem + (size_t)x_cap * IG_REC_BYTES;
+  unsigned char* Whi = smem + (size_t)(X3 ? 2 : 1) * x_cap * IG_REC_BYTES;
+  unsigned char* Wlo = Whi + (size_t)p.tg * CO_TILE * IG_REC_BYTES;
+  int* taptab = (int*)(Whi + (size_t)(X3 ? 2 : 1) * p.tg * CO_TILE * IG_REC_BYTES);
+  float* sbias = (float*)(taptab + 64);
+  float* sred = (float*)smem;   // [8 waves][CO_TILE][2]
+
+  for (int t = 0; t < p.ntaps; ++t) {
+    const int dy = p.dy[t], dx = p.dx[t];
+    if (tid == 0)
+      taptab[t] = CLAMP ? ((dy & 0xffff) | (dx << 16)) : ((dy - p.dy_min) * p.iw_t + (dx - p.dx_min)) * IG_REC_BYTES;
+  }
+
+  const int plr = pbw * 32 + r;
+  const bool pvalid = plr < TPIX;
+  const int pl = min(plr, TPIX - 1);
+  const int pty = IG_TY(pl, p.tmagic), ptx = pl - pty * TW;
+
+  f32x16 acc[CBW];
+  XFast<PF> pre;
+
+  auto issue_x = [&](const TileGeom& t, int ch, bool live) {
+    if (p.xq) xq_issue<PF, NT>(pre, p.x, t.n, p.cin, live ? ch : 0, p.in_h, p.in_w, t.oy0, t.ox0, live ? t.th : 0, t.tw, tid);
+    else xfast_issue<PF, NT>(pre, p.x, t.n, p.cin, live ? ch : 0, p.in_h, p.in_w, p.in_shift, p.in_row, t.oy0, t.ox0, t.tw,
+                             live ? t.npix : 0, 4, tid);
+  };
+
+  int L = lo + slot, chunk = 0;
+  bool have = L < hi;
+  TileGeom g;
+  if (have) {
+    g = tile_decode<CLAMP, 1>(p, L);
+    issue_x(g, 0, true);
+  }
+  while (have) {
+    const int cvalid = min(32, p.cin - chunk * 32);
+    const int nks = cvalid > 16 ? 2 : 1;
+    __syncthreads();   // every wave is done with the previous stage's X / W / reduction scratch
+    float bias_r = 0.f;
+    if (chunk == p.nchunks - 1 && p.bias && tid < CO_TILE) bias_r = p.bias[min(g.cot * CO_TILE + tid, p.cout - 1)];
+    if (p.xq) xq_commit<X3, PF, NT>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.ox0, g.th, g.tw, nks * 2, tid);
+    else xfast_commit<X3, PF, NT>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.npix, (cvalid + 7) >> 3, nks * 2, tid);
+    if (CLAMP && tid < 5) {
+      *(uint4*)(Xhi + (size_t)g.npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
+      if (X3) *(uint4*)(Xlo + (size_t)g.npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the stage's (first) weight group, with nothing else in the load queue: one L2 round trip.  (Requested
+    // before the X commit its 48 registers were spilled to scratch one load at a time.)
+    const long long slab = (long long)CO_TILE * IG_REC;
+    const uint16_t* wsrc = p.wpack + ((long long)g.cot * p.nchunks + chunk) * p.ntaps * slab;
+    const int nvec0 = min(p.tg, p.ntaps) * CO_TILE * 5;
+    {
+      WPass<X3, WV> wp0;
+      wcopy_issue<X3, WV, NT>(wp0, (const uint4*)wsrc, (const uint4*)(wsrc + p.w_lo_off), nvec0, 0, tid);
+      __builtin_amdgcn_sched_barrier(0);
+      wcopy_commit<X3, WV, NT>(wp0, Whi, Wlo, nvec0, 0, tid);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // next stage: its loads stay in flight through the MFMA phase
+    int nL = L, nchunk = chunk + 1;
+    if (nchunk == p.nchunks) { nchunk = 0; nL = L + gx; }
+    const bool nhave = nL < hi;
+    TileGeom ng = g;
+    if (nhave && nL != L) ng = tile_decode<CLAMP, 1>(p, nL);
+    issue_x(ng, nchunk, nhave);
+
+    if (chunk == 0) {
+#pragma unroll
+      for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
+    }
+    const int bbase = ((pty * p.in_step) * g.tw + ptx * p.in_step) * IG_REC_BYTES + h * 16;
+    __syncthreads();
+
+    for (int t0 = 0; t0 < p.ntaps; t0 += p.tg) {
+      const int tgc = min(p.tg, p.ntaps - t0);
+      if (t0 > 0) {   // more taps than fit (4x4 / 6x6 kernels): later groups load behind the prefetch
+        __syncthreads();
+        const uint16_t* src = wsrc + (long long)t0 * slab;
+        wcopy<X3, WV, NT>(Whi, Wlo, (const uint4*)src, (const uint4*)(src + p.w_lo_off), tgc * CO_TILE * 5, 0, tid);
+        __syncthreads();
+      }
+      int tv = taptab[t0];
+      for (int tl = 0; tl < tgc; ++tl) {
+        const int tcur = tv;
+        tv = taptab[min(t0 + tl + 1, p.ntaps - 1)];
+        int baddr;
+        if (CLAMP) {
+          const int dy = (tcur << 16) >> 16, dx = tcur >> 16;
+          const int gy = (g.y0 + pty) * p.in_step + dy;
+          const int gxx = (g.x0 + ptx) * p.in_step + dx;
+          const bool ok = ((unsigned)gy < (unsigned)p.in_h) & ((unsigned)gxx < (unsigned)p.in_w);
+          const int idx = ok ? (gy - g.oy0) * g.tw + (gxx - g.ox0) : g.npix;
+          baddr = idx * IG_REC_BYTES + h * 16;
+        } else {
+          baddr = bbase + tcur;
+        }
+        const int abase = (tl * CO_TILE + cb0 * 32 + r) * IG_REC_BYTES + h * 16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          if (ks < nks) {
+            bf16x8 ah[CBW], al[CBW];
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb) {
+              ah[cb] = lds_frag(Whi + abase + cb * 32 * IG_REC_BYTES + ks * 32);
+              al[cb] = ah[cb];
+              if (X3) al[cb] = lds_frag(Wlo + abase + cb * 32 * IG_REC_BYTES + ks * 32);
+            }
+            const bf16x8 bh = lds_frag(Xhi + baddr + ks * 32);
+            bf16x8 bl = bh;
+            if (X3) bl = lds_frag(Xlo + baddr + ks * 32);
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb) {
+              if (X3) {
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cb], bh, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb], bl, acc[cb], 0, 0, 0);
+              }
+              acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb], bh, acc[cb], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+
+    if (chunk == p.nchunks - 1) {
+      // ---- epilogue (see igemm_pipe_kernel): bias through LDS, buffer stores, DPP partial sums
+      const int co0 = g.cot * CO_TILE;
+      if (tid < CO_TILE) sbias[tid] = bias_r;
+      __syncthreads();
+      const int ly = g.y0 + pty, lx = g.x0 + ptx;
+      const bool pok = pvalid & (ly < p.lh) & (lx < p.lw);
+      const unsigned pixo = pok ? (unsigned)((ly * p.oy_mul + p.oy_off) * p.out_w + (lx * p.ox_mul + p.ox_off)) * 4u : IG_OOB;
+      const int c1 = min(p.y.c1, p.cout);
+      float* const yb1 = p.y.p1 + (long long)g.n * p.y.sn1;
+      float* const yb2 = p.y.p2 + (long long)g.n * p.y.sn2;
+      const unsigned pl1 = (unsigned)p.y.sc1 * 4u, pl2 = (unsigned)p.y.sc2 * 4u;
+#pragma unroll
+      for (int cb = 0; cb < CBW; ++cb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row0 = (cb0 + cb) * 32 + (i & 3) + 8 * (i >> 2);
+          const int row = row0 + 4 * h;
+          const int cu = co0 + row0;
+          const bool first = cu < c1;
+          const unsigned plane = first ? pl1 : pl2;
+          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+              (void*)(first ? yb1 : yb2), 0, (int)((first ? c1 : p.cout - c1) * plane), 0x00020000);
+          const unsigned soff = (unsigned)(first ? cu : cu - c1) * plane;
+          const unsigned vo = pixo + (h ? 4u * plane : 0u);
+          float v = acc[cb][i] + sbias[row];
+          v = v > 0.f ? v : v * p.slope;
+          if (p.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, soff, 0));
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, vo, soff, 0);
+          if (p.stats) {
+            const float vs = (pok & (co0 + row < p.cout)) ? v : 0.f;
+            const float s1 = half_wave_sum_hi16(vs), s2 = half_wave_sum_hi16(vs * vs);
+            if (r == 31) {
+              sred[(w * CO_TILE + row) * 2 + 0] = s1;
+              sred[(w * CO_TILE + row) * 2 + 1] = s2;
+            }
+          }
+        }
+      }
+      if (p.stats) {
+        __syncthreads();
+        if (tid < CO_TILE) {
+          const int co = g.cot * CO_TILE + tid;
+          if (co < p.cout) {
+            // the waves that own row block (tid >> 5): NPBT consecutive ones
+            const int w0 = ((tid >> 5) / CBW) * NPBT;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NPBT; ++ww) {
+              s1 += sred[((w0 + ww) * CO_TILE + tid) * 2 + 0];
+              s2 += sred[((w0 + ww) * CO_TILE + tid) * 2 + 1];
+            }
+            p.stats[((long long)g.pt * p.cout + co) * 2 + 0] = s1;
+            p.stats[((long long)g.pt * p.cout + co) * 2 + 1] = s2;
+          }
+        }
+      }
+    }
+    L = nL; chunk = nchunk; g = ng; have = nhave;
+  }
+}
+
+template <bool X3, int CO_BLKS, bool CLAMP, int NPBT, int PF>
+static int launch_igemm8_t(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
+  auto kern = igemm8_kernel<X3, CO_BLKS, CLAMP, NPBT, PF>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HARD);
+    if (e != hipSuccess) PCUDA_FAIL(PCUDA_E_LAUNCH, "igemm8: cannot raise dynamic LDS: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  const int total = p.n_co_tiles * p.n * p.tiles_x * p.tiles_y;
+  int grid = 256;
+  if (grid > total) grid = total;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pl.lds, s, p, pl.x_cap, total);
+  PCUDA_CHECK_LAUNCH("igemm8_kernel");
+  return PCUDA_OK;
+}
+
+template <bool X3>
+static int igemm8_dispatch(const IgemmParams& p, const IgemmPlan& pl, int co_blks, int pf, hipStream_t s) {
+#define IG8_PF(CB_, CL_, NB_) (pf == 1 ? launch_igemm8_t<X3, CB_, CL_, NB_, 1>(p, pl, s) : launch_igemm8_t<X3, CB_, CL_, NB_, 2>(p, pl, s))
+#define IG8_CL(CB_, NB_) (pl.clamp ? IG8_PF(CB_, true, NB_) : IG8_PF(CB_, false, NB_))
+  if (pl.npb == 2) return co_blks == 2 ? IG8_CL(2, 8) : IG8_CL(1, 8);
+  return IG8_CL(2, 4);   // 128-pixel tiles: only with two row blocks
+#undef IG8_CL
+#undef IG8_PF
+}
+
 template <bool X3, int CO_BLKS, bool CLAMP, int NPB>
 static int launch_igemm_t(const IgemmParams& p, int x_cap, size_t lds, hipStream_t s) {
   auto kern = igemm_kernel<X3, CO_BLKS, CLAMP, NPB>;
@@ -592,7 +860,7 @@ static int launch_pipe_t(const IgemmParams& p, const IgemmPlan& pl, hipStream_t 
 
 template <bool X3, int CO_BLKS, bool CLAMP, int NPB>
 static int launch_pipe_pf(const IgemmParams& p, const IgemmPlan& pl, int pf, hipStream_t s) {
-  constexpr int WVF = CO_BLKS == 2 ? 12 : 6;
+  constexpr int WVF = 5;
   if (pl.fat) {
     if (pf == 1) return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 1, WVF>(p, pl, s);
     if (pf == 2) return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 2, WVF>(p, pl, s);
@@ -614,6 +882,7 @@ static int launch_pipe_c(const IgemmParams& p, const IgemmPlan& pl, int pf, hipS
 
 template <bool X3>
 static int igemm_dispatch(const IgemmParams& p, const IgemmPlan& pl, int co_blks, int pf, bool pipe, hipStream_t s) {
+  if (pipe && pl.w8) return igemm8_dispatch<X3>(p, pl, co_blks, pf, s);
   if (pipe) return co_blks == 2 ? launch_pipe_c<X3, 2>(p, pl, pf, s) : launch_pipe_c<X3, 1>(p, pl, pf, s);
   return co_blks == 2 ? launch_igemm_c<X3, 2>(p, pl, s) : launch_igemm_c<X3, 1>(p, pl, s);
 }
