@@ -139,6 +139,15 @@ __device__ __forceinline__ void stage_x_chunk(unsigned char* __restrict__ xhi, u
 // ------------------------------------------------------------------------------------------
 #define IG_OOB 0x40000000u
 
+// A zero the optimiser cannot see through.  Added to the scale/shift pointers inside the per-tile commit so
+// that their (loop-invariant, wave-uniform) loads are NOT hoisted out of the tile loop: hoisted, the 64 values
+// of a chunk overflow the scalar registers and end up spilled to scratch and re-read from there every tile.
+__device__ __forceinline__ int opaque_zero() {
+  int z;
+  asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+  return z;
+}
+
 template <int PF>
 struct XFast {
   float v[PF][32];
@@ -188,7 +197,7 @@ __device__ __forceinline__ void xfast_commit(XFast<PF>& pre, unsigned char* __re
   const float* scp = first ? x.scale1 : x.scale2;
   const float* shp = first ? x.shift1 : x.shift2;
   const int csrc = first ? min(x.c1, cin) : cin - x.c1;
-  const int cl0 = first ? c0 : c0 - x.c1;
+  const int cl0 = (first ? c0 : c0 - x.c1) + opaque_zero();
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     if (g >= ngroups && g < nwrite) {   // channels past cin inside a 16-wide k-step: zeros, not LDS garbage
@@ -291,7 +300,7 @@ __device__ __forceinline__ void xq_commit(XFast<PF>& pre, unsigned char* __restr
   const float* scp = first ? x.scale1 : x.scale2;
   const float* shp = first ? x.shift1 : x.shift2;
   const int csrc = first ? min(x.c1, cin) : cin - x.c1;
-  const int cl0 = (first ? c0 : c0 - x.c1) + w * 8;
+  const int cl0 = (first ? c0 : c0 - x.c1) + w * 8 + opaque_zero();
   const int lead = ox0 & 3, nq = (tw + lead + 3) >> 2, nitems = th * nq;
   const int qmagic = (1 << 16) / nq + 1;
   float sc[8], sh[8];

@@ -44,7 +44,10 @@ __device__ __forceinline__ WTile wtile_decode(const WgradParams& p, int tile) {
 // registers), commit = mask, db partial sums, bf16 hi/lo split, LDS write.
 template <int CO_TILE>
 __device__ __forceinline__ void zpre_issue(float (&zv)[CO_TILE / 16][8], const WgradParams& p, const WTile& t,
-                                           int cot, int tid) {
+                                           int cot, int tid0) {
+  // (opaque zero: keeps the per-element tile coordinates of the generic path from being hoisted out of the
+  // tile loop -- 64 loop-invariant registers that were spilled to scratch and reloaded every tile)
+  const int tid = tid0 + opaque_zero();
   const int TW = p.tw, TPIX = p.tw * p.th;
 #pragma unroll
   for (int j = 0; j < CO_TILE / 16; ++j) {
@@ -112,6 +115,7 @@ __device__ __forceinline__ void zpre_commit(float (&zv)[CO_TILE / 16][8], const 
                                             int cot, int tid, unsigned char* __restrict__ Zhi,
                                             unsigned char* __restrict__ Zlo, bool do_db,
                                             float (&dbacc)[CO_TILE / 16], bool premasked) {
+  tid += opaque_zero();   // see zpre_issue
   const int TW = p.tw, TPIX = p.tw * p.th;
 #pragma unroll
   for (int j = 0; j < CO_TILE / 16; ++j) {
@@ -303,6 +307,9 @@ __global__ __launch_bounds__(256, ((TAPS_MAX <= 9 && PF <= 1) ? 2 : 1)) void wgr
     tap_off[ti] = ((tap_dy[ti] - p.dy_min) * p.iw_t + (tap_dx[ti] - p.dx_min)) * IG_REC_BYTES;
   }
 
+  // dZ is prefetched like X except where that does not fit the 256 registers of two waves per SIMD (the
+  // 64-row, 9-tap variant spilled 52 dwords inside the tile loop): there dZ is loaded at commit time
+  constexpr bool ZPRE = PF > 0 && !(CO_BLKS == 2 && TAPS_MAX == 9 && PF == 1 && MODE != 0);
   XFast<XPF> xpre;
   float zv[CO_TILE / 16][8];
   ZConst<CO_TILE> zc;
@@ -312,8 +319,10 @@ __global__ __launch_bounds__(256, ((TAPS_MAX <= 9 && PF <= 1) ? 2 : 1)) void wgr
   if (PF > 0 && tile_lo < tile_hi) {
     xfast_issue<XPF>(xpre, p.x, cur.n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row, cur.oy0, cur.ox0, cur.tw,
                      cur.npix, ngroups, tid);
-    if (zfast) zfast_issue<CO_TILE>(zv, zc, p, cur);
-    else zpre_issue<CO_TILE>(zv, p, cur, cot, tid);
+    if (ZPRE) {
+      if (zfast) zfast_issue<CO_TILE>(zv, zc, p, cur);
+      else zpre_issue<CO_TILE>(zv, p, cur, cot, tid);
+    }
   }
 
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
@@ -322,6 +331,10 @@ __global__ __launch_bounds__(256, ((TAPS_MAX <= 9 && PF <= 1) ? 2 : 1)) void wgr
     __syncthreads();   // the previous tile's MFMA phase is done with the LDS tiles
     if (PF > 0) {
       xfast_commit<X3, XPF>(xpre, Xhi, Xlo, p.x, p.cin, chunk, npix, ngroups, 4, tid);
+      if (!ZPRE) {
+        if (zfast) zfast_issue<CO_TILE>(zv, zc, p, cur);
+        else zpre_issue<CO_TILE>(zv, p, cur, cot, tid);
+      }
     } else {
       stage_x_chunk<X3, 1>(Xhi, Xlo, p.x, cur.n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row, oy0, ox0, cur.th,
                            tw, ngroups, 4, tid);
@@ -338,8 +351,10 @@ __global__ __launch_bounds__(256, ((TAPS_MAX <= 9 && PF <= 1) ? 2 : 1)) void wgr
       nxt = wtile_decode<CLAMP>(p, tile + 1);
       xfast_issue<XPF>(xpre, p.x, nxt.n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row, nxt.oy0, nxt.ox0, nxt.tw,
                        nxt.npix, ngroups, tid);
-      if (zfast) zfast_issue<CO_TILE>(zv, zc, p, nxt);
-      else zpre_issue<CO_TILE>(zv, p, nxt, cot, tid);
+      if (ZPRE) {
+        if (zfast) zfast_issue<CO_TILE>(zv, zc, p, nxt);
+        else zpre_issue<CO_TILE>(zv, p, nxt, cot, tid);
+      }
     }
 
     // ---- MFMA phase
