@@ -201,7 +201,7 @@ def main():
         K.prof_reset()
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         result["roofline"] = {
-            "kernel": "igemm_kernel (implicit-GEMM MFMA conv: forward + dgrad)", "bound": "mfma",
+            "kernel": "igemm_pipe_kernel / igemm8_kernel (implicit-GEMM MFMA conv: forward + dgrad launches)", "bound": "mfma",
             "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
             "traffic": None, "launches_per_step": launches // nprof, "avg_launch_us": round(1000.0 * ms / max(launches, 1), 2),
             "ms_per_step": round(ms / nprof, 3),

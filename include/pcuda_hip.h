@@ -59,6 +59,9 @@ int pcuda_prof_reset(void);
 int pcuda_prof_read(int family, double* ms, double* work, long long* launches);
 /* writes one CSV row per recorded launch (family, work, ms, shape tag) */
 int pcuda_prof_dump(const char* path);
+/* timing experiments only (PCUDA_DBG bit 128): the eight per-phase cycle sums the pipelined forward/dgrad
+ * kernel accumulates (barrier, X commit, issue, weight copy, barrier, MFMA, epilogue, loop tail); read + reset */
+int pcuda_debug_read_clocks(unsigned long long* out8);
 
 /* ------------------------------------------------------------------------------------
  * 2-D convolution: replaces nn.Conv2d forward/backward at

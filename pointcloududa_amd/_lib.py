@@ -41,6 +41,7 @@ _PROTOS = {
     "pcuda_prof_reset": (i32, []),
     "pcuda_prof_read": (i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]),
     "pcuda_prof_dump": (i32, [C.c_char_p]),
+    "pcuda_debug_read_clocks": (i32, [vp]),
     "pcuda_conv2d_packed_fwd_bytes": (sz, [C.POINTER(ConvGeom), i32]),
     "pcuda_conv2d_packed_dgrad_bytes": (sz, [C.POINTER(ConvGeom), i32]),
     "pcuda_conv2d_pack_fwd": (i32, [C.POINTER(ConvGeom), i32, vp, vp, vp]),

@@ -6,7 +6,6 @@ import torch
 from pointcloududa_amd import kernels as K
 from pointcloududa_amd import _lib
 lib = _lib.lib()
-lib.pcuda_debug_read_clocks.argtypes = [ctypes.c_void_p]
 dev = torch.device("cuda", 0)
 K.set_precision(os.environ.get("PREC", "bf16x3"))
 CASES = {"g32": (32, 32, 32, 256, 256, 3, 1, 1, 1), "g64": (32, 64, 64, 128, 128, 3, 1, 1, 1),
