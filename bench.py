@@ -156,12 +156,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # PCUDA_GRAPH=1 (single process): replay the step from a captured hipGraph.  Off by default: measured 68.7 vs
+    # 69.4 ms/step -- the ~4 ms between kernels is dependent-launch latency on the GPU, not host launch time.
+    use_graph = world == 1 and os.environ.get("PCUDA_GRAPH", "0") == "1"
+    step = tr.step_graphed if use_graph else tr.step
     for _ in range(args.warmup):
-        tr.step(*batch)
+        step(*batch)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = tr.step(*batch)
+        out = step(*batch)
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -182,6 +186,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": wl["desc"], "per_gpu_batch": b, "global_batch": b * world, "precision": args.precision,
                    "parallelism": "dp%d" % world, "algorithmic_gflop_per_pair": wl["gflop_per_pair"],
+                   "launch": "hipGraph replay" if (use_graph and getattr(tr, "_graph", None) is not None) else "eager",
                    "losses": {k: round(host[k], 5) for k in ("seg_loss", "adv_loss") if k in host}},
     }
 

@@ -259,6 +259,11 @@ int pcuda_fps(const double* pts, const int* counts, const int* first, int b, int
  * ---------------------------------------------------------------------------------- */
 int pcuda_adam_step(float* p, const float* g, float* m, float* v, long long numel, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int step, float grad_scale, pcuda_stream_t s);
+/* same update with the step count held in device memory: *step_dev is incremented on the stream first and then
+ * used for the bias corrections, so a captured graph of the train step replays correctly */
+int pcuda_adam_step_dev(float* p, const float* g, float* m, float* v, long long numel, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, int* step_dev, float grad_scale,
+                        pcuda_stream_t s);
 int pcuda_sgd_step(float* p, const float* g, float* mom, long long numel, float lr, float momentum,
                    float weight_decay, int first_step, float grad_scale, pcuda_stream_t s);
 

@@ -51,6 +51,11 @@ namespace {
 
 // PCUDA_FAT=1 plans one workgroup per CU with all taps resident (experimental: the weight stash spills)
 unsigned long long* g_dbg_clk_host = nullptr;
+bool ig_wstay_mode() {   // PCUDA_WSTAY=1: measured slower on the 256x256 32-channel level (0.38 vs 0.33 ms)
+  static int m = -1;
+  if (m < 0) { const char* e = getenv("PCUDA_WSTAY"); m = (e && atoi(e)) ? 1 : 0; }
+  return m != 0;
+}
 // LDS / workgroup plan: 0 = two (or three) 256-thread workgroups per CU with small weight groups,
 // 1 (PCUDA_FAT=1, experimental) = one 256-thread workgroup with two alternating weight buffers,
 // 2 (default; PCUDA_W8=0 turns it off) = one 512-thread workgroup with every tap resident where it fits
@@ -175,9 +180,10 @@ int plan_igemm_mode(int rows, int lh, int lw, int in_h, int in_w, int in_step, c
 // workgroup anyway (its LDS tile > 80 KiB: the stride-2 4x4 layers) or where there are not enough
 // (tile, co-tile) items for two workgroups per CU (16x16 maps); measured slower elsewhere (3x3 layers at
 // 32x32 and up, the 4-tap dgrad classes), where two independent workgroups per CU overlap better.
-int plan_igemm(int rows, int n, int lh, int lw, int in_h, int in_w, int in_step, const TapSet& taps, bool x3,
+int plan_igemm(int rows, int red, int n, int lh, int lw, int in_h, int in_w, int in_step, const TapSet& taps, bool x3,
                IgemmPlan* best) {
   const int mode_env = ig_plan_mode();
+  const bool single_chunk = red <= 32;
   IgemmPlan p0;
   const int rc0 = plan_igemm_mode(rows, lh, lw, in_h, in_w, in_step, taps, x3, mode_env == 2 ? 0 : mode_env, &p0);
   if (mode_env != 2) { *best = p0; return rc0; }
@@ -186,7 +192,9 @@ int plan_igemm(int rows, int n, int lh, int lw, int in_h, int in_w, int in_step,
   if (rc8 < 0 || !p8.w8) { *best = p0; return rc0; }
   if (rc0 < 0) { *best = p8; return rc8; }
   const long long items = (long long)n * p0.tiles_x * p0.tiles_y * cdiv(rows, 32 * ig_co_blks(rows));
-  const bool use8 = p0.lds > 81920 || items <= 320;
+  // (one chunk, one co-tile, every tap resident: the eight-wave kernel loads the weights once per workgroup)
+  const bool wstay = rows <= 64 && taps.n <= p8.tg && single_chunk;
+  const bool use8 = p0.lds > 81920 || items <= 320 || (wstay && ig_wstay_mode());
   *best = use8 ? p8 : p0;
   return 0;
 }
@@ -196,7 +204,7 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
   const int co_blks = ig_co_blks(p.cout);
   const int co_tile = 32 * co_blks;
   IgemmPlan pl;
-  if (plan_igemm(p.cout, p.n, p.lh, p.lw, p.in_h, p.in_w, p.in_step, taps, x3, &pl) < 0)
+  if (plan_igemm(p.cout, p.cin, p.n, p.lh, p.lw, p.in_h, p.in_w, p.in_step, taps, x3, &pl) < 0)
     PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "igemm: no tile of this convolution fits LDS (in_step %d, tap span %d)",
                p.in_step, taps.dy_max - taps.dy_min);
   p.n_co_tiles = cdiv(p.cout, co_tile);
@@ -288,7 +296,7 @@ extern "C" int pcuda_conv2d_fwd_tiles(const pcuda_conv_geom* g, int prec) {
   if (!geom_ok(g)) return 0;
   TapSet t = fwd_taps(g);
   IgemmPlan pl;
-  if (plan_igemm(g->cout, g->n, g->out_h, g->out_w, g->in_h, g->in_w, g->stride, t, prec == PCUDA_PREC_BF16X3, &pl) < 0)
+  if (plan_igemm(g->cout, g->cin, g->n, g->out_h, g->out_w, g->in_h, g->in_w, g->stride, t, prec == PCUDA_PREC_BF16X3, &pl) < 0)
     return 0;
   return g->n * pl.tiles_x * pl.tiles_y;
 }

@@ -521,6 +521,13 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=
                                   eps, weight_decay, step, grad_scale, _stream()), "adam_step")
 
 
+def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step_t, grad_scale=1.0):
+    """Adam with the step count in the int32 device tensor ``step_t`` (incremented by the call): graph-capturable."""
+    check(L.lib().pcuda_adam_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1,
+                                      beta2, eps, weight_decay, step_t.data_ptr(), grad_scale, _stream()),
+          "adam_step_dev")
+
+
 def sgd_step(p, g, mom, lr, momentum, weight_decay, first_step, grad_scale=1.0):
     check(L.lib().pcuda_sgd_step(p.data_ptr(), g.data_ptr(), _ptr(mom), p.numel(), lr, momentum, weight_decay,
                                  1 if first_step else 0, grad_scale, _stream()), "sgd_step")

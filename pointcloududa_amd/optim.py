@@ -77,15 +77,17 @@ class FusedAdam(_FlatOptimizer):
         self.betas, self.eps, self.wd = betas, eps, weight_decay
         self.m = torch.zeros_like(self.p)
         self.v = torch.zeros_like(self.p)
+        # the step count lives on the device (the kernel increments it): a captured graph of the step replays right
+        self.step_t = torch.zeros(1, dtype=torch.int32, device=self.p.device)
 
     def step(self, grad_scale: float = 1.0):
-        self.steps += 1
+        self.steps += 1   # host-side count of step() calls (not advanced by graph replays; see state_dict)
         self.module._wgen = getattr(self.module, "_wgen", 0) + 1   # packed conv weights are stale now
-        K.adam_step(self.p, self.g, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
-                    self.steps, grad_scale)
+        K.adam_step_dev(self.p, self.g, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                        self.step_t, grad_scale)
 
     def state_dict(self):
-        return {"steps": self.steps, "lr": self.lr, "exp_avg": self.m, "exp_avg_sq": self.v}
+        return {"steps": int(self.step_t.item()), "lr": self.lr, "exp_avg": self.m, "exp_avg_sq": self.v}
 
 
 class FusedSGD(_FlatOptimizer):

@@ -172,6 +172,44 @@ class AdversarialTrainer:
                 o.step(o.all_reduce_grads(self.group))
         return out
 
+    # ------------------------------------------------------------------ the same iteration as one hipGraph
+    def step_graphed(self, img_a, mask_a_u8, vert_a, img_b, vert_b) -> Dict[str, torch.Tensor]:
+        """``step`` replayed from a captured hipGraph (single process only: the RCCL all-reduce stays eager).
+
+        The ~650 kernel launches of a step leave the GPU idle for a few milliseconds between kernels when driven
+        from Python; a graph replay removes that.  The first call runs two eager steps (every lazily created
+        buffer, packed-weight cache and kernel attribute exists afterwards) and captures a third; later calls
+        copy the batch into the captured input buffers and replay.  Learning rates are baked into the capture
+        (re-capture after changing them: ``self._graph = None``); Adam's step count lives on the device.
+        Falls back to ``step`` if capture is not possible."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            return self.step(img_a, mask_a_u8, vert_a, img_b, vert_b)
+        batch = (img_a, mask_a_u8, vert_a, img_b, vert_b)
+        if getattr(self, "_graph", None) is None:
+            if getattr(self, "_graph_failed", False):
+                return self.step(*batch)
+            try:
+                for _ in range(2):
+                    self.step(*batch)
+                torch.cuda.synchronize()
+                self._gin = tuple(t.clone() for t in batch)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._gout = self.step(*self._gin)
+                self._graph = graph
+            except Exception as e:   # noqa: BLE001 -- any capture failure means: stay eager
+                import warnings
+                warnings.warn("hipGraph capture of the train step failed (%s: %s); running eagerly" % (type(e).__name__, e))
+                self._graph, self._graph_failed = None, True
+                torch.cuda.synchronize()
+                return self.step(*batch)
+        for dst, src in zip(self._gin, batch):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
+        self._graph.replay()
+        return self._gout
+
     @staticmethod
     def to_host(out: Dict[str, torch.Tensor], cfg: "TrainCfg") -> Dict[str, float]:
         """One synchronisation for a whole step (or epoch): device scalars -> the reference's metrics."""
