@@ -177,9 +177,9 @@ class AdversarialTrainer:
         """``step`` replayed from a captured hipGraph (single process only: the RCCL all-reduce stays eager).
 
         The ~650 kernel launches of a step leave the GPU idle for a few milliseconds between kernels when driven
-        from Python; a graph replay removes that.  The first call runs two eager steps (every lazily created
-        buffer, packed-weight cache and kernel attribute exists afterwards) and captures a third; later calls
-        copy the batch into the captured input buffers and replay.  Learning rates are baked into the capture
+        from Python; a graph replay removes that.  Every call advances exactly one step: the first two run eagerly
+        (every lazily created buffer, packed-weight cache and kernel attribute exists afterwards), the third
+        captures and replays, later calls copy the batch into the captured input buffers and replay.  Learning rates are baked into the capture
         (re-capture after changing them: ``self._graph = None``); Adam's step count lives on the device.
         Falls back to ``step`` if capture is not possible."""
         import torch.distributed as dist
@@ -187,15 +187,14 @@ class AdversarialTrainer:
             return self.step(img_a, mask_a_u8, vert_a, img_b, vert_b)
         batch = (img_a, mask_a_u8, vert_a, img_b, vert_b)
         if getattr(self, "_graph", None) is None:
-            if getattr(self, "_graph_failed", False):
-                return self.step(*batch)
+            self._gcalls = getattr(self, "_gcalls", 0) + 1
+            if getattr(self, "_graph_failed", False) or self._gcalls <= 2:
+                return self.step(*batch)       # calls 1 and 2: eager (every lazily created buffer exists afterwards)
             try:
-                for _ in range(2):
-                    self.step(*batch)
                 torch.cuda.synchronize()
                 self._gin = tuple(t.clone() for t in batch)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph):   # records only: nothing executes during capture
                     self._gout = self.step(*self._gin)
                 self._graph = graph
             except Exception as e:   # noqa: BLE001 -- any capture failure means: stay eager

@@ -106,3 +106,23 @@ def test_train_step_vs_reference_golden(dev, tag, cfg_kw, full):
                 # by up to 2*lr in either implementation -> allow half the elements to do so
                 slack = 0.5 * v.numel() * 2 * tr.cfg.lr if nm == "gen" else 0.0
                 assert abs(got_abs - ref_abs) <= 2e-3 * max(ref_abs, 1e-3) + 1e-6 + slack, (nm, k, got_abs, ref_abs)
+
+
+def test_graph_replay_matches_eager_steps(dev):
+    """AdversarialTrainer.step_graphed (hipGraph replay, Adam's step count on the device) walks the same
+    parameter trajectory as eager steps: two trainers from identical weights, five identical batches."""
+    from oracle.synth import synth_batch
+    cfg_kw = dict(filters=4, in_channels=1, n_class=4, pointnet=True, fc_inch=9)
+    cfg, tr_e = _build(cfg_kw, 7, dev)
+    _, tr_g = _build(cfg_kw, 7, dev)
+    batch = [torch.from_numpy(t).to(dev) for t in synth_batch(4, cfg.in_channels, cfg.n_class, 128, seed=300)]
+    for it in range(5):
+        out_e = tr_e.step(*batch)
+        out_g = tr_g.step_graphed(*batch)
+    assert getattr(tr_g, "_graph", None) is not None, "the step was not captured"
+    he, hg = tr_e.to_host(out_e, tr_e.cfg), tr_g.to_host(out_g, tr_g.cfg)
+    for k in ("seg_loss", "adv_loss"):
+        assert abs(he[k] - hg[k]) <= 1e-5 * max(1.0, abs(he[k])), (k, he[k], hg[k])
+    assert int(tr_g.opt_gen.step_t.item()) == int(tr_e.opt_gen.step_t.item()) == 5
+    assert rel_err(tr_g.opt_gen.p, tr_e.opt_gen.p) < 1e-6
+    assert rel_err(tr_g.opt_d4.p, tr_e.opt_d4.p) < 1e-6
