@@ -221,6 +221,14 @@ int pcuda_nn_loss_bwd(const float* x, const float* y, int b, int npts, const int
  * dice = mean_{c>=1} (2*sum(y*hard)+1)/(sum y + sum hard + 1).  workspace: 3*c doubles. */
 int pcuda_dice_metric(const float* logits, const uint8_t* onehot, int n, int c, long long hw, float* dice,
                       void* workspace, size_t workspace_bytes, pcuda_stream_t s);
+/* validation metrics (train_mscmrseg.py:85-92, metric.py:39-82): labels[n][i] = first channel holding the
+ * per-pixel maximum of x[n][c][i] (fp32 logits, or a uint8 one-hot mask when x_is_u8); strides in elements */
+int pcuda_argmax_labels(const void* x, int x_is_u8, long long sn, long long sc, int n, int c, long long hw,
+                        uint8_t* labels, pcuda_stream_t s);
+/* dice[k] = 2|pred==k & gt==k| / (|pred==k| + |gt==k|), 0 if both empty (medpy dc), k < c.
+ * workspace: 3*c 64-bit counters */
+int pcuda_label_dice(const uint8_t* pred, const uint8_t* gt, long long numel, int c, float* dice, void* workspace,
+                     size_t workspace_bytes, pcuda_stream_t s);
 
 /* ------------------------------------------------------------------------------------
  * small dense ops of PointNetCls / the point head (PointNetCls.py; unet.py:86,94-95)

@@ -484,6 +484,40 @@ def gold_step(tag, cfg: ON.SegCfg, b, hw, seed, n_steps=2, full=True):
     print(tag, "ok")
 
 
+def gold_valid(tag, cfg: ON.SegCfg, b, hw, seed):
+    """One iteration of valid_model_with_one_dataset (train_mscmrseg.py:67-92, re-typed around the REFERENCE
+    model in eval mode).  medpy is absent: its `dc` is restated (published definition) in oracle.metrics, and
+    soft_to_hard_pred / argmax are the reference's own numpy lines."""
+    from oracle import metrics as OM
+    from oracle import validate as OV
+    params = ON.make_params(ON.seg_param_shapes(cfg), seed)
+    img, mask, vert, _, _ = synth_batch(b, cfg.in_channels, cfg.n_class, hw, seed=seed + 1)
+    ref = load_into(ref_seg(cfg), params).eval()
+    with torch.no_grad():
+        prediction, _, vert_s = ref(torch.tensor(img))
+        yb = torch.tensor(mask, dtype=torch.float32)
+        l1 = torch.nn.BCELoss()(torch.sigmoid(prediction), yb)
+        l2 = ref_loss.jaccard_loss(logits=torch.sigmoid(prediction), true=yb, activation=False)
+        l3 = ref_loss.batch_NN_loss(x=vert_s, y=torch.tensor(vert))
+    y_pred = prediction.cpu().detach().numpy()
+    y_pred = np.where(y_pred == np.max(y_pred, axis=1, keepdims=True), 1, 0)      # utils.py:32-40
+    y_pred = np.argmax(np.moveaxis(y_pred, 1, -1), axis=-1)
+    y_gt = np.argmax(np.moveaxis(mask, 1, -1), axis=-1)
+    dice = [OM.binary_dc(np.clip(np.where(y_pred == c, y_pred, 0), 0, 1), np.clip(np.where(y_gt == c, y_gt, 0), 0, 1))
+            for c in (1, 2, 3)]                                                        # metric.py:57-73
+    o = OV.valid_batch(params, img, mask, vert, cfg)
+    close(torch.tensor(o["logits"]), prediction, 1e-5, tag + " eval logits")
+    close(torch.tensor(o["loss"]), l1 + l2 + l3, 1e-5, tag + " loss")
+    assert np.array_equal(o["labels"], y_pred.astype(np.uint8)), tag + " labels"
+    assert abs(o["dice"] - float(np.mean(dice))) < 1e-12, tag + " dice"
+    out = {"seed": np.int64(seed), "b": np.int64(b), "hw": np.int64(hw), "logits": prediction.numpy(),
+           "verts": vert_s.numpy(), "loss": np.float64(float(l1 + l2 + l3)), "vert_loss": np.float64(float(l3)),
+           "labels": y_pred.astype(np.uint8), "dice_per_class": np.array(dice, dtype=np.float64)}
+    np.savez_compressed(os.path.join(GOLD, tag + ".npz"), **out)
+    print("wrote", tag, "loss %.6f dice %s" % (out["loss"], np.round(dice, 4)))
+
+
+
 def main():
     gold_param_counts()
     gold_losses()
@@ -497,6 +531,7 @@ def main():
     gold_pncls("pncls", False, False, b=16, seed=300)
     gold_pncls("pncls_ft_ext", True, True, b=12, seed=310)
     gold_step("step_small", small, b=4, hw=128, seed=400, n_steps=2, full=True)
+    gold_valid("valid_small", small, b=3, hw=128, seed=700)
     if os.environ.get("GOLDEN_FULL", "1") == "1":
         full = ON.SegCfg(filters=32, in_channels=1, n_class=4, pointnet=True, fc_inch=121)
         gold_seg("seg_full256", full, b=2, hw=256, seed=500, full_tensors=False)

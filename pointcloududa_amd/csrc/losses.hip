@@ -511,3 +511,83 @@ extern "C" int pcuda_dice_metric(const float* logits, const uint8_t* onehot, int
   PCUDA_CHECK_LAUNCH("dice_final_kernel");
   return PCUDA_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// validation metrics (train_mscmrseg.py:85-92; metric.py:39-82): label maps and per-class Dice
+// ------------------------------------------------------------------------------------------
+// labels[n][i] = FIRST channel holding the per-pixel maximum (= np.argmax(soft_to_hard_pred(x), axis=-1))
+template <typename T>
+__global__ __launch_bounds__(256) void argmax_labels_kernel(const T* __restrict__ x, long long sn, long long sc, int c,
+                                                            long long hw, long long npix, uint8_t* __restrict__ lab) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < npix; i += 256ll * gridDim.x) {
+    const long long n = i / hw, q = i - n * hw;
+    const T* px = x + n * sn + q;
+    float best = (float)px[0];
+    int bi = 0;
+    for (int k = 1; k < c; ++k) {
+      const float v = (float)px[(long long)k * sc];
+      if (v > best) { best = v; bi = k; }
+    }
+    lab[i] = (uint8_t)bi;
+  }
+}
+
+// cnt[k][0..2] += (|pred==k & gt==k|, |pred==k|, |gt==k|), integer counts (order independent)
+__global__ __launch_bounds__(256) void label_overlap_kernel(const uint8_t* __restrict__ pred,
+                                                            const uint8_t* __restrict__ gt, long long numel, int c,
+                                                            unsigned long long* __restrict__ cnt) {
+  __shared__ unsigned int h[MAXC * 3];
+  for (int i = threadIdx.x; i < c * 3; i += 256) h[i] = 0;
+  __syncthreads();
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < numel; i += 256ll * gridDim.x) {
+    const int a = pred[i], b = gt[i];
+    if (a < c) atomicAdd(&h[a * 3 + 1], 1u);
+    if (b < c) atomicAdd(&h[b * 3 + 2], 1u);
+    if (a == b && a < c) atomicAdd(&h[a * 3 + 0], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < c * 3; i += 256)
+    if (h[i]) atomicAdd(&cnt[i], (unsigned long long)h[i]);
+}
+// medpy.metric.binary.dc: 2|A.B| / (|A| + |B|), 0 when both are empty
+__global__ void label_dice_final_kernel(const unsigned long long* __restrict__ cnt, int c, float* __restrict__ dice) {
+  const int k = threadIdx.x;
+  if (k < c) {
+    const double den = (double)cnt[k * 3 + 1] + (double)cnt[k * 3 + 2];
+    dice[k] = den > 0.0 ? (float)(2.0 * (double)cnt[k * 3 + 0] / den) : 0.f;
+  }
+}
+
+extern "C" int pcuda_argmax_labels(const void* x, int x_is_u8, long long sn, long long sc, int n, int c, long long hw,
+                                   uint8_t* labels, pcuda_stream_t s) {
+  if (!x || !labels || n <= 0 || c < 1 || c > 255 || hw <= 0) PCUDA_FAIL(PCUDA_E_BADARG, "argmax_labels: bad arguments");
+  const long long npix = (long long)n * hw;
+  const int blocks = (int)(cdiv(npix, 256) > 4096 ? 4096 : cdiv(npix, 256));
+  ProfScope prof(PCUDA_FAM_POINTWISE, (double)npix * ((x_is_u8 ? 1.0 : 4.0) * c + 1.0), (hipStream_t)s);
+  if (x_is_u8)
+    hipLaunchKernelGGL(argmax_labels_kernel<uint8_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const uint8_t*)x, sn,
+                       sc, c, hw, npix, labels);
+  else
+    hipLaunchKernelGGL(argmax_labels_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)x, sn, sc,
+                       c, hw, npix, labels);
+  PCUDA_CHECK_LAUNCH("argmax_labels_kernel");
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_label_dice(const uint8_t* pred, const uint8_t* gt, long long numel, int c, float* dice,
+                                void* workspace, size_t workspace_bytes, pcuda_stream_t s) {
+  if (!pred || !gt || !dice || numel <= 0 || c < 1 || c > MAXC) PCUDA_FAIL(PCUDA_E_BADARG, "label_dice: bad arguments");
+  if (!workspace || workspace_bytes < (size_t)c * 3 * sizeof(unsigned long long))
+    PCUDA_FAIL(PCUDA_E_WORKSPACE, "label_dice: workspace too small");
+  if (hipMemsetAsync(workspace, 0, (size_t)c * 3 * sizeof(unsigned long long), (hipStream_t)s) != hipSuccess)
+    PCUDA_FAIL(PCUDA_E_LAUNCH, "label_dice: memset failed");
+  const int blocks = (int)(cdiv(numel, 256) > 2048 ? 2048 : cdiv(numel, 256));
+  ProfScope prof(PCUDA_FAM_POINTWISE, 2.0 * (double)numel, (hipStream_t)s);
+  hipLaunchKernelGGL(label_overlap_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, pred, gt, numel, c,
+                     (unsigned long long*)workspace);
+  PCUDA_CHECK_LAUNCH("label_overlap_kernel");
+  hipLaunchKernelGGL(label_dice_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)s,
+                     (const unsigned long long*)workspace, c, dice);
+  PCUDA_CHECK_LAUNCH("label_dice_final_kernel");
+  return PCUDA_OK;
+}

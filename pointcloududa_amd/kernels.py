@@ -433,6 +433,34 @@ def dice_metric(logits, onehot):
     return out
 
 
+def argmax_labels(x):
+    """[N,C,H,W] fp32 logits or uint8 one-hot -> uint8 label map [N,H,W]: first channel holding the maximum."""
+    if x.dtype not in (torch.float32, torch.uint8):
+        raise TypeError("argmax_labels: fp32 logits or a uint8 one-hot mask")
+    _req(x, x.dtype)
+    n, c = x.shape[:2]
+    hw = x.numel() // (n * c)
+    if x.stride(-1) != 1 or (x.dim() == 4 and x.stride(2) != x.shape[3]):
+        x = x.contiguous()
+    lab = torch.empty((n,) + tuple(x.shape[2:]), dtype=torch.uint8, device=x.device)
+    check(L.lib().pcuda_argmax_labels(x.data_ptr(), 1 if x.dtype == torch.uint8 else 0, x.stride(0), x.stride(1), n, c,
+                                      hw, lab.data_ptr(), _stream()), "argmax_labels")
+    return lab
+
+
+def label_dice(pred_labels, gt_labels, num_classes):
+    """per-class Dice (medpy dc) of two uint8 label maps -> fp32 [num_classes] on the device"""
+    _req(pred_labels, torch.uint8); _req(gt_labels, torch.uint8)
+    if pred_labels.shape != gt_labels.shape:
+        raise ValueError("label_dice: shapes differ")
+    pred_labels, gt_labels = pred_labels.contiguous(), gt_labels.contiguous()
+    ws = torch.empty(3 * num_classes, dtype=torch.int64, device=pred_labels.device)
+    out = torch.empty(num_classes, dtype=torch.float32, device=pred_labels.device)
+    check(L.lib().pcuda_label_dice(pred_labels.data_ptr(), gt_labels.data_ptr(), pred_labels.numel(), num_classes,
+                                   out.data_ptr(), ws.data_ptr(), ws.numel() * 8, _stream()), "label_dice")
+    return out
+
+
 # ------------------------------------------------------------------------------------------
 # dense
 # ------------------------------------------------------------------------------------------

@@ -169,3 +169,35 @@ def test_oracle_step_vs_reference_golden():
               "d2_loss_tgt", "d1_loss_tgt", "d4_loss_tgt"):
         assert abs(out[k] - float(g["s0/" + k])) <= 2e-5 * max(1.0, abs(float(g["s0/" + k]))), k
     assert rel_err(orc.kept["oS"], g["s0/oS"]) < 1e-4 and rel_err(orc.kept["oT"], g["s0/oT"]) < 1e-4
+
+
+def test_oracle_validation_loop_matches_reference_golden():
+    """oracle.validate.valid_batch (train_mscmrseg.py:67-92 restated) against the values the REFERENCE model
+    produced in eval mode (oracle/make_golden.py:gold_valid)."""
+    from oracle import nets as ON
+    from oracle import validate as OV
+    from oracle.synth import synth_batch
+    g = np.load(os.path.join(GOLD, "valid_small.npz"))
+    cfg = ON.SegCfg(filters=4, in_channels=1, n_class=4, pointnet=True, fc_inch=9)
+    seed, b, hw = int(g["seed"]), int(g["b"]), int(g["hw"])
+    params = ON.make_params(ON.seg_param_shapes(cfg), seed)
+    img, mask, vert, _, _ = synth_batch(b, cfg.in_channels, cfg.n_class, hw, seed=seed + 1)
+    o = OV.valid_batch(params, img, mask, vert, cfg)
+    assert rel_err(o["logits"], g["logits"]) < 1e-5
+    assert abs(o["loss"] - float(g["loss"])) < 1e-5 and abs(o["vert_loss"] - float(g["vert_loss"])) < 1e-6
+    assert np.array_equal(o["labels"], g["labels"])
+    assert np.allclose(o["dice_per_class"][1:4], g["dice_per_class"], atol=1e-12)
+
+
+def test_validation_metrics_known_answers():
+    from oracle import metrics as OM
+    logits = np.zeros((1, 3, 1, 4), dtype=np.float32)
+    logits[0, :, 0, 0] = [0.2, 0.9, 0.9]      # tie between channels 1 and 2 -> first (1)
+    logits[0, :, 0, 1] = [5.0, -1.0, 2.0]
+    logits[0, :, 0, 2] = [-3.0, -2.0, -1.0]
+    logits[0, :, 0, 3] = [0.0, 0.0, 0.0]      # all equal -> 0
+    assert OM.argmax_labels(logits).tolist() == [[[1, 0, 2, 0]]]
+    pred = np.array([0, 1, 1, 2, 2, 2], dtype=np.uint8)
+    gt = np.array([0, 1, 2, 2, 2, 0], dtype=np.uint8)
+    dc = OM.label_dice(pred, gt, 4)
+    assert np.allclose(dc, [2 * 1 / 3, 2 * 1 / 3, 2 * 2 / 6, 0.0])   # class 3 empty on both sides -> 0
