@@ -63,6 +63,16 @@ class _FlatOptimizer:
     def zero_grad(self):
         self.g.zero_()
 
+    # ---- torch.optim-format state (what the reference's checkpoints hold: callbacks.py:61-94)
+    def _slices(self):
+        """(offset, numel, shape) of every parameter inside the flat buffers, in module.parameters() order --
+        the order torch.optim indexes its state by when built from ``model.parameters()``"""
+        out, total = [], 0
+        for p in self.module.parameters():
+            out.append((total, p.numel(), tuple(p.shape)))
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        return out
+
     def all_reduce_grads(self, group=None):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -89,6 +99,36 @@ class FusedAdam(_FlatOptimizer):
     def state_dict(self):
         return {"steps": int(self.step_t.item()), "lr": self.lr, "exp_avg": self.m, "exp_avg_sq": self.v}
 
+    def torch_state_dict(self):
+        """The state in ``torch.optim.Adam.state_dict()`` form (loadable by the reference's optimiser)."""
+        step = int(self.step_t.item())
+        state = {}
+        if step > 0:
+            for i, (o, n, shp) in enumerate(self._slices()):
+                state[i] = {"step": torch.tensor(float(step)), "exp_avg": self.m[o:o + n].view(shp).clone(),
+                            "exp_avg_sq": self.v[o:o + n].view(shp).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(self._slices())))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_torch_state_dict(self, sd):
+        """Inverse of ``torch_state_dict``: accepts what ``torch.optim.Adam.state_dict()`` (any torch >= 1.4) holds."""
+        g = sd["param_groups"][0]
+        self.lr = float(g["lr"]); self.betas = tuple(g["betas"]); self.eps = float(g["eps"])
+        self.wd = float(g.get("weight_decay", 0.0))
+        self.m.zero_(); self.v.zero_()
+        step = 0
+        for i, (o, n, shp) in enumerate(self._slices()):
+            st = sd["state"].get(i, sd["state"].get(str(i)))
+            if st is None:
+                continue
+            self.m[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            self.v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            step = max(step, int(float(st["step"])))
+        self.step_t.fill_(step)
+        self.steps = step
+
 
 class FusedSGD(_FlatOptimizer):
     def __init__(self, module, lr=2.5e-5, momentum=0.99, weight_decay=0.0005):
@@ -103,3 +143,27 @@ class FusedSGD(_FlatOptimizer):
 
     def state_dict(self):
         return {"steps": self.steps, "lr": self.lr, "momentum_buffer": self.buf}
+
+    def torch_state_dict(self):
+        """The state in ``torch.optim.SGD.state_dict()`` form."""
+        state = {}
+        if self.buf is not None and self.steps > 0:
+            for i, (o, n, shp) in enumerate(self._slices()):
+                state[i] = {"momentum_buffer": self.buf[o:o + n].view(shp).clone()}
+        group = {"lr": self.lr, "momentum": self.momentum, "dampening": 0, "weight_decay": self.wd, "nesterov": False,
+                 "maximize": False, "foreach": None, "differentiable": False, "fused": None,
+                 "params": list(range(len(self._slices())))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_torch_state_dict(self, sd):
+        g = sd["param_groups"][0]
+        self.lr = float(g["lr"]); self.momentum = float(g.get("momentum", 0.0)); self.wd = float(g.get("weight_decay", 0.0))
+        loaded = False
+        if self.buf is not None:
+            self.buf.zero_()
+            for i, (o, n, shp) in enumerate(self._slices()):
+                st = sd["state"].get(i, sd["state"].get(str(i)))
+                if st is not None and st.get("momentum_buffer") is not None:
+                    self.buf[o:o + n].copy_(st["momentum_buffer"].reshape(-1))
+                    loaded = True
+        self.steps = 1 if loaded else 0   # "first step" only decides whether the momentum buffer is initialised
