@@ -221,6 +221,12 @@ int pcuda_nn_loss_bwd(const float* x, const float* y, int b, int npts, const int
  * dice = mean_{c>=1} (2*sum(y*hard)+1)/(sum y + sum hard + 1).  workspace: 3*c doubles. */
 int pcuda_dice_metric(const float* logits, const uint8_t* onehot, int n, int c, long long hw, float* dice,
                       void* workspace, size_t workspace_bytes, pcuda_stream_t s);
+/* loader-side batch assembly (data_generator_mmwhs.py:265-272, utils.py:7-29, crop_volume :134-137): centre crop
+ * (crop = the generator's crop_size, 0 = none), channel-last -> channel-first and integer labels -> one-hot uint8
+ * in one pass.  images_hwc [b][h][w][c] fp32, mask_labels [b][h][w] int32 (may be NULL together with onehot),
+ * outputs images_chw [b][c][oh][ow], onehot [b][num_classes][oh][ow] */
+int pcuda_assemble_batch(const float* images_hwc, const int* mask_labels, int b, int h, int w, int c, int crop,
+                         int num_classes, float* images_chw, uint8_t* onehot, pcuda_stream_t s);
 /* validation metrics (train_mscmrseg.py:85-92, metric.py:39-82): labels[n][i] = first channel holding the
  * per-pixel maximum of x[n][c][i] (fp32 logits, or a uint8 one-hot mask when x_is_u8); strides in elements */
 int pcuda_argmax_labels(const void* x, int x_is_u8, long long sn, long long sc, int n, int c, long long hw,

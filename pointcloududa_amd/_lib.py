@@ -76,6 +76,7 @@ _PROTOS = {
     "pcuda_nn_loss_fwd": (i32, [vp, vp, i32, i32, vp, vp, vp, vp]),
     "pcuda_nn_loss_bwd": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp]),
     "pcuda_dice_metric": (i32, [vp, vp, i32, i32, i64, vp, vp, sz, vp]),
+    "pcuda_assemble_batch": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     "pcuda_argmax_labels": (i32, [vp, i32, i64, i64, i32, i32, i64, vp, vp]),
     "pcuda_label_dice": (i32, [vp, vp, i64, i32, vp, vp, sz, vp]),
     "pcuda_linear_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),

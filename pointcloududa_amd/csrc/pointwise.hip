@@ -556,3 +556,47 @@ extern "C" int pcuda_mul(const float* a, const float* b, float* y, long long num
   PCUDA_CHECK_LAUNCH("mul_kernel");
   return PCUDA_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// loader-side batch assembly (data_generator_mmwhs.py:265-272, utils.py:7-29): centre crop, channel-last ->
+// channel-first, labels -> one-hot uint8, in one pass over the batch
+// ------------------------------------------------------------------------------------------
+// img_out[b][c][y][x] = img_in[b][y0 + y][x0 + x][c];  onehot[b][k][y][x] = (mask[b][y0 + y][x0 + x] == k)
+__global__ __launch_bounds__(256) void assemble_batch_kernel(const float* __restrict__ img_in, const int* __restrict__ mask,
+                                                             int b, int h, int w, int c, int y0, int x0, int oh, int ow,
+                                                             int k, float* __restrict__ img_out,
+                                                             uint8_t* __restrict__ onehot) {
+  const long long npix = (long long)b * oh * ow;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < npix; i += 256ll * gridDim.x) {
+    const int x = (int)(i % ow);
+    const long long t = i / ow;
+    const int y = (int)(t % oh), n = (int)(t / oh);
+    const long long src = ((long long)n * h + (y0 + y)) * w + (x0 + x);
+    const long long plane = (long long)oh * ow, dst = (long long)y * ow + x;
+    for (int ch = 0; ch < c; ++ch) img_out[((long long)n * c + ch) * plane + dst] = img_in[src * c + ch];
+    if (onehot) {
+      const int lab = mask[src];
+      for (int kk = 0; kk < k; ++kk) onehot[((long long)n * k + kk) * plane + dst] = (uint8_t)(lab == kk);
+    }
+  }
+}
+
+extern "C" int pcuda_assemble_batch(const float* images_hwc, const int* mask_labels, int b, int h, int w, int c,
+                                    int crop, int num_classes, float* images_chw, uint8_t* onehot, pcuda_stream_t s) {
+  if (!images_hwc || !images_chw || b <= 0 || h <= 0 || w <= 0 || c <= 0 || (onehot && (!mask_labels || num_classes < 2)))
+    PCUDA_FAIL(PCUDA_E_BADARG, "assemble_batch: bad arguments");
+  // ImageProcessor.crop_volume(vol, crop_size = crop // 2): [H/2 - crop//2, H/2 + crop//2)
+  int y0 = 0, x0 = 0, oh = h, ow = w;
+  if (crop > 0) {
+    const int hc = crop / 2;
+    y0 = h / 2 - hc; x0 = w / 2 - hc; oh = 2 * hc; ow = 2 * hc;
+    if (y0 < 0 || x0 < 0 || y0 + oh > h || x0 + ow > w) PCUDA_FAIL(PCUDA_E_BADARG, "assemble_batch: crop larger than the image");
+  }
+  const long long npix = (long long)b * oh * ow;
+  const int blocks = (int)(cdiv(npix, 256) > 4096 ? 4096 : cdiv(npix, 256));
+  ProfScope prof(PCUDA_FAM_POINTWISE, (double)npix * (8.0 * c + (onehot ? 4.0 + num_classes : 0.0)), (hipStream_t)s);
+  hipLaunchKernelGGL(assemble_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, images_hwc, mask_labels, b, h, w,
+                     c, y0, x0, oh, ow, num_classes, images_chw, onehot);
+  PCUDA_CHECK_LAUNCH("assemble_batch_kernel");
+  return PCUDA_OK;
+}

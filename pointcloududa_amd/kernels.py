@@ -433,6 +433,25 @@ def dice_metric(logits, onehot):
     return out
 
 
+def assemble_batch(images_hwc, mask_labels, num_classes, crop=0):
+    """[B,H,W,C] fp32 images (+ [B,H,W] int32 labels) -> ([B,C,h,w] fp32, [B,K,h,w] uint8 one-hot | None)."""
+    _req(images_hwc)
+    images_hwc = images_hwc.contiguous()
+    b, h, w, c = images_hwc.shape
+    oh, ow = (2 * (crop // 2), 2 * (crop // 2)) if crop else (h, w)
+    out = torch.empty((b, c, oh, ow), dtype=torch.float32, device=images_hwc.device)
+    onehot = None
+    if mask_labels is not None:
+        _req(mask_labels, torch.int32)
+        mask_labels = mask_labels.contiguous()
+        if tuple(mask_labels.shape) != (b, h, w):
+            raise ValueError("assemble_batch: mask shape %r does not match the images" % (tuple(mask_labels.shape),))
+        onehot = torch.empty((b, num_classes, oh, ow), dtype=torch.uint8, device=images_hwc.device)
+    check(L.lib().pcuda_assemble_batch(images_hwc.data_ptr(), _ptr(mask_labels), b, h, w, c, int(crop), int(num_classes),
+                                       out.data_ptr(), _ptr(onehot), _stream()), "assemble_batch")
+    return out, onehot
+
+
 def argmax_labels(x):
     """[N,C,H,W] fp32 logits or uint8 one-hot -> uint8 label map [N,H,W]: first channel holding the maximum."""
     if x.dtype not in (torch.float32, torch.uint8):

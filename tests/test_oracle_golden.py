@@ -201,3 +201,15 @@ def test_validation_metrics_known_answers():
     gt = np.array([0, 1, 2, 2, 2, 0], dtype=np.uint8)
     dc = OM.label_dice(pred, gt, 4)
     assert np.allclose(dc, [2 * 1 / 3, 2 * 1 / 3, 2 * 2 / 6, 0.0])   # class 3 empty on both sides -> 0
+
+
+def test_batch_assembly_known_answers():
+    """oracle.batch (data_generator_mmwhs.py:265-274, utils.py:7-29) on hand-checkable inputs."""
+    from oracle import batch as OB
+    img = np.arange(2 * 6 * 6 * 3, dtype=np.float32).reshape(2, 6, 6, 3)
+    m = (np.arange(2 * 6 * 6).reshape(2, 6, 6, 1) % 5).astype(np.int64)
+    im, oh, v = OB.assemble_batch(img, m, [[[255, 0, 51]]] * 2, num_classes=5, crop_size=4)
+    assert im.shape == (2, 3, 4, 4) and oh.shape == (2, 5, 4, 4) and oh.dtype == np.uint8
+    assert im[1, 2, 0, 0] == img[1, 1, 1, 2] and im[0, 0, 3, 3] == img[0, 4, 4, 0]      # rows/cols 1..4 survive
+    assert oh.sum(1).min() == 1 and oh.sum(1).max() == 1 and oh[0, m[0, 1, 1, 0], 0, 0] == 1
+    assert np.allclose(v[0, 0], [1.0, 0.0, 0.2])
