@@ -484,6 +484,110 @@ def gold_step(tag, cfg: ON.SegCfg, b, hw, seed, n_steps=2, full=True):
     print(tag, "ok")
 
 
+def ref_step_mmwhs(gen, d1, d2, d4, opt_g, opt1, opt2, opt4, batch, dr, wp, w1, w2, w4):
+    """One iteration of train_epoch's loop, re-typed from train_mmwhs.py:187-360 around the imported reference
+    modules (-softmax, no -etpls/-Tetpls/-d4aux; CPU tensors instead of .cuda(); host metrics omitted)."""
+    import math
+    img_a, mask_a, vert_a, img_b, vert_b = batch
+    smooth = 1e-7
+    res = {}
+    opt_g.zero_grad()
+    for o, m in ((opt1, d1), (opt2, d2), (opt4, d4)):
+        o.zero_grad()
+        for p in m.parameters():
+            p.requires_grad = False
+    for p in gen.parameters():
+        p.requires_grad = True
+    o_s, _, v_s = gen(torch.from_numpy(img_a).float())
+    pred_s = F.softmax(o_s, dim=1)
+    l_seg = F.cross_entropy(pred_s, torch.from_numpy(np.argmax(mask_a, axis=1)).long())
+    l_seg2 = ref_loss.jaccard_loss(logits=pred_s, true=torch.from_numpy(mask_a).float(), activation=False)
+    l_seg3 = ref_loss.batch_NN_loss(x=v_s, y=torch.from_numpy(vert_a).float())
+    res["ver_s_loss"] = l_seg3.item()
+    c = pred_s.size()[1]
+    emap_s = -1.0 * pred_s * torch.log(pred_s + smooth) / math.log(c)
+    res["entropy_s"] = torch.mean(torch.sum(emap_s, dim=1)).item()
+    (l_seg + l_seg2 + wp * l_seg3 + 0).backward()
+    res["seg_loss"] = (l_seg + l_seg2).item()
+    res["grad_seg"] = {k: p.grad.clone() for k, p in gen.named_parameters() if p.grad is not None}
+    o_t, _, v_t = gen(torch.from_numpy(img_b).float())
+    pred_t = F.softmax(o_t, dim=1)
+    emap_t = -1.0 * pred_t * torch.log(pred_t + smooth) / math.log(pred_t.size()[1])
+    res["entropy_t"] = torch.mean(torch.sum(emap_t, dim=1)).item()
+    do = d2(emap_t)
+    a2 = dr * F.binary_cross_entropy_with_logits(do, torch.FloatTensor(do.data.size()).fill_(1))
+    res["ver_t_loss"] = ref_loss.batch_NN_loss(x=v_t, y=torch.from_numpy(vert_b).float()).item()
+    do = d4(v_t.transpose(2, 1))[0]
+    a4 = dr * F.binary_cross_entropy_with_logits(do, torch.FloatTensor(do.data.size()).fill_(1))
+    do = d1(pred_t)
+    a1 = dr * F.binary_cross_entropy_with_logits(do, torch.FloatTensor(do.data.size()).fill_(1))
+    adv = 0 + w2 * a2 + w4 * a4 + w1 * a1
+    res["adv_loss"] = adv.item()
+    adv.backward()
+    res["grad_total"] = {k: p.grad.clone() for k, p in gen.named_parameters() if p.grad is not None}
+    opt_g.step()
+    for m in (d1, d2, d4):
+        for p in m.parameters():
+            p.requires_grad = True
+    for p in gen.parameters():
+        p.requires_grad = False
+    for tag, lbl, em, pr, vx in (("src", 1, emap_s, pred_s, v_s), ("tgt", 0, emap_t, pred_t, v_t)):
+        do = d2(em.detach())
+        l = F.binary_cross_entropy_with_logits(do, torch.FloatTensor(do.data.size()).fill_(lbl)); l.backward()
+        res["d2_loss_" + tag] = l.item()
+        do = d1(pr.detach())
+        l = F.binary_cross_entropy_with_logits(do, torch.FloatTensor(do.data.size()).fill_(lbl)); l.backward()
+        res["d1_loss_" + tag] = l.item()
+        do = d4(vx.detach().transpose(2, 1))[0]
+        l = F.binary_cross_entropy_with_logits(do, torch.FloatTensor(do.data.size()).fill_(lbl)); l.backward()
+        res["d4_loss_" + tag] = l.item()
+    for nm, m in (("grad_d1", d1), ("grad_d2", d2), ("grad_d4", d4)):
+        res[nm] = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    for o in (opt1, opt2, opt4):
+        o.step()
+    res["oS"], res["oT"] = o_s.detach(), o_t.detach()
+    res["vertS"], res["vertT"] = v_s.detach(), v_t.detach()
+    return res
+
+
+def gold_step_mmwhs(tag, cfg: ON.SegCfg, b, hw, seed):
+    """The MM-WHS loop (train_mmwhs.py:187-360, optimisers :453-489) with the repository README's point-cloud
+    discriminator PointNetCls(feature_transform=True, ext=True): one step from identical parameters."""
+    scfg = StepCfg(variant="mmwhs", d1=True, d2=True, d4=True, n_class=cfg.n_class, softmax=True, d_momentum=0.95,
+                   pn_feature_transform=True, pn_ext=True)
+    pg = ON.make_params(ON.seg_param_shapes(cfg), seed)
+    p1 = ON.make_params(ON.disc_param_shapes(cfg.n_class), seed + 1, std=0.02)
+    p2 = ON.make_params(ON.disc_param_shapes(cfg.n_class), seed + 2, std=0.02)
+    p4 = ON.make_params(ON.pointnet_cls_param_shapes(feature_transform=True, ext=True), seed + 3)
+    gen = load_into(ref_seg(cfg), pg).train()
+    d1 = load_into(UncertaintyDiscriminator(in_channel=cfg.n_class), p1).train()
+    d2 = load_into(UncertaintyDiscriminator(in_channel=cfg.n_class), p2).train()
+    d4 = load_into(PointNetCls(feature_transform=True, ext=True, drop=0.0), p4).train()
+    og = torch.optim.Adam(gen.parameters(), lr=scfg.lr, betas=(0.9, 0.99))
+    mk = lambda m, lr: torch.optim.SGD(m.parameters(), lr=lr, momentum=.95, weight_decay=.0005)
+    o1, o2, o4 = mk(d1, scfg.d1lr), mk(d2, scfg.d2lr), mk(d4, scfg.d4lr)
+    orc = OracleTrainer(cfg, scfg, pg, p1, p2, p4)
+    batch = synth_batch(b, cfg.in_channels, cfg.n_class, hw, seed=seed + 100)
+    r = ref_step_mmwhs(gen, d1, d2, d4, og, o1, o2, o4, batch, scfg.dr, scfg.wp, scfg.w1, scfg.w2, scfg.w4)
+    q = orc.step(*batch, keep=True)
+    out = {"seed": np.int64(seed), "b": np.int64(b), "hw": np.int64(hw)}
+    for k in ("seg_loss", "ver_s_loss", "ver_t_loss", "adv_loss", "d2_loss_src", "d1_loss_src", "d4_loss_src",
+              "d2_loss_tgt", "d1_loss_tgt", "d4_loss_tgt"):
+        close(torch.tensor(q[k]), torch.tensor(r[k]), 2e-5, "%s %s" % (tag, k))
+        out[k] = np.float64(r[k])
+    close(orc.kept["oS"], r["oS"], 1e-4, tag + " oS"); close(orc.kept["oT"], r["oT"], 1e-4, tag + " oT")
+    close(orc.kept["vertS"], r["vertS"], 1e-4, tag + " vertS")
+    for nm in ("grad_seg", "grad_total", "grad_d1", "grad_d2", "grad_d4"):
+        for k, g in r[nm].items():
+            close(orc.kept[nm][k], g, 1e-3, "%s %s %s" % (tag, nm, k))
+            out["%s_norm/%s" % (nm, k)] = np.float64(g.double().norm().item())
+    out["oS_s"], out["oT_s"] = sample(r["oS"]), sample(r["oT"])      # strided samples keep the fixture small
+    out["vertS"], out["vertT"] = r["vertS"].numpy(), r["vertT"].numpy()
+    np.savez_compressed(os.path.join(GOLD, tag + ".npz"), **out)
+    print(tag, "ok", {k: round(float(out[k]), 5) for k in ("seg_loss", "adv_loss", "d4_loss_src")})
+
+
+
 def gold_valid(tag, cfg: ON.SegCfg, b, hw, seed):
     """One iteration of valid_model_with_one_dataset (train_mscmrseg.py:67-92, re-typed around the REFERENCE
     model in eval mode).  medpy is absent: its `dc` is restated (published definition) in oracle.metrics, and
@@ -532,6 +636,8 @@ def main():
     gold_pncls("pncls_ft_ext", True, True, b=12, seed=310)
     gold_step("step_small", small, b=4, hw=128, seed=400, n_steps=2, full=True)
     gold_valid("valid_small", small, b=3, hw=128, seed=700)
+    gold_step_mmwhs("step_mmwhs_small", ON.SegCfg(filters=4, in_channels=3, n_class=5, pointnet=True, fc_inch=9), b=8,
+                    hw=128, seed=800)
     if os.environ.get("GOLDEN_FULL", "1") == "1":
         full = ON.SegCfg(filters=32, in_channels=1, n_class=4, pointnet=True, fc_inch=121)
         gold_seg("seg_full256", full, b=2, hw=256, seed=500, full_tensors=False)

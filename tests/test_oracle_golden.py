@@ -213,3 +213,26 @@ def test_batch_assembly_known_answers():
     assert im[1, 2, 0, 0] == img[1, 1, 1, 2] and im[0, 0, 3, 3] == img[0, 4, 4, 0]      # rows/cols 1..4 survive
     assert oh.sum(1).min() == 1 and oh.sum(1).max() == 1 and oh[0, m[0, 1, 1, 0], 0, 0] == 1
     assert np.allclose(v[0, 0], [1.0, 0.0, 0.2])
+
+
+def test_oracle_mmwhs_step_vs_reference_golden():
+    """the MM-WHS variant of the step (train_mmwhs.py:187-360: softmax + double-softmax CE, normalised entropy
+    map, w1/w2/w4, PointNetCls(feature_transform, ext)) against the loop re-typed around the reference modules"""
+    from oracle import nets as ON
+    from oracle.step import OracleTrainer, StepCfg
+    from oracle.synth import synth_batch
+    g = _g("step_mmwhs_small")
+    seed, b, hw = int(g["seed"]), int(g["b"]), int(g["hw"])
+    cfg = ON.SegCfg(filters=4, in_channels=3, n_class=5, pointnet=True, fc_inch=9)
+    scfg = StepCfg(variant="mmwhs", n_class=5, softmax=True, d_momentum=0.95, pn_feature_transform=True, pn_ext=True)
+    orc = OracleTrainer(cfg, scfg, ON.make_params(ON.seg_param_shapes(cfg), seed),
+                        ON.make_params(ON.disc_param_shapes(5), seed + 1, std=0.02),
+                        ON.make_params(ON.disc_param_shapes(5), seed + 2, std=0.02),
+                        ON.make_params(ON.pointnet_cls_param_shapes(feature_transform=True, ext=True), seed + 3))
+    out = orc.step(*synth_batch(b, 3, 5, hw, seed=seed + 100), keep=True)
+    for k in ("seg_loss", "ver_s_loss", "ver_t_loss", "adv_loss", "d2_loss_src", "d1_loss_src", "d4_loss_src",
+              "d2_loss_tgt", "d1_loss_tgt", "d4_loss_tgt"):
+        assert abs(out[k] - float(g[k])) <= 2e-5 * max(1.0, abs(float(g[k]))), k
+    f = orc.kept["oS"].reshape(-1)
+    assert rel_err(f[::max(1, f.numel() // 4096)][:4096], g["oS_s"]) < 1e-4
+    assert rel_err(orc.kept["vertS"], g["vertS"]) < 1e-4

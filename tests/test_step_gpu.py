@@ -126,3 +126,43 @@ def test_graph_replay_matches_eager_steps(dev):
     assert int(tr_g.opt_gen.step_t.item()) == int(tr_e.opt_gen.step_t.item()) == 5
     assert rel_err(tr_g.opt_gen.p, tr_e.opt_gen.p) < 1e-6
     assert rel_err(tr_g.opt_d4.p, tr_e.opt_d4.p) < 1e-6
+
+
+def test_mmwhs_variant_step_vs_reference_golden(dev):
+    """The MM-WHS loop (train_mmwhs.py:187-360; SURVEY config 4 in miniature: 3-channel input, 5 classes, softmax
+    mode, PointNetCls(feature_transform=True, ext=True), discriminator momentum 0.95) on the HIP kernels against
+    the loop re-typed around the reference modules."""
+    from oracle import nets as ON
+    from oracle.synth import synth_batch
+    from pointcloududa_amd.networks import PointNetCls, Segmentation_model_Point, UncertaintyDiscriminator
+    from pointcloududa_amd.train_step import AdversarialTrainer, TrainCfg
+    from test_networks_gpu import _strided
+    g = np.load(os.path.join(GOLD, "step_mmwhs_small.npz"))
+    seed, b, hw = int(g["seed"]), int(g["b"]), int(g["hw"])
+    cfg_kw = dict(filters=4, in_channels=3, n_class=5, pointnet=True, fc_inch=9)
+    cfg = ON.SegCfg(**cfg_kw)
+    load = lambda m, p: (m.load_state_dict({k: v.clone() for k, v in p.items()}), m.to(dev).train())[1]
+    gen = load(Segmentation_model_Point(**cfg_kw), ON.make_params(ON.seg_param_shapes(cfg), seed))
+    d1 = load(UncertaintyDiscriminator(in_channel=5), ON.make_params(ON.disc_param_shapes(5), seed + 1, std=0.02))
+    d2 = load(UncertaintyDiscriminator(in_channel=5), ON.make_params(ON.disc_param_shapes(5), seed + 2, std=0.02))
+    d4 = load(PointNetCls(feature_transform=True, ext=True, drop=0.0),
+              ON.make_params(ON.pointnet_cls_param_shapes(feature_transform=True, ext=True), seed + 3))
+    tr = AdversarialTrainer(gen, d1, d2, d4, TrainCfg(variant="mmwhs", n_class=5, softmax=True, d_momentum=0.95))
+    batch = [torch.from_numpy(t).to(dev) for t in synth_batch(b, 3, 5, hw, seed=seed + 100)]
+    out = tr.step(*batch, keep=True)
+    h = AdversarialTrainer.to_host(out, tr.cfg)
+    for k in ("seg_loss", "ver_s_loss", "ver_t_loss", "adv_loss", "d2_loss_src", "d1_loss_src", "d4_loss_src",
+              "d2_loss_tgt", "d1_loss_tgt", "d4_loss_tgt"):
+        ref = float(g[k])
+        assert abs(h[k] - ref) <= 2e-2 * max(1e-3, abs(ref)), (k, h[k], ref)
+    last = tr.last
+    assert rel_err(_strided(last["oS"]), g["oS_s"]) < 1e-3 and rel_err(_strided(last["oT"]), g["oT_s"]) < 1e-3
+    assert rel_err(last["vertS"], g["vertS"]) < 1e-3 and rel_err(last["vertT"], g["vertT"]) < 1e-3
+    for nm, mod, snap, lim in (("grad_seg", tr.gen, last["grad_seg"], 3e-2), ("grad_d1", tr.dis1, last["grad_d1"], 3e-2),
+                               ("grad_d2", tr.dis2, last["grad_d2"], 3e-2), ("grad_d4", tr.dis4, last["grad_d4"], 0.15)):
+        tot_ref = tot_got = 0.0
+        for k, (off, n) in _flat_norms(None, mod).items():
+            key = "%s_norm/%s" % (nm, k)
+            if key in g:
+                tot_ref += float(g[key]) ** 2; tot_got += float(snap[off:off + n].double().norm()) ** 2
+        assert abs(tot_got ** 0.5 - tot_ref ** 0.5) <= lim * tot_ref ** 0.5, (nm, tot_got ** 0.5, tot_ref ** 0.5)
