@@ -158,7 +158,11 @@ extern "C" int pcuda_conv2d_wgrad(const pcuda_conv_geom* g, int prec, const pcud
     // software-pipelined variants hold the next tile's loads in registers: input tiles <= 256*PF pixels
     static int nopipe = -1;
     if (nopipe < 0) { const char* e = getenv("PCUDA_NOPIPE"); nopipe = (e && atoi(e)) ? 1 : 0; }
-    const int pf = (nopipe || !fast_src_ok(x, g->cin)) ? 0 : (x_cap <= 256 ? 1 : (x_cap <= 768 ? 3 : 0));
+    int pf = (nopipe || !fast_src_ok(x, g->cin)) ? 0 : (x_cap <= 256 ? 1 : (x_cap <= 768 ? 3 : 0));
+    // 16-tap groups (4x4 kernels): LDS leaves room for one workgroup per CU, so make it eight waves
+    static int now8 = -1;
+    if (now8 < 0) { const char* e = getenv("PCUDA_WG_NO8"); now8 = (e && atoi(e)) ? 1 : 0; }
+    if (!now8 && pf > 0 && w.taps_per_group > 9 && x_cap <= 1024) pf = 100 + (x_cap <= 512 ? 1 : 2);
     snprintf(tag, sizeof(tag), "wgrad n%d cin%d cout%d %dx%d k%d s%d d%d ksplit%d clamp%d pf%d lds%zu", g->n, g->cin,
              g->cout, g->out_h, g->out_w, g->k, g->stride, g->dil, w.ksplit, clamp ? 1 : 0, pf, lds);
     ProfScope prof(PCUDA_FAM_CONV_WGRAD, flops, s, tag);

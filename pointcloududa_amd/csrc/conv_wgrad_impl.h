@@ -42,16 +42,16 @@ __device__ __forceinline__ WTile wtile_decode(const WgradParams& p, int tile) {
 // dZ tile [CO_TILE][128 px] in natural (pixel-contiguous) order: every thread owns CO_TILE/16 octets
 // (row = item >> 4, 8 consecutive tile slots).  issue = the global loads only (values stay in
 // registers), commit = mask, db partial sums, bf16 hi/lo split, LDS write.
-template <int CO_TILE>
-__device__ __forceinline__ void zpre_issue(float (&zv)[CO_TILE / 16][8], const WgradParams& p, const WTile& t,
+template <int CO_TILE, int NT = 256>
+__device__ __forceinline__ void zpre_issue(float (&zv)[CO_TILE * 16 / NT][8], const WgradParams& p, const WTile& t,
                                            int cot, int tid0) {
   // (opaque zero: keeps the per-element tile coordinates of the generic path from being hoisted out of the
   // tile loop -- 64 loop-invariant registers that were spilled to scratch and reloaded every tile)
   const int tid = tid0 + opaque_zero();
   const int TW = p.tw, TPIX = p.tw * p.th;
 #pragma unroll
-  for (int j = 0; j < CO_TILE / 16; ++j) {
-    const int item = tid + 256 * j;
+  for (int j = 0; j < CO_TILE * 16 / NT; ++j) {
+    const int item = tid + NT * j;
     const int row = item >> 4, oct = item & 15;
     const int pl = oct * 8;
     const int cco = min(cot * CO_TILE + row, p.cout - 1);
@@ -79,30 +79,30 @@ __device__ __forceinline__ void zpre_issue(float (&zv)[CO_TILE / 16][8], const W
 // offsets inside the image are computed once per kernel, a tile adds its (uniform) origin and, on edge
 // tiles, one clamp correction shared by all of the lane's octets.  (The wide raw_buffer_load builtins
 // of this hipcc compile to single-dword loads, so these stay flat float4 loads + a mask at commit.)
-template <int CO_TILE>
+template <int CO_TILE, int NT = 256>
 struct ZConst {
-  int off[CO_TILE / 16];
+  int off[CO_TILE * 16 / NT];
   int ty, tx;
 };
-template <int CO_TILE>
-__device__ __forceinline__ void zfast_init(ZConst<CO_TILE>& zc, const WgradParams& p, int cot, int tid) {
+template <int CO_TILE, int NT = 256>
+__device__ __forceinline__ void zfast_init(ZConst<CO_TILE, NT>& zc, const WgradParams& p, int cot, int tid) {
   const int pl = (tid & 15) * 8;
   zc.ty = IG_TY(pl, p.tmagic); zc.tx = pl - zc.ty * p.tw;
 #pragma unroll
-  for (int j = 0; j < CO_TILE / 16; ++j) {
-    const int co = min(cot * CO_TILE + ((tid + 256 * j) >> 4), p.cout - 1);
+  for (int j = 0; j < CO_TILE * 16 / NT; ++j) {
+    const int co = min(cot * CO_TILE + ((tid + NT * j) >> 4), p.cout - 1);
     zc.off[j] = co * (int)p.dz_sc + zc.ty * p.out_w + zc.tx;
   }
 }
-template <int CO_TILE>
-__device__ __forceinline__ void zfast_issue(float (&zv)[CO_TILE / 16][8], const ZConst<CO_TILE>& zc,
+template <int CO_TILE, int NT = 256>
+__device__ __forceinline__ void zfast_issue(float (&zv)[CO_TILE * 16 / NT][8], const ZConst<CO_TILE, NT>& zc,
                                             const WgradParams& p, const WTile& t) {
   const float* tb = p.dz + (long long)t.n * p.dz_sn + (long long)(t.y0 * p.out_w + t.x0);   // uniform
   const int cy = min(t.y0 + zc.ty, p.out_h - 1) - (t.y0 + zc.ty);   // <= 0 on edge tiles only
   const int cx = min(t.x0 + zc.tx, p.out_w - 8) - (t.x0 + zc.tx);
   const int dl = cy * p.out_w + cx;
 #pragma unroll
-  for (int j = 0; j < CO_TILE / 16; ++j) {
+  for (int j = 0; j < CO_TILE * 16 / NT; ++j) {
     const float* rp = tb + (zc.off[j] + dl);
     const float4 a = *(const float4*)rp, b = *(const float4*)(rp + 4);
     zv[j][0] = a.x; zv[j][1] = a.y; zv[j][2] = a.z; zv[j][3] = a.w;
@@ -110,16 +110,16 @@ __device__ __forceinline__ void zfast_issue(float (&zv)[CO_TILE / 16][8], const 
   }
 }
 
-template <bool X3, int CO_TILE>
-__device__ __forceinline__ void zpre_commit(float (&zv)[CO_TILE / 16][8], const WgradParams& p, const WTile& t,
+template <bool X3, int CO_TILE, int NT = 256>
+__device__ __forceinline__ void zpre_commit(float (&zv)[CO_TILE * 16 / NT][8], const WgradParams& p, const WTile& t,
                                             int cot, int tid, unsigned char* __restrict__ Zhi,
                                             unsigned char* __restrict__ Zlo, bool do_db,
-                                            float (&dbacc)[CO_TILE / 16], bool premasked) {
+                                            float (&dbacc)[CO_TILE * 16 / NT], bool premasked) {
   tid += opaque_zero();   // see zpre_issue
   const int TW = p.tw, TPIX = p.tw * p.th;
 #pragma unroll
-  for (int j = 0; j < CO_TILE / 16; ++j) {
-    const int item = tid + 256 * j;
+  for (int j = 0; j < CO_TILE * 16 / NT; ++j) {
+    const int item = tid + NT * j;
     const int row = item >> 4, oct = item & 15;
     const int pl = oct * 8;
     const bool cok = cot * CO_TILE + row < p.cout;
@@ -252,12 +252,16 @@ __device__ __forceinline__ void wgrad_mfma_phase(const WgradParams& p, f32x16 (&
 // MFMA phases of the 1-2 resident workgroups simply added up: 5-10x off both the HBM and the MFMA
 // bound on every 3x3 layer.)
 // MODE: see wgrad_mfma_phase (2 = clamped LDS tile)
-template <bool X3, int CO_BLKS, int MODE, int TAPS_MAX, int PF>
-__global__ __launch_bounds__(256, ((TAPS_MAX <= 9 && PF <= 1) ? 2 : 1)) void wgrad_kernel(const WgradParams p, const int x_cap, float* db_partial) {
+// NW = 4 waves, or 8 (one 512-thread workgroup per CU: two waves per SIMD for the 16-tap stride-2 layers, whose
+// LDS tiles allow only one workgroup per CU; per lane the staging work, its registers and the accumulators halve)
+template <bool X3, int CO_BLKS, int MODE, int TAPS_MAX, int PF, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (NW == 8 || (TAPS_MAX <= 9 && PF <= 1)) ? 2 : 1) void wgrad_kernel(const WgradParams p, const int x_cap, float* db_partial) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool CLAMP = MODE == 2;
   constexpr int CO_TILE = 32 * CO_BLKS;
-  constexpr int NWT = 4 / CO_BLKS;             // waves sharing one row block
+  constexpr int NT = 64 * NW, ZJ = CO_TILE * 16 / NT;
+  static_assert(NW == 4 || PF > 0, "the eight-wave variant is pipelined");
+  constexpr int NWT = NW / CO_BLKS;            // waves sharing one row block
   constexpr int MAXT = (TAPS_MAX + NWT - 1) / NWT;   // taps per wave (block handles <= TAPS_MAX taps)
   constexpr int XPF = PF > 0 ? PF : 1;
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -290,9 +294,9 @@ __global__ __launch_bounds__(256, ((TAPS_MAX <= 9 && PF <= 1) ? 2 : 1)) void wgr
   for (int ti = 0; ti < MAXT; ++ti)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[ti][i] = 0.f;
-  float dbacc[CO_TILE / 16];
+  float dbacc[ZJ];
 #pragma unroll
-  for (int j = 0; j < CO_TILE / 16; ++j) dbacc[j] = 0.f;
+  for (int j = 0; j < ZJ; ++j) dbacc[j] = 0.f;
 
   const int cvalid = min(32, p.cin - chunk * 32);
   const int ngroups = (cvalid + 7) >> 3;
@@ -311,17 +315,17 @@ __global__ __launch_bounds__(256, ((TAPS_MAX <= 9 && PF <= 1) ? 2 : 1)) void wgr
   // 64-row, 9-tap variant spilled 52 dwords inside the tile loop): there dZ is loaded at commit time
   constexpr bool ZPRE = PF > 0 && !(CO_BLKS == 2 && TAPS_MAX == 9 && PF == 1 && MODE != 0);
   XFast<XPF> xpre;
-  float zv[CO_TILE / 16][8];
-  ZConst<CO_TILE> zc;
+  float zv[ZJ][8];
+  ZConst<CO_TILE, NT> zc;
   const bool zfast = PF > 0 && p.aligned4;   // uniform
-  if (zfast) zfast_init<CO_TILE>(zc, p, cot, tid);
+  if (zfast) zfast_init<CO_TILE, NT>(zc, p, cot, tid);
   WTile cur = wtile_decode<CLAMP>(p, min(tile_lo, ntiles - 1));
   if (PF > 0 && tile_lo < tile_hi) {
-    xfast_issue<XPF>(xpre, p.x, cur.n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row, cur.oy0, cur.ox0, cur.tw,
+    xfast_issue<XPF, NT>(xpre, p.x, cur.n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row, cur.oy0, cur.ox0, cur.tw,
                      cur.npix, ngroups, tid);
     if (ZPRE) {
-      if (zfast) zfast_issue<CO_TILE>(zv, zc, p, cur);
-      else zpre_issue<CO_TILE>(zv, p, cur, cot, tid);
+      if (zfast) zfast_issue<CO_TILE, NT>(zv, zc, p, cur);
+      else zpre_issue<CO_TILE, NT>(zv, p, cur, cot, tid);
     }
   }
 
@@ -330,30 +334,30 @@ __global__ __launch_bounds__(256, ((TAPS_MAX <= 9 && PF <= 1) ? 2 : 1)) void wgr
     const int oy0 = cur.oy0, ox0 = cur.ox0, tw = cur.tw, npix = cur.npix;
     __syncthreads();   // the previous tile's MFMA phase is done with the LDS tiles
     if (PF > 0) {
-      xfast_commit<X3, XPF>(xpre, Xhi, Xlo, p.x, p.cin, chunk, npix, ngroups, 4, tid);
+      xfast_commit<X3, XPF, NT>(xpre, Xhi, Xlo, p.x, p.cin, chunk, npix, ngroups, 4, tid);
       if (!ZPRE) {
-        if (zfast) zfast_issue<CO_TILE>(zv, zc, p, cur);
-        else zpre_issue<CO_TILE>(zv, p, cur, cot, tid);
+        if (zfast) zfast_issue<CO_TILE, NT>(zv, zc, p, cur);
+        else zpre_issue<CO_TILE, NT>(zv, p, cur, cot, tid);
       }
     } else {
       stage_x_chunk<X3, 1>(Xhi, Xlo, p.x, cur.n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row, oy0, ox0, cur.th,
                            tw, ngroups, 4, tid);
-      zpre_issue<CO_TILE>(zv, p, cur, cot, tid);
+      zpre_issue<CO_TILE, NT>(zv, p, cur, cot, tid);
     }
     if (CLAMP && tid < 5) {
       *(uint4*)(Xhi + (size_t)npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
       if (X3) *(uint4*)(Xlo + (size_t)npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
     }
-    zpre_commit<X3, CO_TILE>(zv, p, cur, cot, tid, Zhi, Zlo, do_db, dbacc, false);
+    zpre_commit<X3, CO_TILE, NT>(zv, p, cur, cot, tid, Zhi, Zlo, do_db, dbacc, false);
     __syncthreads();
     WTile nxt = cur;
     if (PF > 0 && tile + 1 < tile_hi) {   // (the block's last tile skips the loads altogether)
       nxt = wtile_decode<CLAMP>(p, tile + 1);
-      xfast_issue<XPF>(xpre, p.x, nxt.n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row, nxt.oy0, nxt.ox0, nxt.tw,
+      xfast_issue<XPF, NT>(xpre, p.x, nxt.n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row, nxt.oy0, nxt.ox0, nxt.tw,
                        nxt.npix, ngroups, tid);
       if (ZPRE) {
-        if (zfast) zfast_issue<CO_TILE>(zv, zc, p, nxt);
-        else zpre_issue<CO_TILE>(zv, p, nxt, cot, tid);
+        if (zfast) zfast_issue<CO_TILE, NT>(zv, zc, p, nxt);
+        else zpre_issue<CO_TILE, NT>(zv, p, nxt, cot, tid);
       }
     }
 
@@ -381,11 +385,11 @@ __global__ __launch_bounds__(256, ((TAPS_MAX <= 9 && PF <= 1) ? 2 : 1)) void wgr
   }
   if (do_db) {
 #pragma unroll
-    for (int j = 0; j < CO_TILE / 16; ++j) {
+    for (int j = 0; j < ZJ; ++j) {
       float s = dbacc[j];
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-      const int row = (tid + 256 * j) >> 4;
+      const int row = (tid + NT * j) >> 4;
       const int co = cot * CO_TILE + row;
       if ((tid & 15) == 0 && co < p.cout) db_partial[(long long)kslice * p.cout + co] = s;
     }
@@ -393,16 +397,16 @@ __global__ __launch_bounds__(256, ((TAPS_MAX <= 9 && PF <= 1) ? 2 : 1)) void wgr
 }
 
 
-template <bool X3, int CO_BLKS, int MODE, int TAPS_MAX, int PF>
+template <bool X3, int CO_BLKS, int MODE, int TAPS_MAX, int PF, int NW = 4>
 static int launch_wgrad_t(const WgradParams& p, int x_cap, size_t lds, float* dbp, dim3 grid, hipStream_t s) {
-  auto kern = wgrad_kernel<X3, CO_BLKS, MODE, TAPS_MAX, PF>;
+  auto kern = wgrad_kernel<X3, CO_BLKS, MODE, TAPS_MAX, PF, NW>;
   static size_t lds_set = 0;
   if (lds > 32 * 1024 && lds > lds_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HARD);
     if (e != hipSuccess) PCUDA_FAIL(PCUDA_E_LAUNCH, "wgrad: cannot raise dynamic LDS: %s", hipGetErrorString(e));
     lds_set = LDS_HARD;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p, x_cap, dbp);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, s, p, x_cap, dbp);
   PCUDA_CHECK_LAUNCH("wgrad_kernel");
   return PCUDA_OK;
 }
@@ -412,6 +416,13 @@ template <bool X3>
 static int wgrad_dispatch(const WgradParams& p, int co_blks, bool clamp, int taps_max, int pf, int x_cap, size_t lds,
                           float* dbp, dim3 grid, hipStream_t s) {
   const int mode = clamp ? 2 : (p.tw16 ? 0 : 1);
+  if (pf >= 100) {   // eight waves (16-tap groups): pf - 100 = staging slots per lane at 512 lanes
+#define WG8_PF(CB_, MD_) (pf == 101 ? launch_wgrad_t<X3, CB_, MD_, 16, 1, 8>(p, x_cap, lds, dbp, grid, s) : launch_wgrad_t<X3, CB_, MD_, 16, 2, 8>(p, x_cap, lds, dbp, grid, s))
+#define WG8_MD(CB_) (mode == 2 ? WG8_PF(CB_, 2) : mode == 0 ? WG8_PF(CB_, 0) : WG8_PF(CB_, 1))
+    return co_blks == 2 ? WG8_MD(2) : WG8_MD(1);
+#undef WG8_MD
+#undef WG8_PF
+  }
 #define WG_PF(CB_, MD_, TM_)                                                                     \
   (pf == 1 ? launch_wgrad_t<X3, CB_, MD_, TM_, 1>(p, x_cap, lds, dbp, grid, s)                  \
    : pf == 3 ? launch_wgrad_t<X3, CB_, MD_, TM_, 3>(p, x_cap, lds, dbp, grid, s)                \
