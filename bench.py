@@ -137,9 +137,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("PCUDA_FORCE_COLLECTIVES") == "1":   # (forced: exercise the RCCL path on one GPU)
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)      # RCCL over xGMI
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"))
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)      # RCCL over xGMI
     if args.gpus != world and rank == 0:
         print("note: --gpus %d but WORLD_SIZE %d: using the launcher's world size" % (args.gpus, world), file=sys.stderr)
 

@@ -53,6 +53,17 @@ def flatten_module(module: nn.Module):
     return flat, grad
 
 
+def _collectives_on(group=None) -> bool:
+    """True when gradients have to be all-reduced: an initialised process group of more than one rank.
+    ``PCUDA_FORCE_COLLECTIVES=1`` keeps the collectives in a one-rank group too (to exercise the RCCL path -- stream
+    ordering, async handles -- on a single-GPU machine)."""
+    import os
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("PCUDA_FORCE_COLLECTIVES") == "1"
+
+
 class _FlatOptimizer:
     def __init__(self, module: nn.Module, lr: float):
         self.module = module
@@ -75,10 +86,25 @@ class _FlatOptimizer:
 
     def all_reduce_grads(self, group=None):
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if _collectives_on(group):
             dist.all_reduce(self.g, op=dist.ReduceOp.SUM, group=group)
             return 1.0 / dist.get_world_size(group)
         return 1.0
+
+    def all_reduce_grads_async(self, group=None):
+        """Start the all-reduce of the flat gradient and return ``(work, scale)``; ``finish_all_reduce(work)``
+        must run before ``step(scale)``.  Lets the caller put independent kernels under the collective: RCCL
+        runs on its own stream, ordered after everything already enqueued on the current one."""
+        import torch.distributed as dist
+        if _collectives_on(group):
+            work = dist.all_reduce(self.g, op=dist.ReduceOp.SUM, group=group, async_op=True)
+            return work, 1.0 / dist.get_world_size(group)
+        return None, 1.0
+
+    @staticmethod
+    def finish_all_reduce(work):
+        if work is not None:
+            work.wait()      # the current stream waits for the collective; the host does not block on NCCL
 
 
 class FusedAdam(_FlatOptimizer):

@@ -134,7 +134,13 @@ class AdversarialTrainer:
         if keep:
             self.last.update({"oT": o_t.detach(), "vertT": None if vert_t is None else vert_t.detach(),
                               "grad_total": self.opt_gen.g.clone()})
-        self.opt_gen.step(self.opt_gen.all_reduce_grads(self.group))
+        # The segmenter's update needs the all-reduced gradient, but nothing in phases 3-5 reads the segmenter's
+        # parameters or gradient buffer (the discriminators train on the detached outputs of phases 1-2): start the
+        # 76 MB all-reduce now and apply Adam after the discriminator passes, which hide it.  Single process:
+        # no collective, same order of arithmetic as the reference.
+        g_work, g_scale = self.opt_gen.all_reduce_grads_async(self.group)
+        if g_work is None:
+            self.opt_gen.step(g_scale)
 
         # 3./4. discriminators: source batch as 1, target batch as 0 (:250-322)
         if self._dis():
@@ -168,8 +174,15 @@ class AdversarialTrainer:
                     if o is not None:
                         self.last[nm] = o.g.clone()
             # 5. update (:325-330)
+            if g_work is not None:
+                self.opt_gen.finish_all_reduce(g_work)
+                self.opt_gen.step(g_scale)
+                g_work = None
             for o in self._d_opts():
                 o.step(o.all_reduce_grads(self.group))
+        if g_work is not None:      # no discriminator configured
+            self.opt_gen.finish_all_reduce(g_work)
+            self.opt_gen.step(g_scale)
         return out
 
     # ------------------------------------------------------------------ the same iteration as one hipGraph

@@ -166,3 +166,34 @@ def test_mmwhs_variant_step_vs_reference_golden(dev):
             if key in g:
                 tot_ref += float(g[key]) ** 2; tot_got += float(snap[off:off + n].double().norm()) ** 2
         assert abs(tot_got ** 0.5 - tot_ref ** 0.5) <= lim * tot_ref ** 0.5, (nm, tot_got ** 0.5, tot_ref ** 0.5)
+
+
+def test_step_with_rccl_collectives_in_a_one_rank_group(dev, monkeypatch):
+    """The N > 1 wiring on one GPU: with PCUDA_FORCE_COLLECTIVES=1 the step issues its RCCL all-reduces (the
+    segmenter's asynchronously, under the discriminator passes) in a one-rank nccl group; the trajectory must be
+    the one of the collective-free step (sum over one rank, scale 1)."""
+    import socket
+    import torch.distributed as dist
+    from oracle.synth import synth_batch
+    if not dist.is_nccl_available():
+        pytest.skip("no RCCL in this torch build")
+    cfg_kw = dict(filters=4, in_channels=1, n_class=4, pointnet=True, fc_inch=9)
+    cfg, tr_a = _build(cfg_kw, 11, dev)
+    _, tr_b = _build(cfg_kw, 11, dev)
+    batch = [torch.from_numpy(t).to(dev) for t in synth_batch(4, cfg.in_channels, cfg.n_class, 128, seed=301)]
+    for _ in range(2):
+        tr_a.step(*batch)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1"); monkeypatch.setenv("MASTER_PORT", str(port))
+    monkeypatch.setenv("PCUDA_FORCE_COLLECTIVES", "1")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        work, scale = tr_b.opt_gen.all_reduce_grads_async()
+        assert work is not None and scale == 1.0
+        tr_b.opt_gen.finish_all_reduce(work)
+        for _ in range(2):
+            tr_b.step(*batch)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    assert rel_err(tr_b.opt_gen.p, tr_a.opt_gen.p) < 1e-6 and rel_err(tr_b.opt_d1.p, tr_a.opt_d1.p) < 1e-6
