@@ -117,6 +117,26 @@ def cpu_baseline(wl, budget_s=20.0):
             "sample": "%d step(s) of the same workload at batch %d (fp32, torch CPU oracle, %d threads)" % (n, b, cores)}
 
 
+def pmc_traffic_per_launch():
+    """HBM bytes per launch of the forward+dgrad conv family from the committed rocprofv3 PMC summary of this same
+    command (profiles/r*_pmc_traffic.csv, written by scripts/gpu_pmc_step.sh: one --pmc pass per counter, FETCH_SIZE
+    and WRITE_SIZE in KB).  bench.py cannot run under the profiler and time itself at once, so this number is read
+    back rather than collected live; FETCH_SIZE is doubled (gfx950 tallies the 128-B requests of wide loads at 64 B:
+    MI355X_MICROARCH.md, HBM section -- exact for the float4 staging loads, uncalibrated for the dword path)."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.csv")))
+    if not files:
+        return None, None
+    n = fetch = write = 0.0
+    for r in csv.DictReader(open(files[-1])):
+        if r["kernel"].startswith(("igemm_pipe_kernel", "igemm8_kernel", "igemm_kernel")):
+            n += float(r["launches"]); fetch += float(r["FETCH_SIZE_KB_sum_raw"]); write += float(r["WRITE_SIZE_KB_sum"])
+    if n == 0:
+        return None, None
+    return int((2.0 * fetch + write) * 1024.0 / n), "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE)" % os.path.basename(files[-1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -207,10 +227,12 @@ def main():
         pms, pbytes, pl_n = K.prof_read(2)
         K.prof_reset()
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic_per_launch()
         result["roofline"] = {
             "kernel": "igemm_pipe_kernel / igemm8_kernel (implicit-GEMM MFMA conv: forward + dgrad launches)", "bound": "mfma",
             "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-            "traffic": None, "launches_per_step": launches // nprof, "avg_launch_us": round(1000.0 * ms / max(launches, 1), 2),
+            "traffic": traffic, "traffic_unit": "bytes per launch (HBM, PMC)", "traffic_source": traffic_src,
+            "launches_per_step": launches // nprof, "avg_launch_us": round(1000.0 * ms / max(launches, 1), 2),
             "ms_per_step": round(ms / nprof, 3),
             "mfma_flops_per_algorithmic_flop": 3 if args.precision == "bf16x3" else 1,
             "other": {
