@@ -8,12 +8,19 @@
 // loop over up to 1024 slices was latency-bound: 0.5 ms for a 9K-weight layer.)
 // ntaps > 1: partial is [k][tap][co*cin] and dw is [co*cin][tap] (OIHW): coalesced reads, the
 // transpose costs one scattered write per weight.
+// The bias gradient rides in the same launch: workgroups past the weight slab's reduce db's [k][cout] slab.
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ partial, long long numel,
                                                            int ksplit, float* __restrict__ dw, int accumulate,
-                                                           int ntaps) {
+                                                           int ntaps, const float* __restrict__ db_partial,
+                                                           long long nb, float* __restrict__ db) {
   __shared__ float sh[16][64];
   const int lane = threadIdx.x & 63, kg = threadIdx.x >> 6, nkg = blockDim.x >> 6;
-  const long long i = (long long)blockIdx.x * 64 + lane;
+  const long long nblk_w = (numel + 63) / 64;
+  long long blk = blockIdx.x;
+  if (blk >= nblk_w) {   // uniform per workgroup: switch to the bias problem
+    blk -= nblk_w; partial = db_partial; numel = nb; dw = db; ntaps = 1;
+  }
+  const long long i = blk * 64 + lane;
   float s = 0.f;
   if (i < numel) {
     int k = kg;
@@ -175,14 +182,10 @@ extern "C" int pcuda_conv2d_wgrad(const pcuda_conv_geom* g, int prec, const pcud
   {
     int nkg = 1;
     while (nkg < 16 && nkg * 2 <= w.ksplit) nkg <<= 1;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(welems, 64)), dim3(64 * nkg), 0, s,
-                       (const float*)workspace, welems, w.ksplit, dw, accumulate, t.n);
+    const unsigned nblk = (unsigned)cdiv(welems, 64) + (db ? (unsigned)cdiv(g->cout, 64) : 0u);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk), dim3(64 * nkg), 0, s, (const float*)workspace, welems, w.ksplit,
+                       dw, accumulate, t.n, (const float*)dbp, (long long)(db ? g->cout : 0), db);
     PCUDA_CHECK_LAUNCH("wgrad_reduce_kernel");
-    if (db) {
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(g->cout, 64)), dim3(64 * nkg), 0, s, (const float*)dbp,
-                         (long long)g->cout, w.ksplit, db, accumulate, 1);
-      PCUDA_CHECK_LAUNCH("wgrad_reduce_kernel(db)");
-    }
   }
   return PCUDA_OK;
 }
