@@ -101,6 +101,9 @@ size_t pcuda_conv2d_packed_dgrad_bytes(const pcuda_conv_geom* g, int prec);
  * bf16 hi (+lo)); call once per optimiser step */
 int pcuda_conv2d_pack_fwd(const pcuda_conv_geom* g, int prec, const float* w, void* packed, pcuda_stream_t s);
 int pcuda_conv2d_pack_dgrad(const pcuda_conv_geom* g, int prec, const float* w, void* packed, pcuda_stream_t s);
+/* both repacks in ONE launch (forward layout + every dgrad parity class); packed_dgrad may be NULL */
+int pcuda_conv2d_pack_all(const pcuda_conv_geom* g, int prec, const float* w, void* packed_fwd, void* packed_dgrad,
+                          pcuda_stream_t s);
 
 /* y = lrelu(conv(x) + bias, slope)   (slope = 1 -> no activation; bias may be NULL)
  * bn_partials (optional): per-tile partial sums [ntiles][cout][2] (sum, sum of squares) of the

@@ -45,6 +45,7 @@ _PROTOS = {
     "pcuda_conv2d_packed_fwd_bytes": (sz, [C.POINTER(ConvGeom), i32]),
     "pcuda_conv2d_packed_dgrad_bytes": (sz, [C.POINTER(ConvGeom), i32]),
     "pcuda_conv2d_pack_fwd": (i32, [C.POINTER(ConvGeom), i32, vp, vp, vp]),
+    "pcuda_conv2d_pack_all": (i32, [C.POINTER(ConvGeom), i32, vp, vp, vp, vp]),
     "pcuda_conv2d_pack_dgrad": (i32, [C.POINTER(ConvGeom), i32, vp, vp, vp]),
     "pcuda_conv2d_fwd_tiles": (i32, [C.POINTER(ConvGeom), i32]),
     "pcuda_conv2d_forward": (i32, [C.POINTER(ConvGeom), i32, C.POINTER(Src), vp, vp, f32, C.POINTER(Dst), vp, vp]),

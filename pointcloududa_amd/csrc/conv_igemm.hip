@@ -41,6 +41,35 @@ __global__ void pack_kernel(const PackParams p) {
 }
 
 
+// several repacks of one weight tensor in one launch (forward layout + every dgrad parity class): blockIdx.y = job
+#define PACK_MAX_JOBS 5
+struct PackJobs {
+  int n;
+  PackParams p[PACK_MAX_JOBS];
+};
+__global__ void pack_multi_kernel(const PackJobs jobs) {
+  const PackParams& p = jobs.p[blockIdx.y];
+  const long long total = (long long)p.n_co_tiles * p.nchunks * p.ntaps * p.co_tile * IG_REC;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    int col = (int)(idx % IG_REC);
+    long long rest = idx / IG_REC;
+    int row = (int)(rest % p.co_tile); rest /= p.co_tile;
+    int t = (int)(rest % p.ntaps); rest /= p.ntaps;
+    int ch = (int)(rest % p.nchunks);
+    int cot = (int)(rest / p.nchunks);
+    int r = cot * p.co_tile + row, c = ch * 32 + col;
+    float v = 0.f;
+    if (col < 32 && r < p.rows && c < p.red) v = p.w[r * p.s_row + c * p.s_red + p.tap_src[t]];
+    __bf16 hi = (__bf16)v;
+    p.out[idx] = __builtin_bit_cast(uint16_t, hi);
+    if (p.lo_off) {
+      __bf16 lo = (__bf16)(v - (float)hi);
+      p.out[p.lo_off + idx] = __builtin_bit_cast(uint16_t, lo);
+    }
+  }
+}
+
 // ==========================================================================================
 // host side
 // ==========================================================================================
@@ -75,10 +104,8 @@ size_t packed_elems(int rows, int red, int ntaps) {   // bf16 elements of ONE pl
   return (size_t)n_co_tiles * nchunks * ntaps * co_tile * IG_REC;
 }
 
-int launch_pack(const float* w, uint16_t* out, int prec, int rows, int red, long long s_row, long long s_red,
-                const TapSet& taps, hipStream_t s) {
-  if (taps.n == 0) return PCUDA_OK;
-  PackParams p;
+size_t fill_pack(PackParams& p, const float* w, uint16_t* out, int prec, int rows, int red, long long s_row,
+                 long long s_red, const TapSet& taps) {
   p.w = w; p.out = out;
   p.rows = rows; p.red = red; p.s_row = s_row; p.s_red = s_red;
   p.ntaps = taps.n;
@@ -88,6 +115,14 @@ int launch_pack(const float* w, uint16_t* out, int prec, int rows, int red, long
   p.nchunks = cdiv(red, 32);
   const size_t plane = packed_elems(rows, red, taps.n);
   p.lo_off = prec == PCUDA_PREC_BF16X3 ? (long long)plane : 0;
+  return plane;
+}
+
+int launch_pack(const float* w, uint16_t* out, int prec, int rows, int red, long long s_row, long long s_red,
+                const TapSet& taps, hipStream_t s) {
+  if (taps.n == 0) return PCUDA_OK;
+  PackParams p;
+  const size_t plane = fill_pack(p, w, out, prec, rows, red, s_row, s_red, taps);
   const int blocks = (int)((plane + 255) / 256 > 4096 ? 4096 : (plane + 255) / 256);
   hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, s, p);
   PCUDA_CHECK_LAUNCH("pack_kernel");
@@ -289,6 +324,36 @@ extern "C" int pcuda_conv2d_pack_dgrad(const pcuda_conv_geom* g, int prec, const
       if (rc) return rc;
       out += packed_elems(g->cin, g->cout, t.n) * (prec == PCUDA_PREC_BF16X3 ? 2 : 1);
     }
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_conv2d_pack_all(const pcuda_conv_geom* g, int prec, const float* w, void* packed_fwd,
+                                     void* packed_dgrad, pcuda_stream_t s) {
+  if (!geom_ok(g) || !w || !packed_fwd) PCUDA_FAIL(PCUDA_E_BADARG, "pack_all: bad geometry or null pointer");
+  if (g->stride * g->stride + 1 > PACK_MAX_JOBS) {   // strides > 2: one launch per layout
+    int rc = pcuda_conv2d_pack_fwd(g, prec, w, packed_fwd, s);
+    if (rc == PCUDA_OK && packed_dgrad) rc = pcuda_conv2d_pack_dgrad(g, prec, w, packed_dgrad, s);
+    return rc;
+  }
+  const int kk = g->k * g->k;
+  PackJobs jobs;
+  jobs.n = 0;
+  size_t maxplane = fill_pack(jobs.p[jobs.n++], w, (uint16_t*)packed_fwd, prec, g->cout, g->cin, (long long)g->cin * kk,
+                              kk, fwd_taps(g));
+  if (packed_dgrad) {
+    uint16_t* out = (uint16_t*)packed_dgrad;
+    for (int ry = 0; ry < g->stride; ++ry)
+      for (int rx = 0; rx < g->stride; ++rx) {
+        TapSet t = dgrad_taps(g, ry, rx);
+        if (t.n == 0) continue;
+        const size_t plane = fill_pack(jobs.p[jobs.n++], w, out, prec, g->cin, g->cout, kk, (long long)g->cin * kk, t);
+        if (plane > maxplane) maxplane = plane;
+        out += plane * (prec == PCUDA_PREC_BF16X3 ? 2 : 1);
+      }
+  }
+  const int blocks = (int)((maxplane + 255) / 256 > 2048 ? 2048 : (maxplane + 255) / 256);
+  hipLaunchKernelGGL(pack_multi_kernel, dim3(blocks, jobs.n), dim3(256), 0, (hipStream_t)s, jobs);
+  PCUDA_CHECK_LAUNCH("pack_multi_kernel");
   return PCUDA_OK;
 }
 

@@ -103,6 +103,9 @@ class ConvOp:
     def __init__(self, cin, cout, k, stride=1, pad=0, dil=1, in_up=False):
         self.cin, self.cout, self.k, self.stride, self.pad, self.dil, self.in_up = cin, cout, k, stride, pad, dil, in_up
         self._pk = {}     # (kind, prec) -> (weight ptr, version, generation, packed tensor)
+        # training: a forward-layout repack is followed by a dgrad in the same step, so both go out in one launch;
+        # set False for layers whose input never needs a gradient / for inference-only use
+        self.pack_dgrad_with_fwd = os.environ.get("PCUDA_PACK_ALL", "1") != "0"
         self.owner = None  # object whose ``_wgen`` counter is bumped when weights change behind torch's back
 
     def out_hw(self, in_h, in_w):
@@ -132,8 +135,19 @@ class ConvOp:
         if nbytes == 0:
             raise RuntimeError("conv geometry rejected by libpcuda_hip")
         buf = hit[3] if (hit is not None and hit[3].numel() == nbytes) else torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-        fn = lib.pcuda_conv2d_pack_fwd if kind == "fwd" else lib.pcuda_conv2d_pack_dgrad
-        check(fn(C.byref(g), _precision, w.data_ptr(), buf.data_ptr(), _stream()), "pack_" + kind)
+        if kind == "fwd" and self.pack_dgrad_with_fwd:
+            # the weights changed (optimiser step): repack the forward layout AND the dgrad layouts in one launch
+            dkey = ("dgrad", _precision)
+            dhit = self._pk.get(dkey)
+            dbytes = lib.pcuda_conv2d_packed_dgrad_bytes(C.byref(g), _precision)
+            dbuf = dhit[3] if (dhit is not None and dhit[3].numel() == dbytes) else torch.empty(
+                dbytes, dtype=torch.uint8, device=w.device)
+            check(lib.pcuda_conv2d_pack_all(C.byref(g), _precision, w.data_ptr(), buf.data_ptr(), dbuf.data_ptr(),
+                                            _stream()), "pack_all")
+            self._pk[dkey] = (w.data_ptr(), w._version, gen, dbuf)
+        else:
+            fn = lib.pcuda_conv2d_pack_fwd if kind == "fwd" else lib.pcuda_conv2d_pack_dgrad
+            check(fn(C.byref(g), _precision, w.data_ptr(), buf.data_ptr(), _stream()), "pack_" + kind)
         self._pk[key] = (w.data_ptr(), w._version, gen, buf)
         return buf
 
