@@ -36,11 +36,16 @@ WORKLOADS = {
     # BASELINE.json configs[1]
     "unet_d2": dict(desc="MS-CMRSeg UNet + entropy-map discriminator (d2), 256x256x1, 4 classes",
                     batch=16, d1=False, d2=True, d4=False, gflop_per_pair=243.0),
+    # BASELINE.json configs[3], per rank: global batch 128 = 16 / rank x 8 (run with --gpus 8)
+    "mmwhs_uda": dict(desc="MM-WHS-like full UDA: 3-channel input, 5 classes, softmax mode, PointNetCls(feature_transform,"
+                           " ext), train_mmwhs.py loop",
+                      batch=16, d1=True, d2=True, d4=True, gflop_per_pair=286.0, variant="mmwhs", in_channels=3,
+                      n_class=5, pn=dict(feature_transform=True, ext=True)),
 }
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
-def synth_device_batch(b, hw, n_class, seed, dev):
+def synth_device_batch(b, hw, n_class, seed, dev, in_channels=1, gaussian=False):
     """device-resident synthetic batch in the reference's layout: images U[0,1),
     one-hot uint8 nested-ellipse masks, vertices = HIP sampler(mask) / 255."""
     from pointcloududa_amd.utils.npy2point import masks_to_pointclouds
@@ -59,8 +64,9 @@ def synth_device_batch(b, hw, n_class, seed, dev):
         return lab
 
     g = torch.Generator(device="cpu").manual_seed(seed)
-    img_a = torch.rand((b, 1, hw, hw), generator=g).to(dev)
-    img_b = torch.rand((b, 1, hw, hw), generator=g).to(dev)
+    draw = torch.randn if gaussian else torch.rand           # MM-WHS slices are z-scored, MS-CMRSeg uint8/255
+    img_a = draw((b, in_channels, hw, hw), generator=g).to(dev)
+    img_b = draw((b, in_channels, hw, hw), generator=g).to(dev)
     lab_a, lab_b = labels(), labels()
     onehot = torch.from_numpy(np.ascontiguousarray(np.moveaxis(np.eye(n_class, dtype=np.uint8)[lab_a], -1, 1))).to(dev)
     firsts = torch.from_numpy(rng.integers(0, 1 << 30, size=(2, b)).astype(np.int32)).to(dev)
@@ -74,11 +80,13 @@ def build_trainer(wl, dev, seed, group=None):
     from pointcloududa_amd.train_step import AdversarialTrainer, TrainCfg
     torch.manual_seed(seed)                       # train_mscmrseg.py:668-670 seeds torch + numpy with 0
     np.random.seed(seed)
-    gen = Segmentation_model_Point(filters=32, in_channels=1, n_class=4, pointnet=wl["d4"], fc_inch=121).to(dev)
-    d1 = UncertaintyDiscriminator(in_channel=4).to(dev) if wl["d1"] else None
-    d2 = UncertaintyDiscriminator(in_channel=4).to(dev) if wl["d2"] else None
-    d4 = PointNetCls().to(dev) if wl["d4"] else None          # dropout p = 0.3 as in the reference
-    cfg = TrainCfg(variant="mscmrseg", d1=wl["d1"], d2=wl["d2"], d4=wl["d4"], n_class=4)
+    nc, cin, variant = wl.get("n_class", 4), wl.get("in_channels", 1), wl.get("variant", "mscmrseg")
+    gen = Segmentation_model_Point(filters=32, in_channels=cin, n_class=nc, pointnet=wl["d4"], fc_inch=121).to(dev)
+    d1 = UncertaintyDiscriminator(in_channel=nc).to(dev) if wl["d1"] else None
+    d2 = UncertaintyDiscriminator(in_channel=nc).to(dev) if wl["d2"] else None
+    d4 = PointNetCls(**wl.get("pn", {})).to(dev) if wl["d4"] else None          # dropout p = 0.3 as in the reference
+    cfg = TrainCfg(variant=variant, d1=wl["d1"], d2=wl["d2"], d4=wl["d4"], n_class=nc,
+                   d_momentum=0.95 if variant == "mmwhs" else 0.99)     # train_mmwhs.py:856-859 / train_mscmrseg.py:437
     tr = AdversarialTrainer(gen, d1, d2, d4, cfg, process_group=group)
     tr.train()
     return tr
@@ -92,15 +100,19 @@ def cpu_baseline(wl, budget_s=20.0):
     from oracle.synth import synth_batch
     cores = min(os.cpu_count() or 1, 16)       # oneDNN convs at batch 2 do not scale past a socket's worth of threads
     torch.set_num_threads(cores)
-    cfg = ON.SegCfg(filters=32, in_channels=1, n_class=4, pointnet=wl["d4"], fc_inch=121)
-    scfg = StepCfg(d1=wl["d1"], d2=wl["d2"], d4=wl["d4"], n_class=4)
+    nc, cin, variant = wl.get("n_class", 4), wl.get("in_channels", 1), wl.get("variant", "mscmrseg")
+    pn = wl.get("pn", {})
+    cfg = ON.SegCfg(filters=32, in_channels=cin, n_class=nc, pointnet=wl["d4"], fc_inch=121)
+    scfg = StepCfg(variant=variant, d1=wl["d1"], d2=wl["d2"], d4=wl["d4"], n_class=nc,
+                   d_momentum=0.95 if variant == "mmwhs" else 0.99,
+                   pn_feature_transform=pn.get("feature_transform", False), pn_ext=pn.get("ext", False))
     pg = ON.make_params(ON.seg_param_shapes(cfg), 1)
-    p1 = ON.make_params(ON.disc_param_shapes(4), 2, std=0.02) if wl["d1"] else None
-    p2 = ON.make_params(ON.disc_param_shapes(4), 3, std=0.02) if wl["d2"] else None
-    p4 = ON.make_params(ON.pointnet_cls_param_shapes(), 4) if wl["d4"] else None
+    p1 = ON.make_params(ON.disc_param_shapes(nc), 2, std=0.02) if wl["d1"] else None
+    p2 = ON.make_params(ON.disc_param_shapes(nc), 3, std=0.02) if wl["d2"] else None
+    p4 = ON.make_params(ON.pointnet_cls_param_shapes(**pn), 4) if wl["d4"] else None
     orc = OracleTrainer(cfg, scfg, pg, p1, p2, p4)
     b = 2
-    batch = synth_batch(b, 1, 4, 256, seed=5)
+    batch = synth_batch(b, cin, nc, 256, seed=5, gaussian=variant == "mmwhs")
     t0 = time.perf_counter()
     orc.step(*batch)                                           # warm-up (also the fallback sample)
     warm = time.perf_counter() - t0
@@ -140,8 +152,8 @@ def pmc_traffic_per_launch():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="full_uda", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--precision", default=os.environ.get("PCUDA_PRECISION", "bf16x3"), choices=["bf16x3", "bf16"])
@@ -171,7 +183,8 @@ def main():
     wl = WORKLOADS[args.workload]
     b = args.batch or wl["batch"]
     tr = build_trainer(wl, dev, seed=0)
-    batch = synth_device_batch(b, 256, 4, seed=100 + rank, dev=dev)
+    batch = synth_device_batch(b, 256, wl.get("n_class", 4), seed=100 + rank, dev=dev, in_channels=wl.get("in_channels", 1),
+                               gaussian=wl.get("variant") == "mmwhs")
 
     def sync():
         if dist is not None:
@@ -227,7 +240,9 @@ def main():
         pms, pbytes, pl_n = K.prof_read(2)
         K.prof_reset()
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic_per_launch()
+        # the committed PMC passes were taken on the default command (full_uda, batch 32, bf16x3): only that run quotes them
+        same_cmd = args.workload == "full_uda" and b == wl["batch"] and args.precision == "bf16x3"
+        traffic, traffic_src = pmc_traffic_per_launch() if same_cmd else (None, None)
         result["roofline"] = {
             "kernel": "igemm_pipe_kernel / igemm8_kernel (implicit-GEMM MFMA conv: forward + dgrad launches)", "bound": "mfma",
             "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),

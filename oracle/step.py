@@ -24,6 +24,11 @@ from .nets import (Params, SegCfg, disc_forward, is_trainable, pointnet_cls_forw
                    seg_forward)
 
 
+def _f(t) -> float:
+    """python float of a (possibly graph-attached) scalar"""
+    return float(t.detach()) if isinstance(t, torch.Tensor) else float(t)
+
+
 @dataclass
 class StepCfg:
     variant: str = "mscmrseg"        # or "mmwhs"
@@ -139,11 +144,11 @@ class OracleTrainer:
         if not ms:
             emap_s = self._entropy(o_s)                                  # train_mmwhs.py:224
             ent_s = torch.mean(torch.sum(emap_s, dim=1))
-            out["entropy_loss"] = float(ent_s)
+            out["entropy_loss"] = _f(ent_s)
             if c.d2 and c.etpls:
                 loss1 = loss1 + ent_s
-        out["seg_loss"] = float(l_bce + l_jac)
-        out["loss_bce"], out["loss_jac"] = float(l_bce), float(l_jac)
+        out["seg_loss"] = _f(l_bce + l_jac)
+        out["loss_bce"], out["loss_jac"] = _f(l_bce), _f(l_jac)
         loss1.backward()
         hard = M.soft_to_hard_pred(o_s.detach().numpy(), 1)             # :215-216
         out["seg_dice"] = M.dice_coef_multilabel(np.asarray(mask_a), hard, c.n_class)
@@ -161,7 +166,7 @@ class OracleTrainer:
         adv = 0.0
         if not ms:
             ent_t = torch.mean(torch.sum(emap_t, dim=1))
-            out["entropy_loss_T"] = float(ent_t)
+            out["entropy_loss_T"] = _f(ent_t)
             if c.Tetpls:
                 adv = adv + ent_t
         a2 = a4 = a1 = 0.0
@@ -177,8 +182,8 @@ class OracleTrainer:
             adv = a2 + a4 + a1
         else:
             adv = adv + c.w2 * a2 + c.w4 * a4 + c.w1 * a1
-        out["adv_loss"] = float(adv)
-        out["adv2"], out["adv4"], out["adv1"] = float(a2), float(a4), float(a1)
+        out["adv_loss"] = _f(adv)
+        out["adv2"], out["adv4"], out["adv1"] = _f(a2), _f(a4), _f(a1)
         if torch.is_tensor(adv):
             adv.backward()
         if keep:
@@ -206,17 +211,17 @@ class OracleTrainer:
             if c.d2:
                 d = self._d_img(self.dis2, e)
                 l = L.bce_logits_const(d, label); l.backward()
-                out["d2_loss_" + tag] = float(l)
+                out["d2_loss_" + tag] = _f(l)
                 out["dis2_acc_" + tag] = M.disc_accuracy(d.detach().numpy(), label == 1.0)
             if c.d1:
                 d = self._d_img(self.dis1, i1)
                 l = L.bce_logits_const(d, label); l.backward()
-                out["d1_loss_" + tag] = float(l)
+                out["d1_loss_" + tag] = _f(l)
                 out["dis1_acc_" + tag] = M.disc_accuracy(d.detach().numpy(), label == 1.0)
             if c.d4:
                 d = self._d_pts(v.detach())
                 l = L.bce_logits_const(d, label); l.backward()
-                out["d4_loss_" + tag] = float(l)
+                out["d4_loss_" + tag] = _f(l)
                 out["dis4_acc_" + tag] = M.disc_accuracy(d.detach().numpy(), label == 1.0)
 
         if c.d1 or c.d2 or c.d4:
