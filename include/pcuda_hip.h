@@ -182,6 +182,10 @@ int pcuda_maxpool2_bwd(const float* dy, long long dy_sn, long long dy_sc, const 
 /* dx[h][w] (+)= sum of the 2x2 block of dy[2h][2w] (nearest-upsample backward) */
 int pcuda_upsample2_bwd(const float* dy, long long dy_sn, long long dy_sc, float* dx, long long dx_sn,
                         long long dx_sc, int accumulate, int n, int c, int h, int w, pcuda_stream_t s);
+/* taps unfolded into channels (u: dense [n][c*k*k][oh][ow]); a k x k layer over few input channels becomes a 1x1
+ * layer over c*k*k of them (the discriminators' first layer, GAN.py:96 / :120-124) */
+int pcuda_unfold_taps(const float* x, long long x_sn, long long x_sc, int n, int c, int h, int w, int k, int stride,
+                      int pad, int dil, float* u, int oh, int ow, pcuda_stream_t s);
 /* y = a + b (+ c) (+ d), flat fp32 (bottleneck running sum, unet.py:68-73; gradient joins) */
 int pcuda_add4(const float* a, const float* b, const float* c, const float* d, float* y, long long numel,
                pcuda_stream_t s);

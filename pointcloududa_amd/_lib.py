@@ -65,6 +65,7 @@ _PROTOS = {
     "pcuda_maxpool2_fwd": (i32, [vp, i64, i64, vp, vp, vp, i64, i64, vp, i32, i32, i32, i32, vp]),
     "pcuda_maxpool2_bwd": (i32, [vp, i64, i64, vp, i64, i64, vp, vp, i64, i64, i32, i32, i32, i32, i32, vp]),
     "pcuda_upsample2_bwd": (i32, [vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, i32, vp]),
+    "pcuda_unfold_taps": (i32, [vp, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
     "pcuda_add4": (i32, [vp, vp, vp, vp, vp, i64, vp]),
     "pcuda_mul": (i32, [vp, vp, vp, i64, vp]),
     "pcuda_entropy_fwd": (i32, [vp, i32, f32, vp, vp, i32, i32, i64, vp]),

@@ -355,6 +355,25 @@ __global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restr
   }
 }
 
+// taps unfolded into channels: u[n][c*k*k + ky*k + kx][oy][ox] = x[n][c][oy*stride - pad + ky*dil][ox*stride - pad + kx*dil]
+// (0 outside).  For layers with a handful of input channels (the discriminators' first 4x4 layer: 4 or 5) the
+// convolution over u is a 1x1 layer with a 32-deep reduction chunk that is FULL, instead of 16 taps that each use
+// 4 of a chunk's 32 channels.
+__global__ __launch_bounds__(256) void unfold_taps_kernel(const float* __restrict__ x, long long x_sn, long long x_sc,
+                                                          int h, int w, int k, int stride, int pad, int dil,
+                                                          float* __restrict__ u, int oh, int ow) {
+  const int kc = blockIdx.y, n = blockIdx.z;        // kc = c*k*k + ky*k + kx
+  const int c = kc / (k * k), t = kc - c * k * k, ky = t / k, kx = t - ky * k;
+  const float* px = x + n * x_sn + c * x_sc;
+  float* pu = u + ((long long)n * gridDim.y + kc) * oh * ow;
+  const int total = oh * ow;
+  for (int o = blockIdx.x * PCH + threadIdx.x; o < min(total, (int)(blockIdx.x + 1) * PCH); o += 256) {
+    const int oy = o / ow, ox = o - oy * ow;
+    const int iy = oy * stride - pad + ky * dil, ix = ox * stride - pad + kx * dil;
+    pu[o] = ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w) ? px[(long long)iy * w + ix] : 0.f;
+  }
+}
+
 __global__ __launch_bounds__(256) void add4_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                    const float* __restrict__ c, const float* __restrict__ d,
                                                    float* __restrict__ y, long long numel) {
@@ -537,6 +556,19 @@ extern "C" int pcuda_upsample2_bwd(const float* dy, long long dy_sn, long long d
   hipLaunchKernelGGL(upsample2_bwd_kernel, plane_grid(n, c, (long long)h * w), dim3(256), 0, (hipStream_t)s, dy, dy_sn,
                      dy_sc, dx, dx_sn, dx_sc, accumulate, h, w);
   PCUDA_CHECK_LAUNCH("upsample2_bwd_kernel");
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_unfold_taps(const float* x, long long x_sn, long long x_sc, int n, int c, int h, int w, int k,
+                                 int stride, int pad, int dil, float* u, int oh, int ow, pcuda_stream_t s) {
+  if (!x || !u || k < 1 || stride < 1 || dil < 1 || pad < 0 || h < 1 || w < 1 ||
+      oh != (h + 2 * pad - dil * (k - 1) - 1) / stride + 1 || ow != (w + 2 * pad - dil * (k - 1) - 1) / stride + 1 ||
+      !dims_ok(n, c * k * k, (long long)oh * ow))
+    PCUDA_FAIL(PCUDA_E_BADARG, "unfold_taps: bad arguments");
+  ProfScope prof(PCUDA_FAM_POINTWISE, 8.0 * n * c * k * k * (double)oh * ow, (hipStream_t)s);
+  hipLaunchKernelGGL(unfold_taps_kernel, plane_grid(n, c * k * k, (long long)oh * ow), dim3(256), 0, (hipStream_t)s, x,
+                     x_sn, x_sc, h, w, k, stride, pad, dil, u, oh, ow);
+  PCUDA_CHECK_LAUNCH("unfold_taps_kernel");
   return PCUDA_OK;
 }
 

@@ -321,6 +321,18 @@ def upsample2_bwd(dy):
     return dx
 
 
+def unfold_taps(x, k, stride, pad, dil=1):
+    """[n,c,h,w] -> [n,c*k*k,oh,ow]: every tap of a k x k window as its own channel (zero outside the image)"""
+    n, c, _, xsn, xsc = _planes(x)
+    h, w = x.shape[2], x.shape[3]
+    oh = (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    ow = (w + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    u = torch.empty((n, c * k * k, oh, ow), dtype=torch.float32, device=x.device)
+    check(L.lib().pcuda_unfold_taps(x.data_ptr(), xsn, xsc, n, c, h, w, k, stride, pad, dil, u.data_ptr(), oh, ow,
+                                    _stream()), "unfold_taps")
+    return u
+
+
 def add_n(ts, out=None):
     ts = [t for t in ts if t is not None]
     for t in ts:

@@ -135,3 +135,40 @@ def test_fused_optimisers(dev):
     p3, m3, v3 = p0.to(dev), torch.zeros(5000, device=dev), torch.zeros(5000, device=dev)
     K.adam_step(p3, grads[0].to(dev), m3, v3, 1e-3, 0.9, 0.99, 1e-8, 0.0, 1)
     assert rel_err(p2, p3) < 1e-6
+
+
+@pytest.mark.parametrize("c,h,w,k,s,p,d", [(4, 64, 64, 4, 2, 2, 1), (5, 33, 47, 4, 2, 2, 1), (1, 20, 20, 3, 1, 1, 1),
+                                            (3, 17, 19, 3, 2, 1, 2)])
+def test_unfold_taps_is_exactly_im2col(dev, c, h, w, k, s, p, d):
+    """pcuda_unfold_taps against F.unfold (same (c, ky, kx) channel order): a copy, so bit-exact, on a strided input"""
+    from pointcloududa_amd import kernels as K
+    big = torch.randn(3, c + 2, h, w, device=dev)
+    x = big[:, 1:c + 1]                                        # plane strides differ from the dense ones
+    u = K.unfold_taps(x, k, s, p, d)
+    ref = F.unfold(x.contiguous(), k, dilation=d, padding=p, stride=s).view(3, c * k * k, u.shape[2], u.shape[3])
+    assert torch.equal(u, ref)
+
+
+def test_discriminator_first_layer_folded_equals_direct(dev, monkeypatch):
+    """GAN.py:96 layer as unfold + 1x1 MFMA layer against the same layer on the 16-tap kernel: same products, other
+    summation order -> outputs and input gradients within 1e-4 (weight gradients share one kernel)"""
+    from pointcloududa_amd.networks import UncertaintyDiscriminator
+    from pointcloududa_amd.utils import loss as L
+    torch.manual_seed(3)
+    a = UncertaintyDiscriminator(in_channel=4).to(dev)
+    monkeypatch.setenv("PCUDA_NOFOLD", "1")
+    b = UncertaintyDiscriminator(in_channel=4).to(dev)
+    monkeypatch.delenv("PCUDA_NOFOLD")
+    assert a._fold1 is not None and b._fold1 is None
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(2, 4, 96, 96, device=dev)
+    outs = []
+    for m in (a, b):
+        xi = x.clone().requires_grad_(True)
+        y = m(xi)
+        L.bce_logits_const(y, 0.0).backward()
+        outs.append((y.detach(), xi.grad, [p.grad.clone() for p in m.parameters()]))
+    assert rel_err(outs[0][0], outs[1][0]) < 1e-4
+    assert rel_err(outs[0][1], outs[1][1]) < 1e-4
+    for ga, gb in zip(outs[0][2], outs[1][2]):
+        assert rel_err(ga, gb) < 1e-4
