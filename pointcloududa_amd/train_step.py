@@ -15,6 +15,7 @@ settings -- with three MI355X-first changes that do not alter the arithmetic:
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional
 
@@ -64,6 +65,13 @@ class AdversarialTrainer:
         self._one = torch.ones((), dtype=torch.float32, device=dev)
         self._wp = torch.full((), float(c.wp), dtype=torch.float32, device=dev)
         self.last = {}
+        self.d_streams = os.environ.get("PCUDA_DSTREAMS", "1") != "0"   # discriminator passes on concurrent streams
+        self._streams = []
+
+    def _side_streams(self, n):
+        while len(self._streams) < n:
+            self._streams.append(torch.cuda.Stream())
+        return self._streams[:n]
 
     def _dis(self):
         return [m for m in (self.dis1, self.dis2, self.dis4) if m is not None]
@@ -155,20 +163,30 @@ class AdversarialTrainer:
                 ent_s, pred_s = L.entropy_map(o_s_d, mode, True, want_prob=True)
                 in1_s, in1_t = pred_s, (None if pred_t is None else pred_t.detach())
             ent_t_d = None if ent_t is None else ent_t.detach()
-            for tag, label, e, i1, v in (("src", 1.0, ent_s, in1_s, vert_s), ("tgt", 0.0, ent_t_d, in1_t, vert_t)):
-                if c.d2:
-                    l, acc = L.bce_logits_const(self.dis2(e), label, 1.0, want_acc=True)
-                    l.backward()
-                    out["d2_loss_" + tag], out["dis2_hit_" + tag] = l.detach(), acc
-                if c.d1:
-                    l, acc = L.bce_logits_const(self.dis1(i1), label, 1.0, want_acc=True)
-                    l.backward()
-                    out["d1_loss_" + tag], out["dis1_hit_" + tag] = l.detach(), acc
-                if c.d4:
-                    l, acc = L.bce_logits_const(self.dis4(v.detach().transpose(2, 1), drop_mask)[0], label, 1.0,
-                                                want_acc=True)
-                    l.backward()
-                    out["d4_loss_" + tag], out["dis4_hit_" + tag] = l.detach(), acc
+            # The discriminators are independent networks with their own gradient buffers: each runs its source and
+            # target passes on its own HIP stream (forked from / joined to the caller's), so that the point-cloud
+            # discriminator's many small kernels and the tails of the persistent convolution kernels fill each other's
+            # gaps.  Same arithmetic per network as the reference's interleaved order (:250-322).
+            passes = []
+            if c.d2:
+                passes.append(("d2", "dis2", lambda e, i1, v: self.dis2(e)))
+            if c.d1:
+                passes.append(("d1", "dis1", lambda e, i1, v: self.dis1(i1)))
+            if c.d4:
+                passes.append(("d4", "dis4", lambda e, i1, v: self.dis4(v.detach().transpose(2, 1), drop_mask)[0]))
+            main = torch.cuda.current_stream()
+            side = self._side_streams(len(passes)) if (self.d_streams and len(passes) > 1) else [None] * len(passes)
+            for (nm, hit, fwd), st in zip(passes, side):
+                if st is not None:
+                    st.wait_stream(main)
+                with torch.cuda.stream(st if st is not None else main):
+                    for tag, label, e, i1, v in (("src", 1.0, ent_s, in1_s, vert_s), ("tgt", 0.0, ent_t_d, in1_t, vert_t)):
+                        l, acc = L.bce_logits_const(fwd(e, i1, v), label, 1.0, want_acc=True)
+                        l.backward()
+                        out[nm + "_loss_" + tag], out[hit + "_hit_" + tag] = l.detach(), acc
+            for st in side:
+                if st is not None:
+                    main.wait_stream(st)
             if keep:
                 for nm, o in (("grad_d1", self.opt_d1), ("grad_d2", self.opt_d2), ("grad_d4", self.opt_d4)):
                     if o is not None:
