@@ -113,6 +113,20 @@ class AdversarialTrainer:
                          "grad_seg": self.opt_gen.g.clone()}
 
         # 2. adversarial pass on the target batch (:218-247)
+        # (running this pass's forward on a second stream next to the source batch's backward kernels measured 5%
+        # SLOWER: two persistent convolution grids sharing the CUs evict each other's L2 tiles)
+        o_t, vert_t, ent_t, pred_t = self._phase2(img_b, vert_b, drop_mask, out)
+        if keep:
+            self.last.update({"oT": o_t.detach(), "vertT": None if vert_t is None else vert_t.detach(),
+                              "grad_total": self.opt_gen.g.clone()})
+        self._phase345(o_s, o_t, vert_s, vert_t, ent_t, pred_t, drop_mask, out, keep)
+        return out
+
+    def _phase2(self, img_b, vert_b, drop_mask, out):
+        c = self.cfg
+        ms = c.variant == "mscmrseg"
+        mode = "sigmoid" if (ms or not c.softmax) else "softmax"
+        one = self._one
         o_t, _, vert_t = self.gen(img_b)
         norm = not ms
         pred_t = ent_t = tap_t = None
@@ -126,22 +140,35 @@ class AdversarialTrainer:
         else:
             ent_t, pred_t = L.entropy_map(o_t, mode, True, want_prob=True)
         adv_t, adv_g = [], []
+        # the frozen discriminators' forward passes (and, through autograd's per-node streams, their input-gradient
+        # passes) run next to each other like phases 3-4 below
+        heads = []
         if c.d2:
-            l2 = L.bce_logits_const(self.dis2(ent_t), 1.0, weight=c.dr * (1.0 if ms else c.w2))
-            adv_t.append(l2); adv_g.append(one); out["adv2"] = l2.detach()
+            heads.append(("adv2", lambda: self.dis2(ent_t), c.dr * (1.0 if ms else c.w2)))
         if c.d4:
             out["ver_t_loss"] = L.batch_NN_loss(vert_t.detach(), vert_b)
-            l4 = L.bce_logits_const(self.dis4(vert_t.transpose(2, 1), drop_mask)[0], 1.0,
-                                    weight=c.dr * (1.0 if ms else c.w4))
-            adv_t.append(l4); adv_g.append(one); out["adv4"] = l4.detach()
+            heads.append(("adv4", lambda: self.dis4(vert_t.transpose(2, 1), drop_mask)[0], c.dr * (1.0 if ms else c.w4)))
         if c.d1:
-            l1 = L.bce_logits_const(self.dis1(tap_t if ms else pred_t), 1.0, weight=c.dr * (1.0 if ms else c.w1))
-            adv_t.append(l1); adv_g.append(one); out["adv1"] = l1.detach()
+            heads.append(("adv1", lambda: self.dis1(tap_t if ms else pred_t), c.dr * (1.0 if ms else c.w1)))
+        cur = torch.cuda.current_stream()
+        side = self._side_streams(len(heads)) if (self.d_streams and len(heads) > 1) else [None] * len(heads)
+        for (nm, fwd, wgt), st in zip(heads, side):
+            if st is not None:
+                st.wait_stream(cur)
+            with torch.cuda.stream(st if st is not None else cur):
+                l = L.bce_logits_const(fwd(), 1.0, weight=wgt)
+            adv_t.append(l); adv_g.append(one); out[nm] = l.detach()
+        for st in side:
+            if st is not None:
+                cur.wait_stream(st)
         if adv_t:
             torch.autograd.backward(adv_t, adv_g)
-        if keep:
-            self.last.update({"oT": o_t.detach(), "vertT": None if vert_t is None else vert_t.detach(),
-                              "grad_total": self.opt_gen.g.clone()})
+        return o_t, vert_t, ent_t, pred_t
+
+    def _phase345(self, o_s, o_t, vert_s, vert_t, ent_t, pred_t, drop_mask, out, keep):
+        c = self.cfg
+        ms = c.variant == "mscmrseg"
+        mode = "sigmoid" if (ms or not c.softmax) else "softmax"
         # The segmenter's update needs the all-reduced gradient, but nothing in phases 3-5 reads the segmenter's
         # parameters or gradient buffer (the discriminators train on the detached outputs of phases 1-2): start the
         # 76 MB all-reduce now and apply Adam after the discriminator passes, which hide it.  Single process:
@@ -201,7 +228,6 @@ class AdversarialTrainer:
         if g_work is not None:      # no discriminator configured
             self.opt_gen.finish_all_reduce(g_work)
             self.opt_gen.step(g_scale)
-        return out
 
     # ------------------------------------------------------------------ the same iteration as one hipGraph
     def step_graphed(self, img_a, mask_a_u8, vert_a, img_b, vert_b) -> Dict[str, torch.Tensor]:
