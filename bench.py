@@ -221,6 +221,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": wl["desc"], "per_gpu_batch": b, "global_batch": b * world, "precision": args.precision,
                    "parallelism": "dp%d" % world, "algorithmic_gflop_per_pair": wl["gflop_per_pair"],
+                   "streams": "discriminators concurrent" if tr.d_streams else "single",
                    "launch": "hipGraph replay" if (use_graph and getattr(tr, "_graph", None) is not None) else "eager",
                    "losses": {k: round(host[k], 5) for k in ("seg_loss", "adv_loss") if k in host}},
     }
@@ -229,9 +230,13 @@ def main():
         K.prof_reset()
         K.prof_enable(True)
         nprof = 2
+        # per-launch durations are taken with the discriminator streams serialised (PCUDA_DSTREAMS=0 behaviour): kernels
+        # that share the CUs with another stream's kernels would each be billed the shared time
+        streams_on, tr.d_streams = tr.d_streams, False
         for _ in range(nprof):
             tr.step(*batch)
         torch.cuda.synchronize()
+        tr.d_streams = streams_on
         K.prof_enable(False)
         if os.environ.get("PCUDA_PROF_DUMP"):
             K.prof_dump(os.environ["PCUDA_PROF_DUMP"])

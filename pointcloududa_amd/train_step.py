@@ -67,6 +67,7 @@ class AdversarialTrainer:
         self.last = {}
         self.d_streams = os.environ.get("PCUDA_DSTREAMS", "1") != "0"   # discriminator passes on concurrent streams
         self._streams = []
+        self.d_batch = os.environ.get("PCUDA_DBATCH", "1") != "0"       # d1 / d2: source + target as one batch
 
     def _side_streams(self, n):
         while len(self._streams) < n:
@@ -207,6 +208,21 @@ class AdversarialTrainer:
                 if st is not None:
                     st.wait_stream(main)
                 with torch.cuda.stream(st if st is not None else main):
+                    if nm != "d4" and self.d_batch:
+                        # d1 / d2 have no batch statistics: the source and the target batch go through the network as
+                        # ONE batch of 2B samples (twice the tiles per launch on the 17x17 / 9x9 maps, half the launches);
+                        # the two mean losses of :262-263,:296-297 are taken over the halves of the output, and their
+                        # gradients add up in the weight-gradient kernels exactly as the two backward calls' do
+                        bsz = o_s.shape[0]
+                        d = fwd(torch.cat([ent_s, ent_t_d], 0) if nm == "d2" else None,
+                                torch.cat([in1_s, in1_t], 0) if nm == "d1" else None, None)
+                        ls = []
+                        for tag, label, part in (("src", 1.0, d[:bsz]), ("tgt", 0.0, d[bsz:])):
+                            l, acc = L.bce_logits_const(part, label, 1.0, want_acc=True)
+                            ls.append(l)
+                            out[nm + "_loss_" + tag], out[hit + "_hit_" + tag] = l.detach(), acc
+                        torch.autograd.backward(ls, [self._one, self._one])
+                        continue
                     for tag, label, e, i1, v in (("src", 1.0, ent_s, in1_s, vert_s), ("tgt", 0.0, ent_t_d, in1_t, vert_t)):
                         l, acc = L.bce_logits_const(fwd(e, i1, v), label, 1.0, want_acc=True)
                         l.backward()
