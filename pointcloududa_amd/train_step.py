@@ -67,6 +67,7 @@ class AdversarialTrainer:
         self.last = {}
         self.d_streams = os.environ.get("PCUDA_DSTREAMS", "1") != "0"   # discriminator passes on concurrent streams
         self._streams = []
+        self.d_overlap = os.environ.get("PCUDA_DOVERLAP", "1") != "0"   # discriminator update under the G backward
         self.d_batch = os.environ.get("PCUDA_DBATCH", "1") != "0"       # d1 / d2: source + target as one batch
 
     def _side_streams(self, n):
@@ -116,14 +117,14 @@ class AdversarialTrainer:
         # 2. adversarial pass on the target batch (:218-247)
         # (running this pass's forward on a second stream next to the source batch's backward kernels measured 5%
         # SLOWER: two persistent convolution grids sharing the CUs evict each other's L2 tiles)
-        o_t, vert_t, ent_t, pred_t = self._phase2(img_b, vert_b, drop_mask, out)
+        o_t, vert_t, prep, ev = self._phase2(img_b, vert_b, drop_mask, out, o_s)
         if keep:
             self.last.update({"oT": o_t.detach(), "vertT": None if vert_t is None else vert_t.detach(),
                               "grad_total": self.opt_gen.g.clone()})
-        self._phase345(o_s, o_t, vert_s, vert_t, ent_t, pred_t, drop_mask, out, keep)
+        self._phase345(o_s, vert_s, vert_t, prep, ev, drop_mask, out, keep)
         return out
 
-    def _phase2(self, img_b, vert_b, drop_mask, out):
+    def _phase2(self, img_b, vert_b, drop_mask, out, o_s):
         c = self.cfg
         ms = c.variant == "mscmrseg"
         mode = "sigmoid" if (ms or not c.softmax) else "softmax"
@@ -162,14 +163,29 @@ class AdversarialTrainer:
         for st in side:
             if st is not None:
                 cur.wait_stream(st)
+        # Inputs of the discriminator update (phases 3-4): detached outputs of the two forward passes.  They exist
+        # now, and the update touches nothing the adversarial backward pass below reads or writes (frozen D weights,
+        # separate gradient buffers), so its streams fork HERE: the discriminators' few-tile kernels then run under the
+        # segmenter's backward pass instead of after it.
+        prep = ev = None
+        if self._dis():
+            o_s_d, o_t_d = o_s.detach(), o_t.detach()
+            if ms:
+                ent_s = L.entropy_map(o_s_d, "sigmoid", False) if c.d2 else None
+                in1_s, in1_t = o_s_d, o_t_d
+            else:
+                ent_s, pred_s = L.entropy_map(o_s_d, mode, True, want_prob=True)
+                in1_s, in1_t = pred_s, (None if pred_t is None else pred_t.detach())
+            prep = (ent_s, None if ent_t is None else ent_t.detach(), in1_s, in1_t)
+            if self.d_overlap and self.d_streams:
+                ev = torch.cuda.Event()
+                ev.record(cur)
         if adv_t:
             torch.autograd.backward(adv_t, adv_g)
-        return o_t, vert_t, ent_t, pred_t
+        return o_t, vert_t, prep, ev
 
-    def _phase345(self, o_s, o_t, vert_s, vert_t, ent_t, pred_t, drop_mask, out, keep):
+    def _phase345(self, o_s, vert_s, vert_t, prep, ev, drop_mask, out, keep):
         c = self.cfg
-        ms = c.variant == "mscmrseg"
-        mode = "sigmoid" if (ms or not c.softmax) else "softmax"
         # The segmenter's update needs the all-reduced gradient, but nothing in phases 3-5 reads the segmenter's
         # parameters or gradient buffer (the discriminators train on the detached outputs of phases 1-2): start the
         # 76 MB all-reduce now and apply Adam after the discriminator passes, which hide it.  Single process:
@@ -183,14 +199,7 @@ class AdversarialTrainer:
             for m in self._dis():
                 m.requires_grad_(True)
             self.gen.requires_grad_(False)
-            o_s_d, o_t_d = o_s.detach(), o_t.detach()
-            if ms:
-                ent_s = L.entropy_map(o_s_d, "sigmoid", False) if c.d2 else None
-                in1_s, in1_t = o_s_d, o_t_d
-            else:
-                ent_s, pred_s = L.entropy_map(o_s_d, mode, True, want_prob=True)
-                in1_s, in1_t = pred_s, (None if pred_t is None else pred_t.detach())
-            ent_t_d = None if ent_t is None else ent_t.detach()
+            ent_s, ent_t_d, in1_s, in1_t = prep
             # The discriminators are independent networks with their own gradient buffers: each runs its source and
             # target passes on its own HIP stream (forked from / joined to the caller's), so that the point-cloud
             # discriminator's many small kernels and the tails of the persistent convolution kernels fill each other's
@@ -206,7 +215,10 @@ class AdversarialTrainer:
             side = self._side_streams(len(passes)) if (self.d_streams and len(passes) > 1) else [None] * len(passes)
             for (nm, hit, fwd), st in zip(passes, side):
                 if st is not None:
-                    st.wait_stream(main)
+                    if ev is not None:
+                        st.wait_event(ev)
+                    else:
+                        st.wait_stream(main)
                 with torch.cuda.stream(st if st is not None else main):
                     if nm != "d4" and self.d_batch:
                         # d1 / d2 have no batch statistics: the source and the target batch go through the network as
