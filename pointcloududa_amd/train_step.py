@@ -68,6 +68,7 @@ class AdversarialTrainer:
         self.d_streams = os.environ.get("PCUDA_DSTREAMS", "1") != "0"   # discriminator passes on concurrent streams
         self._streams = []
         self.d_overlap = os.environ.get("PCUDA_DOVERLAP", "1") != "0"   # discriminator update under the G backward
+        self.early_fwd2 = os.environ.get("PCUDA_EARLY2", "1") != "0"    # target forward ahead of the source backward
         self.d_batch = os.environ.get("PCUDA_DBATCH", "1") != "0"       # d1 / d2: source + target as one batch
 
     def _side_streams(self, n):
@@ -108,23 +109,31 @@ class AdversarialTrainer:
             seeds_t.append(l_pt)
             seeds_g.append(self._wp)
         out["loss_bce"], out["loss_jac"] = l_main.detach(), l_jac.detach()
+        # 2. (forward half) adversarial pass on the target batch (:218-241).  The reference runs the source batch's
+        # backward pass first; nothing in it feeds the target forward (weights change only in the optimisers, BatchNorm's
+        # running statistics are updated by the forward passes, in this same order), so the forward goes first and
+        # the frozen discriminators' passes over its outputs -- a few-tile island between the two halves of the
+        # segmenter's work -- run on their streams UNDER the source batch's backward pass.
+        early = self.early_fwd2
+        if early:
+            o_t, vert_t, prep, ev, adv_t, adv_g = self._phase2_forward(img_b, vert_b, drop_mask, out, o_s)
         torch.autograd.backward(seeds_t, seeds_g)
         out["seg_dice"] = K.dice_metric(o_s.detach(), mask_a_u8)      # :215-216, on the device
         if keep:
             self.last = {"oS": o_s.detach(), "vertS": None if vert_s is None else vert_s.detach(),
                          "grad_seg": self.opt_gen.g.clone()}
-
-        # 2. adversarial pass on the target batch (:218-247)
-        # (running this pass's forward on a second stream next to the source batch's backward kernels measured 5%
-        # SLOWER: two persistent convolution grids sharing the CUs evict each other's L2 tiles)
-        o_t, vert_t, prep, ev = self._phase2(img_b, vert_b, drop_mask, out, o_s)
+        if not early:
+            o_t, vert_t, prep, ev, adv_t, adv_g = self._phase2_forward(img_b, vert_b, drop_mask, out, o_s)
+        # 2. (backward half, :242-247)
+        if adv_t:
+            torch.autograd.backward(adv_t, adv_g)
         if keep:
             self.last.update({"oT": o_t.detach(), "vertT": None if vert_t is None else vert_t.detach(),
                               "grad_total": self.opt_gen.g.clone()})
         self._phase345(o_s, vert_s, vert_t, prep, ev, drop_mask, out, keep)
         return out
 
-    def _phase2(self, img_b, vert_b, drop_mask, out, o_s):
+    def _phase2_forward(self, img_b, vert_b, drop_mask, out, o_s):
         c = self.cfg
         ms = c.variant == "mscmrseg"
         mode = "sigmoid" if (ms or not c.softmax) else "softmax"
@@ -160,9 +169,8 @@ class AdversarialTrainer:
             with torch.cuda.stream(st if st is not None else cur):
                 l = L.bce_logits_const(fwd(), 1.0, weight=wgt)
             adv_t.append(l); adv_g.append(one); out[nm] = l.detach()
-        for st in side:
-            if st is not None:
-                cur.wait_stream(st)
+        # (no join here: autograd orders the backward nodes across streams, and the caller's stream waits for the
+        # discriminator streams at the end of phase 4)
         # Inputs of the discriminator update (phases 3-4): detached outputs of the two forward passes.  They exist
         # now, and the update touches nothing the adversarial backward pass below reads or writes (frozen D weights,
         # separate gradient buffers), so its streams fork HERE: the discriminators' few-tile kernels then run under the
@@ -180,9 +188,7 @@ class AdversarialTrainer:
             if self.d_overlap and self.d_streams:
                 ev = torch.cuda.Event()
                 ev.record(cur)
-        if adv_t:
-            torch.autograd.backward(adv_t, adv_g)
-        return o_t, vert_t, prep, ev
+        return o_t, vert_t, prep, ev, adv_t, adv_g
 
     def _phase345(self, o_s, vert_s, vert_t, prep, ev, drop_mask, out, keep):
         c = self.cfg
