@@ -265,11 +265,19 @@ def main():
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(wl)
-    if rank == 0:
-        print(json.dumps(result))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL's version banner sits in the C library's stdout buffer until exit: flush it first, so that the JSON
+        # line is the last line of output
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

@@ -31,6 +31,7 @@ class _SegEngine:
         f = filters
         self.f, self.cin, self.nb, self.depth, self.ncls, self.pointnet, self.fc_inch = \
             f, in_channels, n_block, depth, n_class, pointnet, fc_inch
+        self.after_deep_grads = None      # optional hook of the backward pass (see ``backward``)
         ops = {}
         for i in range(n_block):
             co = f * 2 ** i
@@ -204,6 +205,11 @@ class _SegEngine:
             if G(name + ".weight") is not None:
                 self.ops[name].wgrad(S[name], dz, G(name + ".weight"), G(name + ".bias"), h, w)
             g_next = self.ops[name].dgrad(dz, P[name + ".weight"], h, w)
+        # every weight gradient except the encoder's has been launched: a data-parallel trainer starts their
+        # all-reduce here, under the encoder's backward pass (train_step.py)
+        cb = self.after_deep_grads
+        if cb is not None:
+            cb()
         dA, dB = g_next, None
         for i in reversed(range(nb)):
             hi, wi = H >> i, W >> i

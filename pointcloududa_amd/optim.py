@@ -91,20 +91,42 @@ class _FlatOptimizer:
             return 1.0 / dist.get_world_size(group)
         return 1.0
 
-    def all_reduce_grads_async(self, group=None):
-        """Start the all-reduce of the flat gradient and return ``(work, scale)``; ``finish_all_reduce(work)``
-        must run before ``step(scale)``.  Lets the caller put independent kernels under the collective: RCCL
-        runs on its own stream, ordered after everything already enqueued on the current one."""
+    def all_reduce_grads_async(self, group=None, lo=0, hi=None):
+        """Start the all-reduce of the flat gradient (or of its slice [lo, hi)) and return ``(work, scale)``;
+        ``finish_all_reduce(work)`` must run before ``step(scale)``.  Lets the caller put independent kernels under
+        the collective: RCCL runs on its own stream, ordered after everything already enqueued on the current one."""
         import torch.distributed as dist
         if _collectives_on(group):
-            work = dist.all_reduce(self.g, op=dist.ReduceOp.SUM, group=group, async_op=True)
+            g = self.g if (lo == 0 and hi is None) else self.g[lo:hi]
+            if g.numel() == 0:
+                return None, 1.0 / dist.get_world_size(group)
+            work = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True)
             return work, 1.0 / dist.get_world_size(group)
         return None, 1.0
 
+    def split_after(self, prefix: str) -> int:
+        """Offset in the flat buffers at which the parameters whose names start with ``prefix`` end, if they form
+        the HEAD of the buffer (registration order); 0 otherwise.  Used to all-reduce the rest of the gradient while
+        the backward pass is still producing the head's (the segmenter's encoder is first in the buffer and last in
+        the backward pass)."""
+        off, head_end, seen_other = 0, 0, False
+        for name, p in self.module.named_parameters():
+            n = (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+            if name.startswith(prefix):
+                if seen_other:
+                    return 0
+                head_end = off + n
+            else:
+                seen_other = True
+            off += n
+        return head_end if seen_other else 0
+
     @staticmethod
     def finish_all_reduce(work):
-        if work is not None:
-            work.wait()      # the current stream waits for the collective; the host does not block on NCCL
+        """``work``: one handle or a list of them (None entries allowed)"""
+        for w in (work if isinstance(work, (list, tuple)) else [work]):
+            if w is not None:
+                w.wait()      # the current stream waits for the collective; the host does not block on NCCL
 
 
 class FusedAdam(_FlatOptimizer):

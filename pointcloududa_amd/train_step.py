@@ -22,7 +22,7 @@ from typing import Dict, Optional
 import torch
 
 from . import kernels as K
-from .optim import FusedAdam, FusedSGD
+from .optim import FusedAdam, FusedSGD, _collectives_on
 from .utils import loss as L
 
 
@@ -124,13 +124,28 @@ class AdversarialTrainer:
                          "grad_seg": self.opt_gen.g.clone()}
         if not early:
             o_t, vert_t, prep, ev, adv_t, adv_g = self._phase2_forward(img_b, vert_b, drop_mask, out, o_s)
-        # 2. (backward half, :242-247)
+        # 2. (backward half, :242-247).  Data-parallel: the all-reduce of every segmenter gradient except the encoder's
+        # (92 % of the 76 MB) starts from inside the backward pass, as soon as those kernels are launched, and runs on
+        # RCCL's stream under the encoder's backward kernels; the encoder's slice follows after the pass.
+        g_works, split = [], 0
         if adv_t:
-            torch.autograd.backward(adv_t, adv_g)
+            eng = getattr(self.gen, "_engine", None)
+            if eng is not None and _collectives_on(self.group):
+                split = self.opt_gen.split_after("encoder.")
+                if split:
+                    eng.after_deep_grads = lambda: g_works.append(
+                        self.opt_gen.all_reduce_grads_async(self.group, lo=split)[0])
+            try:
+                torch.autograd.backward(adv_t, adv_g)
+            finally:
+                if eng is not None:
+                    eng.after_deep_grads = None
+            if not g_works:
+                split = 0          # the hook did not fire: one all-reduce of the whole buffer below
         if keep:
             self.last.update({"oT": o_t.detach(), "vertT": None if vert_t is None else vert_t.detach(),
                               "grad_total": self.opt_gen.g.clone()})
-        self._phase345(o_s, vert_s, vert_t, prep, ev, drop_mask, out, keep)
+        self._phase345(o_s, vert_s, vert_t, prep, ev, drop_mask, out, keep, g_works, split)
         return out
 
     def _phase2_forward(self, img_b, vert_b, drop_mask, out, o_s):
@@ -190,13 +205,15 @@ class AdversarialTrainer:
                 ev.record(cur)
         return o_t, vert_t, prep, ev, adv_t, adv_g
 
-    def _phase345(self, o_s, vert_s, vert_t, prep, ev, drop_mask, out, keep):
+    def _phase345(self, o_s, vert_s, vert_t, prep, ev, drop_mask, out, keep, g_works, split):
         c = self.cfg
         # The segmenter's update needs the all-reduced gradient, but nothing in phases 3-5 reads the segmenter's
-        # parameters or gradient buffer (the discriminators train on the detached outputs of phases 1-2): start the
-        # 76 MB all-reduce now and apply Adam after the discriminator passes, which hide it.  Single process:
-        # no collective, same order of arithmetic as the reference.
-        g_work, g_scale = self.opt_gen.all_reduce_grads_async(self.group)
+        # parameters or gradient buffer (the discriminators train on the detached outputs of phases 1-2): the rest of
+        # the all-reduce (the encoder's slice, or everything if no bucket went out during the backward pass) starts
+        # now, and Adam is applied after the discriminator passes, which hide it.  Single process: no collective, same
+        # order of arithmetic as the reference.
+        w_rest, g_scale = self.opt_gen.all_reduce_grads_async(self.group, lo=0, hi=(split or None))
+        g_work = [w for w in g_works + [w_rest] if w is not None] or None
         if g_work is None:
             self.opt_gen.step(g_scale)
 

@@ -49,6 +49,19 @@ def _worker(rank, world, port, ret):
         assert torch.allclose(p.grad, torch.full_like(p.grad, 3.0 * (i + 2)))
     assert float(unrelated) == 1000.0
     opt.zero_grad()
+    # the bucketed form of the segmenter's all-reduce: everything behind the head ("conv1." here) goes out first
+    # (from inside the backward pass), the head afterwards; together they cover the buffer exactly once
+    split = opt.split_after("conv1.")
+    first = next(m.parameters())
+    assert split >= first.numel() and split < grad.numel() and opt.split_after("conv3.") == 0     # not at the head
+    for i, p in enumerate(m.parameters()):
+        p.grad.fill_(float(rank + 1) * (i + 3))
+    w_tail, _ = opt.all_reduce_grads_async(lo=split)
+    w_head, _ = opt.all_reduce_grads_async(lo=0, hi=split)
+    opt.finish_all_reduce([w_tail, None, w_head])
+    for i, p in enumerate(m.parameters()):
+        assert torch.allclose(p.grad, torch.full_like(p.grad, 3.0 * (i + 3)))
+    opt.zero_grad()
     ret[rank] = float(flat.sum())
     dist.barrier()
     dist.destroy_process_group()

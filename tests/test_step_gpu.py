@@ -191,9 +191,18 @@ def test_step_with_rccl_collectives_in_a_one_rank_group(dev, monkeypatch):
         work, scale = tr_b.opt_gen.all_reduce_grads_async()
         assert work is not None and scale == 1.0
         tr_b.opt_gen.finish_all_reduce(work)
+        # the bucketed form: the non-encoder tail goes out from inside the adversarial backward pass, the encoder's
+        # head after it -- count the collectives of one step and check that the two slices tile the buffer
+        split = tr_b.opt_gen.split_after("encoder.")
+        assert 0 < split < tr_b.opt_gen.g.numel()
+        calls = []
+        real = tr_b.opt_gen.all_reduce_grads_async
+        monkeypatch.setattr(tr_b.opt_gen, "all_reduce_grads_async",
+                            lambda group=None, lo=0, hi=None: (calls.append((lo, hi)), real(group, lo, hi))[1])
         for _ in range(2):
             tr_b.step(*batch)
         torch.cuda.synchronize()
+        assert calls == [(split, None), (0, split)] * 2, calls
     finally:
         dist.destroy_process_group()
     assert rel_err(tr_b.opt_gen.p, tr_a.opt_gen.p) < 1e-6 and rel_err(tr_b.opt_d1.p, tr_a.opt_d1.p) < 1e-6
