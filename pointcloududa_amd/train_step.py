@@ -236,6 +236,7 @@ class AdversarialTrainer:
                 passes.append(("d4", "dis4", lambda e, i1, v: self.dis4(v.detach().transpose(2, 1), drop_mask)[0]))
             main = torch.cuda.current_stream()
             side = self._side_streams(len(passes)) if (self.d_streams and len(passes) > 1) else [None] * len(passes)
+            d_works = {}
             for (nm, hit, fwd), st in zip(passes, side):
                 if st is not None:
                     if ev is not None:
@@ -257,25 +258,34 @@ class AdversarialTrainer:
                             ls.append(l)
                             out[nm + "_loss_" + tag], out[hit + "_hit_" + tag] = l.detach(), acc
                         torch.autograd.backward(ls, [self._one, self._one])
-                        continue
-                    for tag, label, e, i1, v in (("src", 1.0, ent_s, in1_s, vert_s), ("tgt", 0.0, ent_t_d, in1_t, vert_t)):
-                        l, acc = L.bce_logits_const(fwd(e, i1, v), label, 1.0, want_acc=True)
-                        l.backward()
-                        out[nm + "_loss_" + tag], out[hit + "_hit_" + tag] = l.detach(), acc
+                    else:
+                        for tag, label, e, i1, v in (("src", 1.0, ent_s, in1_s, vert_s),
+                                                     ("tgt", 0.0, ent_t_d, in1_t, vert_t)):
+                            l, acc = L.bce_logits_const(fwd(e, i1, v), label, 1.0, want_acc=True)
+                            l.backward()
+                            out[nm + "_loss_" + tag], out[hit + "_hit_" + tag] = l.detach(), acc
+                    # data-parallel: this network's all-reduce starts behind its own passes (on its stream), under the
+                    # other discriminators' kernels
+                    d_works[nm] = getattr(self, "opt_" + nm).all_reduce_grads_async(self.group)
             for st in side:
                 if st is not None:
                     main.wait_stream(st)
-            if keep:
+            if keep:      # (single-process diagnostics: with collectives on these would be the summed gradients)
                 for nm, o in (("grad_d1", self.opt_d1), ("grad_d2", self.opt_d2), ("grad_d4", self.opt_d4)):
                     if o is not None:
+                        o.finish_all_reduce(d_works[nm[5:]][0])
                         self.last[nm] = o.g.clone()
             # 5. update (:325-330)
             if g_work is not None:
                 self.opt_gen.finish_all_reduce(g_work)
                 self.opt_gen.step(g_scale)
                 g_work = None
-            for o in self._d_opts():
-                o.step(o.all_reduce_grads(self.group))
+            for nm in ("d1", "d2", "d4"):
+                o = getattr(self, "opt_" + nm)
+                if o is not None:
+                    work, scale = d_works[nm]
+                    o.finish_all_reduce(work)
+                    o.step(scale)
         if g_work is not None:      # no discriminator configured
             self.opt_gen.finish_all_reduce(g_work)
             self.opt_gen.step(g_scale)
