@@ -37,11 +37,12 @@ class _Tape:
     def __init__(self, module, training):
         self.m, self.training, self.steps = module, training, []
         self.P = dict(module.named_parameters())
+        # which parameters want a gradient is decided when the forward pass is recorded, as autograd does
+        self.wants = {k for k, p in self.P.items() if p.requires_grad}
         self.P.update(dict(module.named_buffers()))
 
     def G(self, name):
-        p = self.P[name]
-        return ensure_grad(p) if p.requires_grad else None
+        return ensure_grad(self.P[name]) if name in self.wants else None
 
     def run(self):
         for fn in reversed(self.steps):

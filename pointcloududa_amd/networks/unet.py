@@ -112,7 +112,7 @@ class _SegEngine:
         nb = self.nb
         if H % (1 << nb) or W % (1 << nb):
             raise ValueError("input size must be divisible by %d" % (1 << nb))
-        S = {"hw": (H, W), "n": n}
+        S = {"hw": (H, W), "n": n, "wants": {k for k, p in P.items() if p.requires_grad}}
         cur, h, w, res = x, H, W, None
         skips = []
         for i in range(nb):                                           # unet.py:35-51
@@ -161,9 +161,10 @@ class _SegEngine:
 
     # ---------------------------------------------------------------- backward
     def backward(self, P, S, d_logits, d_verts, need_dx):
+        wants = S["wants"]       # parameters that required a gradient when the forward pass ran (autograd's rule)
+
         def G(name):
-            p = P[name]
-            return ensure_grad(p) if p.requires_grad else None
+            return ensure_grad(P[name]) if name in wants else None
 
         nb, (H, W), n = self.nb, S["hw"], S["n"]
         d_skips = [None] * nb
