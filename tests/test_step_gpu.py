@@ -206,3 +206,33 @@ def test_step_with_rccl_collectives_in_a_one_rank_group(dev, monkeypatch):
     finally:
         dist.destroy_process_group()
     assert rel_err(tr_b.opt_gen.p, tr_a.opt_gen.p) < 1e-6 and rel_err(tr_b.opt_d1.p, tr_a.opt_d1.p) < 1e-6
+
+
+def test_full_size_step_is_reproducible_and_stream_schedule_keeps_the_arithmetic(dev):
+    """BASELINE config 3 at full size (B=32, 256x256, 32 filters, three discriminators).  (a) Two trainers from the
+    same weights walk a BIT-IDENTICAL trajectory over three steps with the concurrent-stream schedule on: every
+    kernel is deterministic (fixed-order split-K reductions, no atomics), so any difference would be a race between
+    streams.  (b) The single-stream schedule with separate source / target discriminator passes (the reference's
+    order of operations) gives the same losses and parameters up to fp32 summation order."""
+    from oracle.synth import synth_batch
+    cfg_kw = dict(filters=32, in_channels=1, n_class=4, pointnet=True, fc_inch=121)
+    cfg, tr_a = _build(cfg_kw, 21, dev)
+    _, tr_b = _build(cfg_kw, 21, dev)
+    _, tr_c = _build(cfg_kw, 21, dev)
+    tr_c.d_streams = tr_c.d_overlap = tr_c.d_batch = tr_c.early_fwd2 = False
+    batches = [[torch.from_numpy(t).to(dev) for t in synth_batch(32, 1, 4, 256, seed=900 + i)] for i in range(3)]
+    outs = []
+    for tr in (tr_a, tr_b, tr_c):
+        for b in batches:
+            out = tr.step(*b)
+        torch.cuda.synchronize()
+        outs.append(tr.to_host(out, tr.cfg))
+    for opt in ("opt_gen", "opt_d1", "opt_d2", "opt_d4"):
+        assert torch.equal(getattr(tr_a, opt).p, getattr(tr_b, opt).p), opt
+    assert outs[0] == outs[1]
+    for k in ("seg_loss", "adv_loss", "d1_loss_src", "d2_loss_tgt", "d4_loss_src"):
+        assert abs(outs[0][k] - outs[2][k]) <= 2e-3 * max(1e-3, abs(outs[2][k])), (k, outs[0][k], outs[2][k])
+    # three Adam steps from identical weights: lr * sign-like updates amplify summation-order noise on near-zero
+    # gradients, so parameters are compared in aggregate
+    for opt, lim in (("opt_gen", 2e-3), ("opt_d1", 1e-5), ("opt_d2", 1e-5), ("opt_d4", 1e-3)):
+        assert rel_err(getattr(tr_a, opt).p, getattr(tr_c, opt).p) < lim, opt
