@@ -129,3 +129,40 @@ def test_conv_concat_affine_split(dev):
     d1b = base.clone()
     op.dgrad(gz.to(dev), w.to(dev), h, w_, dx=d1b, dx2=d2, accumulate=True)
     assert rel_err(d1b - base, xin.grad[:, :c1]) < 1e-4
+
+
+@pytest.mark.parametrize("cin,cout,hw,k,s,p", [(32, 32, 256, 3, 1, 1), (64, 128, 129, 4, 2, 2), (256, 256, 32, 3, 1, 1)])
+def test_conv_full_batch_properties(dev, cin, cout, hw, k, s, p):
+    """BASELINE's full batch (32) at the benchmark's layer shapes, through properties that need no CPU reference:
+    samples are independent (the batch result of sample i IS the single-sample result, bit for bit, forward and
+    dgrad: tiles never mix samples), the weight gradient of the batch is the sum of the halves' (split-K over
+    pixels and samples: fp32 summation order only), and one small CPU-checked sample pins the absolute values."""
+    from pointcloududa_amd import kernels as K
+    K.set_precision("bf16x3")
+    torch.manual_seed(5)
+    n = 32
+    op = K.ConvOp(cin, cout, k, stride=s, pad=p)
+    x = torch.randn(n, cin, hw, hw, device=dev)
+    w = torch.randn(cout, cin, k, k, device=dev) * (2.0 / (cin * k * k)) ** 0.5
+    b = torch.randn(cout, device=dev) * 0.1
+    y, _, _ = op.forward(x, w, b, 0.2, hw, hw)
+    oh = y.shape[2]
+    for i in (0, 17, 31):
+        yi, _, _ = op.forward(x[i:i + 1].contiguous(), w, b, 0.2, hw, hw)
+        assert torch.equal(yi[0], y[i]), i
+    ref = F.leaky_relu(F.conv2d(x[3:4].cpu(), w.cpu(), b.cpu(), stride=s, padding=p), 0.2)
+    assert rel_err(y[3:4], ref) < 1e-4
+    gz = torch.randn(n, cout, oh, oh, device=dev)
+    dx = op.dgrad(gz, w, hw, hw)
+    d17 = op.dgrad(gz[17:18].contiguous(), w, hw, hw)
+    assert torch.equal(d17[0], dx[17])
+    dw, db = torch.zeros_like(w), torch.zeros_like(b)
+    op.wgrad(x, gz, dw, db, hw, hw)
+    dwh, dbh = torch.zeros_like(w), torch.zeros_like(b)
+    op.wgrad(x[:16].contiguous(), gz[:16].contiguous(), dwh, dbh, hw, hw)
+    op.wgrad(x[16:].contiguous(), gz[16:].contiguous(), dwh, dbh, hw, hw)      # accumulates
+    assert rel_err(dw, dwh) < 2e-5 and rel_err(db, dbh) < 2e-5
+    # <dy, conv(x)> = <dgrad(dy), x>: the forward (without bias / activation) and dgrad kernels are adjoint
+    y_lin, _, _ = op.forward(x, w, None, 1.0, hw, hw)
+    lhs, rhs = float((gz.double() * y_lin.double()).sum()), float((dx.double() * x.double()).sum())
+    assert abs(lhs - rhs) <= 2e-5 * max(abs(lhs), abs(rhs), 1.0)
