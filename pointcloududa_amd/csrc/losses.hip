@@ -153,14 +153,22 @@ __global__ __launch_bounds__(256) void seg_loss_partial_kernel(const float* __re
 __global__ void seg_loss_final_kernel(const float* __restrict__ part, int nblocks, int c, double numel_main,
                                       double* __restrict__ sums, float* __restrict__ out2) {
   __shared__ double sh[2 * MAXC + 1];
+  __shared__ double red[256];
   const int nacc = 2 * c + 1;
-  if ((int)threadIdx.x < nacc) {
+  // fixed-order tree per accumulator (a single lane per accumulator walking thousands of partials took 110 us
+  // between the segmenter's forward and backward passes)
+  for (int a = 0; a < nacc; ++a) {
     double s = 0;
-    for (int b = 0; b < nblocks; ++b) s += (double)part[(long long)b * nacc + threadIdx.x];
-    sums[threadIdx.x] = s;
-    sh[threadIdx.x] = s;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += (double)part[(long long)b * nacc + a];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) { sums[a] = red[0]; sh[a] = red[0]; }
+    __syncthreads();
   }
-  __syncthreads();
   if (threadIdx.x == 0) {
     out2[0] = (float)(sh[0] / numel_main);
     double j = 0;
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(256) void nn_loss_fwd_kernel(const float* __restric
                                                           float* __restrict__ val_ws, float* __restrict__ per_item) {
   __shared__ float sx[NN_MAXP * 3], sy[NN_MAXP * 3], rx[NN_MAXP], ry[NN_MAXP];
   __shared__ float sh[4];
-  const int b = blockIdx.x, nb = gridDim.x;
+  const int b = blockIdx.x, nb = gridDim.x, dir = blockIdx.y;      // one workgroup per (item, direction)
   const float* px = x + (long long)b * npts * 3;
   const float* py = y + (long long)b * npts * 3;
   for (int i = threadIdx.x; i < npts * 3; i += 256) { sx[i] = px[i]; sy[i] = py[i]; }
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(256) void nn_loss_fwd_kernel(const float* __restric
   __syncthreads();
   float tot = 0.f;
   // direction 1: for every x_i the nearest y_j ; direction 2: for every y_j the nearest x_i
-  for (int dir = 0; dir < 2; ++dir) {
+  {
     const float* A = dir == 0 ? sx : sy;
     const float* Bm = dir == 0 ? sy : sx;
     const float* ra = dir == 0 ? rx : ry;
@@ -303,13 +311,13 @@ __global__ __launch_bounds__(256) void nn_loss_fwd_kernel(const float* __restric
   tot = wave_sum(tot);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = tot;
   __syncthreads();
-  if (threadIdx.x == 0) per_item[b] = ((sh[0] + sh[1]) + (sh[2] + sh[3])) / (float)npts;
+  if (threadIdx.x == 0) per_item[dir * nb + b] = ((sh[0] + sh[1]) + (sh[2] + sh[3])) / (float)npts;
 }
 
 __global__ void nn_loss_final_kernel(const float* __restrict__ per_item, int b, float* loss) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     float s = 0.f;
-    for (int i = 0; i < b; ++i) s += per_item[i];
+    for (int i = 0; i < b; ++i) s += per_item[i] + per_item[b + i];     // the two directions' means of item i
     *loss = s / (float)b;
   }
 }
@@ -434,7 +442,7 @@ extern "C" int pcuda_seg_loss_fwd(const float* logits, const uint8_t* onehot, in
   }
 #undef SEG_CASE
   PCUDA_CHECK_LAUNCH("seg_loss_partial_kernel");
-  hipLaunchKernelGGL(seg_loss_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, (const float*)part, blocks, c,
+  hipLaunchKernelGGL(seg_loss_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, (const float*)part, blocks, c,
                      numel_main, sums, out2);
   PCUDA_CHECK_LAUNCH("seg_loss_final_kernel");
   return PCUDA_OK;
@@ -475,9 +483,9 @@ extern "C" int pcuda_nn_loss_fwd(const float* x, const float* y, int b, int npts
                                  float* val_ws, pcuda_stream_t s) {
   if (!x || !y || !loss || !idx_ws || !val_ws || b <= 0 || npts <= 0 || npts > NN_MAXP)
     PCUDA_FAIL(PCUDA_E_BADARG, "nn_loss_fwd: bad arguments (npts <= %d)", NN_MAXP);
-  // per-item means live behind the 2*b*npts value slots (caller sizes val_ws as 2*b*npts + b floats)
+  // per-item means live behind the 2*b*npts value slots (caller sizes val_ws as 2*b*npts + 2*b floats)
   float* per_item = val_ws + (size_t)2 * b * npts;
-  hipLaunchKernelGGL(nn_loss_fwd_kernel, dim3(b), dim3(256), 0, (hipStream_t)s, x, y, npts, idx_ws, val_ws, per_item);
+  hipLaunchKernelGGL(nn_loss_fwd_kernel, dim3(b, 2), dim3(256), 0, (hipStream_t)s, x, y, npts, idx_ws, val_ws, per_item);
   PCUDA_CHECK_LAUNCH("nn_loss_fwd_kernel");
   hipLaunchKernelGGL(nn_loss_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, (const float*)per_item, b, loss);
   PCUDA_CHECK_LAUNCH("nn_loss_final_kernel");
