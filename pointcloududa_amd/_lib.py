@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpcuda_hip.so")
+LIB_PATH = os.environ.get("PCUDA_LIB") or os.path.join(_HERE, "lib", "libpcuda_hip.so")   # (PCUDA_LIB: A/B builds)
 
 PREC_BF16X3, PREC_BF16 = 0, 1
 ACT_SIGMOID, ACT_SOFTMAX = 0, 1

@@ -250,7 +250,11 @@ __device__ __forceinline__ TileGeom tile_decode(const IgemmParams& p, int L) {
   return g;
 }
 
-// PCUDA_DBG bit 128: per-phase cycle sums of wave 0 of every workgroup (timing experiments only)
+// PCUDA_DBG bit 128: per-phase cycle sums of wave 0 of every workgroup (timing experiments only).  Compiled in only
+// with -DPCUDA_CLK_DEBUG (make CLK=1): the eight 64-bit counters and the stamps cost scalar registers and pin the
+// schedule around every phase boundary.
+#ifdef PCUDA_CLK_DEBUG
+#define DBG_CLK_DECL unsigned long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
 #define DBG_CLK(i)                                                                  \
   __builtin_amdgcn_sched_barrier(0);                                                \
   if (p.dbg & 128) {                                                                \
@@ -268,6 +272,21 @@ __device__ __forceinline__ TileGeom tile_decode(const IgemmParams& p, int L) {
     clk[i] += now_ - tlast; tlast = now_;                                           \
   }                                                                                 \
   __builtin_amdgcn_sched_barrier(0);
+#define DBG_CLK_FLUSH                                                               \
+  if ((p.dbg & 128) && p.dbg_clk && tid == 0) {                                     \
+    for (int i = 0; i < 8; ++i) atomicAdd(&p.dbg_clk[i], clk[i]);                   \
+  }
+#else
+#define DBG_CLK_DECL
+#define DBG_CLK(i) PCUDA_CLK_FENCE
+#define DBG_CLK_ACC(i) PCUDA_CLK_FENCE
+#define DBG_CLK_FLUSH
+#ifdef PCUDA_CLK_KEEP_FENCES
+#define PCUDA_CLK_FENCE __builtin_amdgcn_sched_barrier(0);
+#else
+#define PCUDA_CLK_FENCE
+#endif
+#endif
 
 // WV = weight-copy register slots per lane and plane.  WV = 2: weight groups of <= 512 vectors, two
 // workgroups per CU.  WV = 6 / 12 (CO_TILE 32 / 64): ONE workgroup per CU with up to nine taps of weights
@@ -324,7 +343,7 @@ __global__ __launch_bounds__(256, (WV > 3 ? 1 : 2)) void igemm_pipe_kernel(const
 
   f32x16 acc[CO_BLKS][NPB];
   XFast<PF> pre;
-  unsigned long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+  DBG_CLK_DECL
 
   int L = lo + slot, chunk = 0;
   bool have = L < hi;
@@ -554,10 +573,7 @@ __global__ __launch_bounds__(256, (WV > 3 ? 1 : 2)) void igemm_pipe_kernel(const
     DBG_CLK(6)
     L = nL; chunk = nchunk; g = ng; have = nhave;
   }
-  if ((p.dbg & 128) && p.dbg_clk && tid == 0) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) atomicAdd(&p.dbg_clk[i], clk[i]);
-  }
+  DBG_CLK_FLUSH
 }
 
 

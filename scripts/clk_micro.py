@@ -1,4 +1,5 @@
-"""per-phase cycle sums of igemm_pipe_kernel (PCUDA_DBG=128) for single layers"""
+"""per-phase cycle sums of igemm_pipe_kernel (PCUDA_DBG=128) for single layers.
+Needs a library with the stamps compiled in: make -C pointcloududa_amd/csrc clean all CLK=1 (or OUT=<path> and PCUDA_LIB=<path>)."""
 import os, sys, ctypes
 os.environ["PCUDA_DBG"] = "128"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
