@@ -293,7 +293,7 @@ __device__ __forceinline__ TileGeom tile_decode(const IgemmParams& p, int L) {
 // resident (512 VGPRs per lane: the whole group sits in registers between its loads and its LDS
 // write) -- a stage then has one weight round trip, issued in front of the X prefetch, and no barrier
 // inside its MFMA phase.
-template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV>
+template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ>
 __global__ __launch_bounds__(256, (WV > 3 ? 1 : 2)) void igemm_pipe_kernel(const IgemmParams p, const int x_cap, const int total) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CO_TILE = 32 * CO_BLKS;
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256, (WV > 3 ? 1 : 2)) void igemm_pipe_kernel(const
   TileGeom g;
   if (have) {
     g = tile_decode<CLAMP, NPB>(p, L);
-    if (p.xq) xq_issue<PF>(pre, p.x, g.n, p.cin, 0, p.in_h, p.in_w, g.oy0, g.ox0, g.th, g.tw, tid);
+    if (XQ) xq_issue<PF>(pre, p.x, g.n, p.cin, 0, p.in_h, p.in_w, g.oy0, g.ox0, g.th, g.tw, tid);
     else xfast_issue<PF>(pre, p.x, g.n, p.cin, 0, p.in_h, p.in_w, p.in_shift, p.in_row, g.oy0, g.ox0, g.tw, g.npix,
                          (min(32, p.cin) + 7) >> 3, tid);
   }
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256, (WV > 3 ? 1 : 2)) void igemm_pipe_kernel(const
     DBG_CLK(7)
     __syncthreads();   // every wave is done with the previous stage's X / W / reduction scratch
     DBG_CLK(0)
-    if (p.xq) xq_commit<X3, PF>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.ox0, g.th, g.tw, nks * 2, tid);
+    if (XQ) xq_commit<X3, PF>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.ox0, g.th, g.tw, nks * 2, tid);
     else xfast_commit<X3, PF>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.npix, (cvalid + 7) >> 3, nks * 2, tid);
     DBG_CLK(1)
     if (CLAMP && tid < 5) {
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256, (WV > 3 ? 1 : 2)) void igemm_pipe_kernel(const
     if (nhave && nL != L) ng = tile_decode<CLAMP, NPB>(p, nL);
     // unconditional (no stage left: zero pixels, every lane out of range -> no memory traffic)
     auto issue_next = [&]() {
-      if (p.xq) xq_issue<PF>(pre, p.x, ng.n, p.cin, nhave ? nchunk : 0, p.in_h, p.in_w, ng.oy0, ng.ox0, nhave ? ng.th : 0,
+      if (XQ) xq_issue<PF>(pre, p.x, ng.n, p.cin, nhave ? nchunk : 0, p.in_h, p.in_w, ng.oy0, ng.ox0, nhave ? ng.th : 0,
                              ng.tw, tid);
       else xfast_issue<PF>(pre, p.x, ng.n, p.cin, nhave ? nchunk : 0, p.in_h, p.in_w, p.in_shift, p.in_row, ng.oy0,
                            ng.ox0, ng.tw, nhave ? ng.npix : 0, 4, tid);
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256, (WV > 3 ? 1 : 2)) void igemm_pipe_kernel(const
 // all CO_BLKS row blocks; 4: 128-pixel tiles with CO_BLKS = 2, waves 0-3 take row block 0, 4-7 block 1).
 // ------------------------------------------------------------------------------------------
 #define IG8_WV 6   // weight-copy slots per lane and plane: 6 * 512 vectors >= 9 taps x 64 rows x 5
-template <bool X3, int CO_BLKS, bool CLAMP, int NPBT, int PF>
+template <bool X3, int CO_BLKS, bool CLAMP, int NPBT, int PF, bool XQ>
 __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, const int x_cap, const int total) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CO_TILE = 32 * CO_BLKS, NT = 512, WV = IG8_WV;
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
   XFast<PF> pre;
 
   auto issue_x = [&](const TileGeom& t, int ch, bool live) {
-    if (p.xq) xq_issue<PF, NT>(pre, p.x, t.n, p.cin, live ? ch : 0, p.in_h, p.in_w, t.oy0, t.ox0, live ? t.th : 0, t.tw, tid);
+    if (XQ) xq_issue<PF, NT>(pre, p.x, t.n, p.cin, live ? ch : 0, p.in_h, p.in_w, t.oy0, t.ox0, live ? t.th : 0, t.tw, tid);
     else xfast_issue<PF, NT>(pre, p.x, t.n, p.cin, live ? ch : 0, p.in_h, p.in_w, p.in_shift, p.in_row, t.oy0, t.ox0, t.tw,
                              live ? t.npix : 0, 4, tid);
   };
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
     __syncthreads();   // every wave is done with the previous stage's X / W / reduction scratch
     float bias_r = 0.f;
     if (chunk == p.nchunks - 1 && p.bias && tid < CO_TILE) bias_r = p.bias[min(g.cot * CO_TILE + tid, p.cout - 1)];
-    if (p.xq) xq_commit<X3, PF, NT>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.ox0, g.th, g.tw, nks * 2, tid);
+    if (XQ) xq_commit<X3, PF, NT>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.ox0, g.th, g.tw, nks * 2, tid);
     else xfast_commit<X3, PF, NT>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.npix, (cvalid + 7) >> 3, nks * 2, tid);
     if (CLAMP && tid < 5) {
       *(uint4*)(Xhi + (size_t)g.npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
@@ -795,9 +795,9 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
   }
 }
 
-template <bool X3, int CO_BLKS, bool CLAMP, int NPBT, int PF>
+template <bool X3, int CO_BLKS, bool CLAMP, int NPBT, int PF, bool XQ>
 static int launch_igemm8_t(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
-  auto kern = igemm8_kernel<X3, CO_BLKS, CLAMP, NPBT, PF>;
+  auto kern = igemm8_kernel<X3, CO_BLKS, CLAMP, NPBT, PF, XQ>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HARD);
@@ -814,7 +814,11 @@ static int launch_igemm8_t(const IgemmParams& p, const IgemmPlan& pl, hipStream_
 
 template <bool X3>
 static int igemm8_dispatch(const IgemmParams& p, const IgemmPlan& pl, int co_blks, int pf, hipStream_t s) {
-#define IG8_PF(CB_, CL_, NB_) (pf == 1 ? launch_igemm8_t<X3, CB_, CL_, NB_, 1>(p, pl, s) : launch_igemm8_t<X3, CB_, CL_, NB_, 2>(p, pl, s))
+// (the staging path is a template parameter: with both paths behind a runtime flag every kernel carried the code and
+// the register pressure of the one it does not use)
+#define IG8_PF(CB_, CL_, NB_)                                                                                        \
+  (p.xq ? (pf == 1 ? launch_igemm8_t<X3, CB_, CL_, NB_, 1, true>(p, pl, s) : launch_igemm8_t<X3, CB_, CL_, NB_, 2, true>(p, pl, s)) \
+        : (pf == 1 ? launch_igemm8_t<X3, CB_, CL_, NB_, 1, false>(p, pl, s) : launch_igemm8_t<X3, CB_, CL_, NB_, 2, false>(p, pl, s)))
 #define IG8_CL(CB_, NB_) (pl.clamp ? IG8_PF(CB_, true, NB_) : IG8_PF(CB_, false, NB_))
   if (pl.npb == 2) return co_blks == 2 ? IG8_CL(2, 8) : IG8_CL(1, 8);
   return IG8_CL(2, 4);   // 128-pixel tiles: only with two row blocks
@@ -845,9 +849,9 @@ static int launch_igemm_c(const IgemmParams& p, const IgemmPlan& pl, hipStream_t
                      : launch_igemm_t<X3, CO_BLKS, false, 1>(p, pl.x_cap, pl.lds, s);
 }
 
-template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV>
+template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ>
 static int launch_pipe_t(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
-  auto kern = igemm_pipe_kernel<X3, CO_BLKS, CLAMP, NPB, PF, WV>;
+  auto kern = igemm_pipe_kernel<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ>;
   static size_t lds_set = 0;
   if (pl.lds > 32 * 1024 && pl.lds > lds_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HARD);
@@ -876,15 +880,16 @@ static int launch_pipe_t(const IgemmParams& p, const IgemmPlan& pl, hipStream_t 
 
 template <bool X3, int CO_BLKS, bool CLAMP, int NPB>
 static int launch_pipe_pf(const IgemmParams& p, const IgemmPlan& pl, int pf, hipStream_t s) {
-  constexpr int WVF = 5;
-  if (pl.fat) {
-    if (pf == 1) return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 1, WVF>(p, pl, s);
-    if (pf == 2) return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 2, WVF>(p, pl, s);
-    return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 3, WVF>(p, pl, s);
+  // (the one-workgroup-per-CU "fat" variant, WV = 5, measured slower everywhere and is no longer instantiated)
+  if (pl.fat) PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "igemm: the fat plan is not built");
+  if (p.xq) {
+    if (pf == 1) return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 1, 3, true>(p, pl, s);
+    if (pf == 2) return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 2, 3, true>(p, pl, s);
+    return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 3, 3, true>(p, pl, s);
   }
-  if (pf == 1) return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 1, 3>(p, pl, s);
-  if (pf == 2) return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 2, 3>(p, pl, s);
-  return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 3, 3>(p, pl, s);
+  if (pf == 1) return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 1, 3, false>(p, pl, s);
+  if (pf == 2) return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 2, 3, false>(p, pl, s);
+  return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 3, 3, false>(p, pl, s);
 }
 
 template <bool X3, int CO_BLKS>
