@@ -317,7 +317,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (TAPS_MAX <= 9 && PF <= 1)) ? 
   XFast<XPF> xpre;
   float zv[ZJ][8];
   ZConst<CO_TILE, NT> zc;
-  const bool zfast = PF > 0 && p.aligned4;   // uniform
+  // (uniform; MODE 0 is only dispatched for float4-readable dZ rows: the scalar dZ path is compiled out of it)
+  const bool zfast = PF > 0 && (MODE == 0 || p.aligned4);
   if (zfast) zfast_init<CO_TILE, NT>(zc, p, cot, tid);
   WTile cur = wtile_decode<CLAMP>(p, min(tile_lo, ntiles - 1));
   if (PF > 0 && tile_lo < tile_hi) {
@@ -362,9 +363,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (TAPS_MAX <= 9 && PF <= 1)) ? 
     }
 
     // ---- MFMA phase
-    if (!(p.dbg & 64)) {
+#ifdef PCUDA_CLK_DEBUG
+    if (!(p.dbg & 64))      // (timing experiments: skip the MFMA phase)
+#endif
       wgrad_mfma_phase<X3, MAXT, MODE>(p, acc, Xhi, Xlo, Zhi, Zlo, cb, lane, tap_off, tap_dy, tap_dx, cur);
-    }
     cur = nxt;
   }
 
@@ -415,7 +417,7 @@ static int launch_wgrad_t(const WgradParams& p, int x_cap, size_t lds, float* db
 template <bool X3>
 static int wgrad_dispatch(const WgradParams& p, int co_blks, bool clamp, int taps_max, int pf, int x_cap, size_t lds,
                           float* dbp, dim3 grid, hipStream_t s) {
-  const int mode = clamp ? 2 : (p.tw16 ? 0 : 1);
+  const int mode = clamp ? 2 : ((p.tw16 && p.aligned4) ? 0 : 1);
   if (pf >= 100) {   // eight waves (16-tap groups): pf - 100 = staging slots per lane at 512 lanes
 #define WG8_PF(CB_, MD_) (pf == 101 ? launch_wgrad_t<X3, CB_, MD_, 16, 1, 8>(p, x_cap, lds, dbp, grid, s) : launch_wgrad_t<X3, CB_, MD_, 16, 2, 8>(p, x_cap, lds, dbp, grid, s))
 #define WG8_MD(CB_) (mode == 2 ? WG8_PF(CB_, 2) : mode == 0 ? WG8_PF(CB_, 0) : WG8_PF(CB_, 1))
