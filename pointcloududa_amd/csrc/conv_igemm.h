@@ -62,6 +62,7 @@ struct WgradParams {
   float* partial;          // [ksplit][cout][cin][ntaps_total] fp32
   int aligned4;            // dz rows can be read with float4
   int tw16;                // TW % 16 == 0 and TW*TH == 128: a k-step's 16 pixel slots share one tile row
+  int xq;                  // 1: quad (float4) staging of the input tile (in_w % 4 == 0, no upsampling fold)
   int dbg;                 // PCUDA_DBG bits (timing experiments only): 16 no X staging, 32 no dZ staging, 64 no MFMA
 };
 

@@ -170,6 +170,14 @@ extern "C" int pcuda_conv2d_wgrad(const pcuda_conv_geom* g, int prec, const pcud
     static int now8 = -1;
     if (now8 < 0) { const char* e = getenv("PCUDA_WG_NO8"); now8 = (e && atoi(e)) ? 1 : 0; }
     if (!now8 && pf > 0 && w.taps_per_group > 9 && x_cap <= 1024) pf = 100 + (x_cap <= 512 ? 1 : 2);
+    {   // quad staging where the (row, quad) items of a tile fit the staging slots of this variant
+      static int noxq = -1;
+      if (noxq < 0) { const char* e = getenv("PCUDA_NOXQ"); noxq = e ? atoi(e) : 0; }
+      const int slots = pf >= 100 ? pf - 100 : pf, per = pf >= 100 ? 128 : 64;
+      const int ih = clamp ? (w.ih_t < g->in_h ? w.ih_t : g->in_h) : w.ih_t;
+      const int in_w_phys = g->in_up ? g->in_w / 2 : g->in_w;
+      p.xq = (!noxq && slots > 0 && !g->in_up && (in_w_phys & 3) == 0 && (ih * ((w.iw_t + 6) / 4) + per - 1) / per <= slots) ? 1 : 0;
+    }
     snprintf(tag, sizeof(tag), "wgrad n%d cin%d cout%d %dx%d k%d s%d d%d ksplit%d clamp%d pf%d lds%zu", g->n, g->cin,
              g->cout, g->out_h, g->out_w, g->k, g->stride, g->dil, w.ksplit, clamp ? 1 : 0, pf, lds);
     ProfScope prof(PCUDA_FAM_CONV_WGRAD, flops, s, tag);

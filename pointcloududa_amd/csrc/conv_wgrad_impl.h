@@ -254,7 +254,7 @@ __device__ __forceinline__ void wgrad_mfma_phase(const WgradParams& p, f32x16 (&
 // MODE: see wgrad_mfma_phase (2 = clamped LDS tile)
 // NW = 4 waves, or 8 (one 512-thread workgroup per CU: two waves per SIMD for the 16-tap stride-2 layers, whose
 // LDS tiles allow only one workgroup per CU; per lane the staging work, its registers and the accumulators halve)
-template <bool X3, int CO_BLKS, int MODE, int TAPS_MAX, int PF, int NW = 4>
+template <bool X3, int CO_BLKS, int MODE, int TAPS_MAX, int PF, int NW = 4, bool XQ = false>
 __global__ __launch_bounds__(64 * NW, (NW == 8 || (TAPS_MAX <= 9 && PF <= 1)) ? 2 : 1) void wgrad_kernel(const WgradParams p, const int x_cap, float* db_partial) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool CLAMP = MODE == 2;
@@ -322,8 +322,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (TAPS_MAX <= 9 && PF <= 1)) ? 
   if (zfast) zfast_init<CO_TILE, NT>(zc, p, cot, tid);
   WTile cur = wtile_decode<CLAMP>(p, min(tile_lo, ntiles - 1));
   if (PF > 0 && tile_lo < tile_hi) {
-    xfast_issue<XPF, NT>(xpre, p.x, cur.n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row, cur.oy0, cur.ox0, cur.tw,
-                     cur.npix, ngroups, tid);
+    // (XQ: float4 staging of rows of 4k pixels, as in the forward kernels -- a quarter of the load instructions)
+    if (XQ) xq_issue<XPF, NT>(xpre, p.x, cur.n, p.cin, chunk, p.in_h, p.in_w, cur.oy0, cur.ox0, cur.th, cur.tw, tid);
+    else xfast_issue<XPF, NT>(xpre, p.x, cur.n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row, cur.oy0, cur.ox0, cur.tw,
+                              cur.npix, ngroups, tid);
     if (ZPRE) {
       if (zfast) zfast_issue<CO_TILE, NT>(zv, zc, p, cur);
       else zpre_issue<CO_TILE, NT>(zv, p, cur, cot, tid);
@@ -335,7 +337,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (TAPS_MAX <= 9 && PF <= 1)) ? 
     const int oy0 = cur.oy0, ox0 = cur.ox0, tw = cur.tw, npix = cur.npix;
     __syncthreads();   // the previous tile's MFMA phase is done with the LDS tiles
     if (PF > 0) {
-      xfast_commit<X3, XPF, NT>(xpre, Xhi, Xlo, p.x, p.cin, chunk, npix, ngroups, 4, tid);
+      if (XQ) xq_commit<X3, XPF, NT>(xpre, Xhi, Xlo, p.x, p.cin, chunk, ox0, cur.th, tw, 4, tid);
+      else xfast_commit<X3, XPF, NT>(xpre, Xhi, Xlo, p.x, p.cin, chunk, npix, ngroups, 4, tid);
       if (!ZPRE) {
         if (zfast) zfast_issue<CO_TILE, NT>(zv, zc, p, cur);
         else zpre_issue<CO_TILE, NT>(zv, p, cur, cot, tid);
@@ -354,8 +357,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (TAPS_MAX <= 9 && PF <= 1)) ? 
     WTile nxt = cur;
     if (PF > 0 && tile + 1 < tile_hi) {   // (the block's last tile skips the loads altogether)
       nxt = wtile_decode<CLAMP>(p, tile + 1);
-      xfast_issue<XPF, NT>(xpre, p.x, nxt.n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row, nxt.oy0, nxt.ox0, nxt.tw,
-                       nxt.npix, ngroups, tid);
+      if (XQ) xq_issue<XPF, NT>(xpre, p.x, nxt.n, p.cin, chunk, p.in_h, p.in_w, nxt.oy0, nxt.ox0, nxt.th, nxt.tw, tid);
+      else xfast_issue<XPF, NT>(xpre, p.x, nxt.n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row, nxt.oy0, nxt.ox0, nxt.tw,
+                                nxt.npix, ngroups, tid);
       if (ZPRE) {
         if (zfast) zfast_issue<CO_TILE, NT>(zv, zc, p, nxt);
         else zpre_issue<CO_TILE, NT>(zv, p, nxt, cot, tid);
@@ -399,9 +403,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (TAPS_MAX <= 9 && PF <= 1)) ? 
 }
 
 
-template <bool X3, int CO_BLKS, int MODE, int TAPS_MAX, int PF, int NW = 4>
-static int launch_wgrad_t(const WgradParams& p, int x_cap, size_t lds, float* dbp, dim3 grid, hipStream_t s) {
-  auto kern = wgrad_kernel<X3, CO_BLKS, MODE, TAPS_MAX, PF, NW>;
+template <bool X3, int CO_BLKS, int MODE, int TAPS_MAX, int PF, int NW, bool XQ>
+static int launch_wgrad_q(const WgradParams& p, int x_cap, size_t lds, float* dbp, dim3 grid, hipStream_t s) {
+  auto kern = wgrad_kernel<X3, CO_BLKS, MODE, TAPS_MAX, PF, NW, XQ>;
   static size_t lds_set = 0;
   if (lds > 32 * 1024 && lds > lds_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HARD);
@@ -411,6 +415,12 @@ static int launch_wgrad_t(const WgradParams& p, int x_cap, size_t lds, float* db
   hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, s, p, x_cap, dbp);
   PCUDA_CHECK_LAUNCH("wgrad_kernel");
   return PCUDA_OK;
+}
+
+template <bool X3, int CO_BLKS, int MODE, int TAPS_MAX, int PF, int NW = 4>
+static int launch_wgrad_t(const WgradParams& p, int x_cap, size_t lds, float* dbp, dim3 grid, hipStream_t s) {
+  if (PF > 0 && p.xq) return launch_wgrad_q<X3, CO_BLKS, MODE, TAPS_MAX, PF, NW, (PF > 0)>(p, x_cap, lds, dbp, grid, s);
+  return launch_wgrad_q<X3, CO_BLKS, MODE, TAPS_MAX, PF, NW, false>(p, x_cap, lds, dbp, grid, s);
 }
 
 
