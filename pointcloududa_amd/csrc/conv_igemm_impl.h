@@ -293,7 +293,7 @@ __device__ __forceinline__ TileGeom tile_decode(const IgemmParams& p, int L) {
 // resident (512 VGPRs per lane: the whole group sits in registers between its loads and its LDS
 // write) -- a stage then has one weight round trip, issued in front of the X prefetch, and no barrier
 // inside its MFMA phase.
-template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ>
+template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ, bool STATS>
 __global__ __launch_bounds__(256, (WV > 3 ? 1 : 2)) void igemm_pipe_kernel(const IgemmParams p, const int x_cap, const int total) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CO_TILE = 32 * CO_BLKS;
@@ -537,13 +537,13 @@ __global__ __launch_bounds__(256, (WV > 3 ? 1 : 2)) void igemm_pipe_kernel(const
             const unsigned vo = pixo[pb] + hoff;
             if (p.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, soff, 0));
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, vo, soff, 0);
-            if (p.stats) {
+            if (STATS) {
               const float vs = (pok[pb] & (co0 + row < p.cout)) ? v : 0.f;
               s1 += vs;
               s2 += vs * vs;
             }
           }
-          if (p.stats) {
+          if (STATS) {
             s1 = half_wave_sum_hi16(s1);
             s2 = half_wave_sum_hi16(s2);
             if (r == 31) {
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256, (WV > 3 ? 1 : 2)) void igemm_pipe_kernel(const
           }
         }
       }
-      if (p.stats) {
+      if (STATS) {
         __syncthreads();
         if (tid < CO_TILE) {
           const int co = g.cot * CO_TILE + tid;
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256, (WV > 3 ? 1 : 2)) void igemm_pipe_kernel(const
 // all CO_BLKS row blocks; 4: 128-pixel tiles with CO_BLKS = 2, waves 0-3 take row block 0, 4-7 block 1).
 // ------------------------------------------------------------------------------------------
 #define IG8_WV 6   // weight-copy slots per lane and plane: 6 * 512 vectors >= 9 taps x 64 rows x 5
-template <bool X3, int CO_BLKS, bool CLAMP, int NPBT, int PF, bool XQ>
+template <bool X3, int CO_BLKS, bool CLAMP, int NPBT, int PF, bool XQ, bool STATS>
 __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, const int x_cap, const int total) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CO_TILE = 32 * CO_BLKS, NT = 512, WV = IG8_WV;
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
           v = v > 0.f ? v : v * p.slope;
           if (p.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, soff, 0));
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, vo, soff, 0);
-          if (p.stats) {
+          if (STATS) {
             const float vs = (pok & (co0 + row < p.cout)) ? v : 0.f;
             const float s1 = half_wave_sum_hi16(vs), s2 = half_wave_sum_hi16(vs * vs);
             if (r == 31) {
@@ -772,7 +772,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
           }
         }
       }
-      if (p.stats) {
+      if (STATS) {
         __syncthreads();
         if (tid < CO_TILE) {
           const int co = g.cot * CO_TILE + tid;
@@ -795,9 +795,9 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
   }
 }
 
-template <bool X3, int CO_BLKS, bool CLAMP, int NPBT, int PF, bool XQ>
-static int launch_igemm8_t(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
-  auto kern = igemm8_kernel<X3, CO_BLKS, CLAMP, NPBT, PF, XQ>;
+template <bool X3, int CO_BLKS, bool CLAMP, int NPBT, int PF, bool XQ, bool STATS>
+static int launch_igemm8_s(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
+  auto kern = igemm8_kernel<X3, CO_BLKS, CLAMP, NPBT, PF, XQ, STATS>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HARD);
@@ -810,6 +810,13 @@ static int launch_igemm8_t(const IgemmParams& p, const IgemmPlan& pl, hipStream_
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pl.lds, s, p, pl.x_cap, total);
   PCUDA_CHECK_LAUNCH("igemm8_kernel");
   return PCUDA_OK;
+}
+
+// (BatchNorm partial sums are a template parameter too: only the segmenter's forward convolutions produce them)
+template <bool X3, int CO_BLKS, bool CLAMP, int NPBT, int PF, bool XQ>
+static int launch_igemm8_t(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
+  return p.stats ? launch_igemm8_s<X3, CO_BLKS, CLAMP, NPBT, PF, XQ, true>(p, pl, s)
+                 : launch_igemm8_s<X3, CO_BLKS, CLAMP, NPBT, PF, XQ, false>(p, pl, s);
 }
 
 template <bool X3>
@@ -849,9 +856,9 @@ static int launch_igemm_c(const IgemmParams& p, const IgemmPlan& pl, hipStream_t
                      : launch_igemm_t<X3, CO_BLKS, false, 1>(p, pl.x_cap, pl.lds, s);
 }
 
-template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ>
-static int launch_pipe_t(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
-  auto kern = igemm_pipe_kernel<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ>;
+template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ, bool STATS>
+static int launch_pipe_s(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
+  auto kern = igemm_pipe_kernel<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, STATS>;
   static size_t lds_set = 0;
   if (pl.lds > 32 * 1024 && pl.lds > lds_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HARD);
@@ -876,6 +883,12 @@ static int launch_pipe_t(const IgemmParams& p, const IgemmPlan& pl, hipStream_t 
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), pl.lds, s, p, pl.x_cap, total);
   PCUDA_CHECK_LAUNCH("igemm_pipe_kernel");
   return PCUDA_OK;
+}
+
+template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ>
+static int launch_pipe_t(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
+  return p.stats ? launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, true>(p, pl, s)
+                 : launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, false>(p, pl, s);
 }
 
 template <bool X3, int CO_BLKS, bool CLAMP, int NPB>
