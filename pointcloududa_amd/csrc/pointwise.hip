@@ -4,7 +4,9 @@
 // Tensors are [n][c][hw] with dense planes and explicit batch / channel strides.
 #include "common.h"
 
+#ifndef PCH
 #define PCH 2048   // plane elements per workgroup (256 threads x 8)
+#endif
 
 __device__ __forceinline__ float block_sum(float v, float* sh) {
   v = wave_sum(v);
