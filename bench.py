@@ -154,6 +154,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--settle", type=int, default=40, help="untimed setup steps in front of the warm-up steps")
     ap.add_argument("--workload", default="full_uda", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--precision", default=os.environ.get("PCUDA_PRECISION", "bf16x3"), choices=["bf16x3", "bf16"])
@@ -195,6 +196,10 @@ def main():
     # 69.4 ms/step -- the ~4 ms between kernels is dependent-launch latency on the GPU, not host launch time.
     use_graph = world == 1 and os.environ.get("PCUDA_GRAPH", "0") == "1"
     step = tr.step_graphed if use_graph else tr.step
+    # settle phase (untimed setup, not part of --warmup): lazily created buffers, packed-weight caches, allocator pools
+    # of the side streams and the GPU's clocks reach their steady state only after a second or two of work
+    for _ in range(args.settle):
+        step(*batch)
     for _ in range(args.warmup):
         step(*batch)
     sync()
