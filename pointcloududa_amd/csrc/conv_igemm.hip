@@ -141,7 +141,7 @@ int plan_lds(bool x3, int co_tile, int x_cap, int ntaps, int mode, int* tg_out, 
   const size_t tab = 512;   // per-tap offset table + the epilogue's bias slice, behind the weight slabs
   if (ntaps < 1) ntaps = 1;
   // one copy pass per group: 3 / 5 slots x 256 lanes, or 6 slots x 512 lanes
-  const int cap = (mode == 2 ? 6 * 512 : (mode == 1 ? 5 * 256 : 3 * 256)) / (co_tile * 5);
+  const int cap = (mode == 2 ? 6 * 512 : (mode == 1 ? 5 * 256 : (co_tile == 32 ? 4 : 3) * 256)) / (co_tile * 5);
   // budgets: 3, 2, 1 workgroups per CU (160 KiB LDS)
   const size_t budgets[3] = {54528, 81920, 163840};
   for (int b = fat ? 2 : 0; b < 3; ++b) {

@@ -294,13 +294,13 @@ __device__ __forceinline__ TileGeom tile_decode(const IgemmParams& p, int L) {
 // write) -- a stage then has one weight round trip, issued in front of the X prefetch, and no barrier
 // inside its MFMA phase.
 template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ, bool STATS>
-__global__ __launch_bounds__(256, (WV > 3 ? 1 : 2)) void igemm_pipe_kernel(const IgemmParams p, const int x_cap, const int total) {
+__global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const IgemmParams p, const int x_cap, const int total) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CO_TILE = 32 * CO_BLKS;
   // DB (one workgroup per CU): weight groups alternate between two LDS buffers -- group i+1 is requested
   // before group i's MFMAs and written behind them -- and the next stage's input is requested in front of
   // the LAST group's MFMAs, so that no weight load ever queues behind the HBM-latency prefetch.
-  constexpr bool DB = WV > 3;
+  constexpr bool DB = WV > 4;
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int TW = p.tw, TPIX = p.tw * p.th;
@@ -895,14 +895,17 @@ template <bool X3, int CO_BLKS, bool CLAMP, int NPB>
 static int launch_pipe_pf(const IgemmParams& p, const IgemmPlan& pl, int pf, hipStream_t s) {
   // (the one-workgroup-per-CU "fat" variant, WV = 5, measured slower everywhere and is no longer instantiated)
   if (pl.fat) PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "igemm: the fat plan is not built");
+  // weight-copy slots per lane: four for the 32-row tiles (five taps per group where LDS allows: a 3x3 layer's
+  // weights in two round trips per stage instead of three), three for the 64-row tiles (LDS holds two taps anyway)
+  constexpr int WVN = CO_BLKS == 1 ? 4 : 3;
   if (p.xq) {
-    if (pf == 1) return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 1, 3, true>(p, pl, s);
-    if (pf == 2) return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 2, 3, true>(p, pl, s);
-    return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 3, 3, true>(p, pl, s);
+    if (pf == 1) return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 1, WVN, true>(p, pl, s);
+    if (pf == 2) return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 2, WVN, true>(p, pl, s);
+    return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 3, WVN, true>(p, pl, s);
   }
-  if (pf == 1) return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 1, 3, false>(p, pl, s);
-  if (pf == 2) return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 2, 3, false>(p, pl, s);
-  return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 3, 3, false>(p, pl, s);
+  if (pf == 1) return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 1, WVN, false>(p, pl, s);
+  if (pf == 2) return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 2, WVN, false>(p, pl, s);
+  return launch_pipe_t<X3, CO_BLKS, CLAMP, NPB, 3, WVN, false>(p, pl, s);
 }
 
 template <bool X3, int CO_BLKS>
