@@ -26,6 +26,39 @@ import torch.nn.functional as F
 
 Params = Dict[str, torch.Tensor]
 
+# --------------------------------------------------------------------------- #
+# shared-routing anchors (tests only)
+# --------------------------------------------------------------------------- #
+# The reference networks' gradients are discontinuous in their activations (LeakyReLU / ReLU sign, max-pool and
+# max-over-points argmax): two fp32-class implementations whose pre-activations differ by 1e-6 take different
+# branches on a few elements and then disagree on some weight gradients by percents.  To compare BACKWARD passes
+# at 1e-4 a test installs an anchor: a callable ``anchor(tag, z) -> z'`` invoked on every routing-relevant
+# intermediate (conv / linear outputs, normalisation outputs); it returns ``z + (z_other - z).detach()``, i.e. the
+# VALUES the implementation under test produced, while autograd still differentiates this restatement.  With no
+# anchor installed (the default, and always in make_golden.py) the functions below are the plain restatement.
+_ANCHOR = None
+
+
+class anchored:
+    """``with anchored(fn): ...`` installs ``fn(tag, tensor) -> tensor`` for the forward passes inside the block"""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __enter__(self):
+        global _ANCHOR
+        self.prev, _ANCHOR = _ANCHOR, self.fn
+        return self
+
+    def __exit__(self, *exc):
+        global _ANCHOR
+        _ANCHOR = self.prev
+        return False
+
+
+def _anc(tag: str, z):
+    return z if _ANCHOR is None else _ANCHOR(tag, z)
+
 
 # --------------------------------------------------------------------------- #
 # configuration + parameter inventories
@@ -215,7 +248,7 @@ def _bn2d(p: Params, name: str, x, training: bool):
 
 
 def _conv(p: Params, name: str, x, **kw):
-    return F.conv2d(x, p[name + ".weight"], p.get(name + ".bias"), **kw)
+    return _anc(name, F.conv2d(x, p[name + ".weight"], p.get(name + ".bias"), **kw))
 
 
 def _double_conv(p: Params, blk: str, x, cfg: SegCfg, training: bool):
@@ -264,7 +297,7 @@ def _point_head(p: Params, x, cfg: SegCfg):
         x = F.leaky_relu(_conv(p, "pointNet.conv2", x, padding=1), 0.01)
     x = F.leaky_relu(_conv(p, "pointNet.final_conv", x), 0.01)
     x = x.reshape(x.shape[0], x.shape[1], -1)
-    return F.linear(x, p["pointNet.final_fc.weight"], p["pointNet.final_fc.bias"])
+    return _anc("pointNet.final_fc", F.linear(x, p["pointNet.final_fc.weight"], p["pointNet.final_fc.bias"]))
 
 
 def _decoder(p: Params, x, skips: List[torch.Tensor], cfg: SegCfg, training: bool):
@@ -297,11 +330,11 @@ def seg_forward(p: Params, x, cfg: SegCfg, training: bool = True):
 def disc_forward(p: Params, x, ext: bool = False):
     """UncertaintyDiscriminator.forward (GAN.py:131-144): 4x4 s2 p2 convs, LeakyReLU(0.2)."""
     for n in ("conv1", "conv2", "conv3", "conv4"):
-        x = F.leaky_relu(F.conv2d(x, p[n + ".weight"], None, stride=2, padding=2), 0.2)
+        x = F.leaky_relu(_anc(n, F.conv2d(x, p[n + ".weight"], None, stride=2, padding=2)), 0.2)
     if ext:
-        x = F.leaky_relu(F.conv2d(x, p["conv4_2.weight"], None, stride=2, padding=1), 0.2)
-        x = F.leaky_relu(F.conv2d(x, p["conv4_3.weight"], None, stride=2, padding=1), 0.2)
-    return F.conv2d(x, p["conv5.weight"], None, stride=2, padding=2)
+        x = F.leaky_relu(_anc("conv4_2", F.conv2d(x, p["conv4_2.weight"], None, stride=2, padding=1)), 0.2)
+        x = F.leaky_relu(_anc("conv4_3", F.conv2d(x, p["conv4_3.weight"], None, stride=2, padding=1)), 0.2)
+    return _anc("conv5", F.conv2d(x, p["conv5.weight"], None, stride=2, padding=2))
 
 
 # --------------------------------------------------------------------------- #
@@ -315,7 +348,7 @@ def _norm1d(p: Params, name_bn: str, name_in: Optional[str], x, training: bool, 
                          p[name_bn + ".weight"], p[name_bn + ".bias"], training, 0.1, 1e-5)
         if training:
             p[name_bn + ".num_batches_tracked"] += 1
-        return y
+        return _anc(name_bn, y)
     # InstanceNorm1d on a 2-D [1,C] input treats it as unbatched [C=1? no: (C,L)=(1,C)]:
     # torch raises for mismatched features unless the tensor is 3-D.  The reference only
     # reaches this path with batch == 1; restated literally.
@@ -323,7 +356,7 @@ def _norm1d(p: Params, name_bn: str, name_in: Optional[str], x, training: bool, 
                         None, None, training, 0.1, 1e-5)
     if training:
         p[name_in + ".num_batches_tracked"] += 1
-    return y
+    return _anc(name_in, y)
 
 
 def _stn(p: Params, pre: str, x, k: int, training: bool, has_in: bool):
@@ -332,14 +365,14 @@ def _stn(p: Params, pre: str, x, k: int, training: bool, has_in: bool):
     batched = (b > 1) or not has_in
     h = x
     for i in (1, 2, 3):
-        h = F.conv1d(h, p[pre + "conv%d.weight" % i], p[pre + "conv%d.bias" % i])
+        h = _anc(pre + "conv%d" % i, F.conv1d(h, p[pre + "conv%d.weight" % i], p[pre + "conv%d.bias" % i]))
         h = F.relu(_norm1d(p, pre + "bn%d" % i, pre + "in%d" % i, h, training, batched))
     h = h.max(dim=2)[0].reshape(-1, 1024)
     for i, j in ((1, 4), (2, 5)):
-        h = F.linear(h, p[pre + "fc%d.weight" % i], p[pre + "fc%d.bias" % i])
+        h = _anc(pre + "fc%d" % i, F.linear(h, p[pre + "fc%d.weight" % i], p[pre + "fc%d.bias" % i]))
         h = F.relu(_norm1d(p, pre + "bn%d" % j, pre + "in%d" % j, h, training, batched))
     h = F.linear(h, p[pre + "fc3.weight"], p[pre + "fc3.bias"])
-    h = h + torch.eye(k, dtype=h.dtype).reshape(1, k * k)
+    h = _anc(pre + "fc3", h + torch.eye(k, dtype=h.dtype).reshape(1, k * k))
     return h.reshape(-1, k, k)
 
 
@@ -359,7 +392,7 @@ def pointnet_cls_forward(p: Params, x, *, feature_transform=False, sample_transf
         x = torch.bmm(x.transpose(2, 1), trans).transpose(2, 1)
 
     def cbr(conv, bn, h, relu=True):
-        h = F.conv1d(h, p["feat.%s.weight" % conv], p["feat.%s.bias" % conv])
+        h = _anc("feat." + conv, F.conv1d(h, p["feat.%s.weight" % conv], p["feat.%s.bias" % conv]))
         h = _norm1d(p, "feat." + bn, None, h, training, True)
         return F.relu(h) if relu else h
 
@@ -378,15 +411,15 @@ def pointnet_cls_forward(p: Params, x, *, feature_transform=False, sample_transf
     h = h.max(dim=2)[0].reshape(-1, 1024)                      # :162-163
 
     batched = b > 1
-    h = F.linear(h, p["fc1.weight"], p["fc1.bias"])
+    h = _anc("fc1", F.linear(h, p["fc1.weight"], p["fc1.bias"]))
     h = F.relu(_norm1d(p, "bn1", "in1", h, training, batched))
-    h = F.linear(h, p["fc2.weight"], p["fc2.bias"])
+    h = _anc("fc2", F.linear(h, p["fc2.weight"], p["fc2.bias"]))
     if training and drop > 0:
         if drop_mask is None:
             raise ValueError("oracle needs an explicit drop_mask when drop > 0 in training")
         h = h * drop_mask
     h = F.relu(_norm1d(p, "bn2", "in2", h, training, batched))
-    h = F.linear(h, p["fc3.weight"], p["fc3.bias"])
+    h = _anc("fc3", F.linear(h, p["fc3.weight"], p["fc3.bias"]))
     return h, trans, trans_feat
 
 

@@ -46,6 +46,8 @@ class _ConvChainFn(torch.autograd.Function):
             h, w = op.out_hw(h, w)
             acts.append(cur)
         ctx.module, ctx.acts, ctx.sizes, ctx.weights = module, acts, sizes, weights
+        if getattr(module, "_keep_acts", False):      # tests (shared-routing backward checks)
+            module._last_acts = list(acts)
         ctx.set_materialize_grads(False)
         return cur
 

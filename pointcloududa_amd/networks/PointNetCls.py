@@ -40,6 +40,12 @@ class _Tape:
         # which parameters want a gradient is decided when the forward pass is recorded, as autograd does
         self.wants = {k for k, p in self.P.items() if p.requires_grad}
         self.P.update(dict(module.named_buffers()))
+        # tests (shared-routing backward checks): name -> intermediate tensor of this forward pass
+        self.trace = {} if getattr(module, "_keep_trace", False) else None
+
+    def _rec(self, name, t, relu=None):
+        if self.trace is not None:
+            self.trace[name] = t if relu is None else (t, relu)
 
     def G(self, name):
         return ensure_grad(self.P[name]) if name in self.wants else None
@@ -61,6 +67,7 @@ class _Tape:
         w4 = w.view(cout, cin, 1, 1)
         a4, part, nt = op.forward(x.t.view(bsz, cin, 1, l), w4, b, 1.0, 1, l, want_stats=self.training)
         a = _Var(a4.view(bsz, cout, l))
+        self._rec(conv, a.t)
         y = self._bn(a, bn, relu, part, nt)
 
         def bwd():
@@ -91,6 +98,7 @@ class _Tape:
             st.scale = (P[bn + ".weight"] * inv).contiguous()
             st.shift = (P[bn + ".bias"] - P[bn + ".running_mean"] * st.scale).contiguous()
         y = _Var(K.bn_apply(a.t, st, relu=relu))
+        self._rec(bn, y.t, relu)
 
         def bwd():
             if y.g is None:
@@ -106,6 +114,7 @@ class _Tape:
         w, b = self.P[name + ".weight"], self.P[name + ".bias"]
         b_eff = b if bias_plus is None else K.add_n([b, bias_plus])
         y = _Var(K.linear_fwd(x.t, w, b_eff))
+        self._rec(name, y.t)
 
         def bwd():
             if y.g is None:
@@ -184,6 +193,8 @@ class _PointNetFn(torch.autograd.Function):
         tape = _Tape(module, module.training)
         xin = _Var(x.contiguous().float())
         y, trans, trans_feat = module._run(tape, xin, drop_mask)
+        if tape.trace is not None:
+            module._last_trace = tape.trace
         if module.training:
             for k, b in module.named_buffers():
                 if k.endswith("num_batches_tracked") and ".in" not in k and not k.startswith("in"):

@@ -112,7 +112,7 @@ class _SegEngine:
         nb = self.nb
         if H % (1 << nb) or W % (1 << nb):
             raise ValueError("input size must be divisible by %d" % (1 << nb))
-        S = {"hw": (H, W), "n": n, "wants": {k for k, p in P.items() if p.requires_grad}}
+        S = {"hw": (H, W), "n": n, "wants": {k for k, p in P.items() if p.requires_grad}, "training": training}
         cur, h, w, res = x, H, W, None
         skips = []
         for i in range(nb):                                           # unet.py:35-51
@@ -161,6 +161,10 @@ class _SegEngine:
 
     # ---------------------------------------------------------------- backward
     def backward(self, P, S, d_logits, d_verts, need_dx):
+        if not S["training"]:
+            # the BatchNorm backward kernels implement the batch-statistics formula; a pass through running statistics
+            # (frozen-BN fine-tuning, input gradients in eval mode) would be silently wrong
+            raise NotImplementedError("backward through Segmentation_model_Point in eval mode is not built")
         wants = S["wants"]       # parameters that required a gradient when the forward pass ran (autograd's rule)
 
         def G(name):
@@ -243,6 +247,8 @@ class _SegFn(torch.autograd.Function):
         if module.training:
             module._bump_batches_tracked()
         ctx.module, ctx.S, ctx.P = module, S, P
+        if getattr(module, "_keep_state", False):     # tests (shared-routing backward checks)
+            module._last_S = S
         ctx.set_materialize_grads(False)
         if verts is None:
             return logits

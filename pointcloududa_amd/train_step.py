@@ -66,15 +66,33 @@ class AdversarialTrainer:
         self._wp = torch.full((), float(c.wp), dtype=torch.float32, device=dev)
         self.last = {}
         self.d_streams = os.environ.get("PCUDA_DSTREAMS", "1") != "0"   # discriminator passes on concurrent streams
-        self._streams = []
+        self._streams = {}
+        self.broadcast_parameters()
         self.d_overlap = os.environ.get("PCUDA_DOVERLAP", "1") != "0"   # discriminator update under the G backward
         self.early_fwd2 = os.environ.get("PCUDA_EARLY2", "1") != "0"    # target forward ahead of the source backward
         self.d_batch = os.environ.get("PCUDA_DBATCH", "1") != "0"       # d1 / d2: source + target as one batch
 
-    def _side_streams(self, n):
-        while len(self._streams) < n:
-            self._streams.append(torch.cuda.Stream())
-        return self._streams[:n]
+    def _side_streams(self, names):
+        """One side stream PER DISCRIMINATOR, keyed by its name: a network's frozen pass (phase 2), its input-gradient
+        pass and its update passes (phases 3-4) all run on the same stream, so its weight repack, its BatchNorm
+        running-statistic updates and its gradient buffer are ordered by the stream itself."""
+        for nm in names:
+            if nm not in self._streams:
+                self._streams[nm] = torch.cuda.Stream()
+        return [self._streams[nm] for nm in names]
+
+    def broadcast_parameters(self, src: int = 0):
+        """Data parallel: every replica starts from rank ``src``'s parameters, BatchNorm running statistics and
+        optimiser state (one broadcast per flat buffer).  No-op without an initialised group of more than one rank."""
+        if not _collectives_on(self.group):
+            return
+        import torch.distributed as dist
+        for opt in [self.opt_gen] + self._d_opts():
+            bufs = [opt.p] + [t for t in (getattr(opt, "m", None), getattr(opt, "v", None), getattr(opt, "buf", None),
+                                          getattr(opt, "step_t", None)) if t is not None]
+            bufs += [b for b in opt.module.buffers() if b.numel() > 0]
+            for t in bufs:
+                dist.broadcast(t, src=src, group=self.group)
 
     def _dis(self):
         return [m for m in (self.dis1, self.dis2, self.dis4) if m is not None]
@@ -177,7 +195,8 @@ class AdversarialTrainer:
         if c.d1:
             heads.append(("adv1", lambda: self.dis1(tap_t if ms else pred_t), c.dr * (1.0 if ms else c.w1)))
         cur = torch.cuda.current_stream()
-        side = self._side_streams(len(heads)) if (self.d_streams and len(heads) > 1) else [None] * len(heads)
+        side = (self._side_streams(["d" + nm[-1] for nm, _, _ in heads]) if (self.d_streams and len(heads) > 1)
+                else [None] * len(heads))
         for (nm, fwd, wgt), st in zip(heads, side):
             if st is not None:
                 st.wait_stream(cur)
@@ -235,7 +254,8 @@ class AdversarialTrainer:
             if c.d4:
                 passes.append(("d4", "dis4", lambda e, i1, v: self.dis4(v.detach().transpose(2, 1), drop_mask)[0]))
             main = torch.cuda.current_stream()
-            side = self._side_streams(len(passes)) if (self.d_streams and len(passes) > 1) else [None] * len(passes)
+            side = (self._side_streams([nm for nm, _, _ in passes]) if (self.d_streams and len(passes) > 1)
+                    else [None] * len(passes))
             d_works = {}
             for (nm, hit, fwd), st in zip(passes, side):
                 if st is not None:

@@ -1,0 +1,192 @@
+"""Backward passes of every network at 1e-4, with the routing decisions shared.
+
+The reference networks' gradients are discontinuous in their activations (LeakyReLU / ReLU sign, max-pool and
+max-over-points argmax, nearest-neighbour indices of the point loss): against an independent fp32 run the
+whole-network gradient checks of test_networks_gpu.py can only be held to ~1e-2 (scripts/gradient_conditioning.py).
+Here the CPU restatement (oracle.nets, PyTorch autograd) is ANCHORED to the HIP forward pass: every conv / linear /
+normalisation output takes the value the HIP kernels produced (``z + (z_hip - z).detach()``), so both sides take the
+same branch everywhere while autograd still differentiates the restatement.  What remains is the arithmetic of the
+HIP backward kernels (dgrad, wgrad, BatchNorm / LeakyReLU / pooling / upsampling backward, the two-destination and
+accumulating forms, the fused losses' gradients) through the PRODUCTION autograd nodes: every parameter gradient and
+the input gradient must agree to 1e-4 of the tensor's scale.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _load(mod, params, dev):
+    mod.load_state_dict({k: v.clone() for k, v in params.items()}, strict=True)
+    return mod.to(dev).train()
+
+
+def _unlrelu(a, slope):
+    """pre-activation with the sign (and, up to one rounding, the value) the HIP kernel saw"""
+    a = a.detach().float().cpu()
+    return a if slope == 1.0 else torch.where(a > 0, a, a / slope)
+
+
+def _anchor_from(table, used):
+    def fn(tag, z):
+        if tag not in table:
+            return z
+        used.add(tag)
+        v = table[tag]
+        if isinstance(v, tuple):          # (post-ReLU value, True): share the mask, keep own value where inactive
+            y = v[0].detach().float().cpu().reshape(z.shape)
+            tgt = torch.where(y > 0, y, torch.clamp(z.detach(), max=0.0))
+        else:
+            tgt = v.reshape(z.shape)
+        assert rel_err(z, tgt) < 2e-3, (tag, rel_err(z, tgt))      # the two forward passes agree before anchoring
+        return z + (tgt - z).detach()
+    return fn
+
+
+def _compare_grads(named_hip, grads_ref, tol=TOL):
+    worst = ("", 0.0)
+    total = sum(float(g.double().norm()) ** 2 for g in grads_ref.values() if g is not None) ** 0.5
+    for k, p in named_hip:
+        g = grads_ref.get(k)
+        if g is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        # (a bias in front of a BatchNorm has an exactly-zero true gradient: both sides hold rounding noise there)
+        if float(g.double().norm()) < 1e-5 * total:
+            assert float(p.grad.double().norm()) < 1e-4 * total, k
+            continue
+        e = rel_err(p.grad, g)
+        if e > worst[1]:
+            worst = (k, e)
+        assert e < tol, (k, e)
+    return worst
+
+
+@pytest.mark.parametrize("cfg_kw,softmax,b,hw,seed", [
+    (dict(filters=4, in_channels=1, n_class=4, pointnet=True, fc_inch=9), False, 2, 128, 1100),
+    (dict(filters=8, in_channels=3, n_class=5, pointnet=False), True, 2, 64, 1110),
+    (dict(filters=16, in_channels=1, n_class=4, pointnet=True, fc_inch=9), False, 3, 128, 1120),
+])
+def test_segmenter_backward_shared_routing(dev, cfg_kw, softmax, b, hw, seed):
+    """encoder blocks + max-pool + dense-skip 1x1 convs, the dilated bottleneck and its running sum, the point head,
+    the decoder (upsampling fold, zero-copy concat) and the classifier, under the reference's supervised loss"""
+    from oracle import losses as OL
+    from oracle import nets as ON
+    from oracle.synth import synth_batch
+    from pointcloududa_amd.networks import Segmentation_model_Point
+    from pointcloududa_amd.utils import loss as L
+    cfg = ON.SegCfg(**cfg_kw)
+    params = ON.make_params(ON.seg_param_shapes(cfg), seed)
+    model = _load(Segmentation_model_Point(**cfg_kw), params, dev)
+    model._keep_state = True
+    img, mask, vert, _, _ = synth_batch(b, cfg.in_channels, cfg.n_class, hw, seed=seed + 1)
+    x = torch.from_numpy(img).to(dev).requires_grad_(True)
+    logits, _, verts = model(x)
+    one = torch.ones((), device=dev)
+    l_main, l_jac = L.seg_loss(logits, torch.from_numpy(mask).to(dev), "softmax" if softmax else "sigmoid")
+    seeds, gs = [l_main, l_jac], [one, one]
+    if cfg.pointnet:
+        seeds.append(L.batch_NN_loss(verts, torch.from_numpy(vert).to(dev))); gs.append(one)
+    torch.autograd.backward(seeds, gs)
+
+    S = model._last_S
+    table = {"classifier": logits.detach().float().cpu()}
+    for blk in ["encoder.encoder%d" % (i + 1) for i in range(cfg.n_block)] + \
+               ["decoder.decoder2_%d" % (i + 1) for i in range(cfg.n_block)]:
+        _, _, a0, _, a1, _ = S[blk]
+        table[blk + ".0"], table[blk + ".3"] = _unlrelu(a0, 0.01), _unlrelu(a1, 0.01)
+    for i in range(1, cfg.n_block):
+        c1 = "encoder.conv1_%d.0" % (i + 1)
+        table[c1] = _unlrelu(S[c1][2], 0.01)
+    for j, o in enumerate(S["bott_outs"]):
+        table["bottleneck.bottleneck%d.0" % (j + 1)] = _unlrelu(o, 0.01)
+    if cfg.pointnet:
+        table["pointNet.final_conv"] = _unlrelu(S["head"][1], 0.01)
+        table["pointNet.final_fc"] = verts.detach().float().cpu()
+
+    p2 = {k: (v.clone().requires_grad_(True) if ON.is_trainable(k) else v.clone()) for k, v in params.items()}
+    xo = torch.from_numpy(img).requires_grad_(True)
+    used = set()
+    with ON.anchored(_anchor_from(table, used)):
+        lo2, ve2 = ON.seg_forward(p2, xo, cfg, training=True)
+    assert used == set(table), set(table) - used
+    m2, j2 = (OL.seg_loss_softmax if softmax else OL.seg_loss_sigmoid)(lo2, torch.from_numpy(mask))
+    loss2 = m2 + j2 + (OL.batch_nn_loss(ve2, torch.from_numpy(vert)) if cfg.pointnet else 0.0)
+    loss2.backward()
+    ref = {k: v.grad for k, v in p2.items() if ON.is_trainable(k)}
+    worst = _compare_grads(model.named_parameters(), ref)
+    e_dx = rel_err(x.grad, xo.grad)
+    assert e_dx < TOL, e_dx
+    print("worst parameter gradient error %s %.2e, dx %.2e" % (worst[0], worst[1], e_dx))
+
+
+@pytest.mark.parametrize("inch,ext,hw,seed", [(4, False, 64, 1200), (5, True, 128, 1210), (4, False, 256, 1220)])
+def test_discriminator_backward_shared_routing(dev, inch, ext, hw, seed):
+    """the full UncertaintyDiscriminator chain (stride-2 4x4 convolutions, their transposed-convolution input gradients
+    per parity class, LeakyReLU(0.2) backward, the tap-unfolded first layer) under the domain loss"""
+    from oracle import losses as OL
+    from oracle import nets as ON
+    from pointcloududa_amd.networks import UncertaintyDiscriminator
+    from pointcloududa_amd.utils import loss as L
+    params = ON.make_params(ON.disc_param_shapes(inch, ext), seed, std=0.02)
+    model = _load(UncertaintyDiscriminator(in_channel=inch, ext=ext), params, dev)
+    model._keep_acts = True
+    rng = np.random.default_rng(seed + 1)
+    xn = rng.normal(0, 1, (2, inch, hw, hw)).astype(np.float32)
+    x = torch.from_numpy(xn).to(dev).requires_grad_(True)
+    d = model(x)
+    L.bce_logits_const(d, 1.0).backward()
+    names = [n for n, _ in model._chain]
+    acts = model._last_acts
+    table = {n: _unlrelu(acts[i + 1], 0.2 if i < len(names) - 1 else 1.0) for i, n in enumerate(names)}
+    p2 = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    xo = torch.from_numpy(xn).requires_grad_(True)
+    used = set()
+    with ON.anchored(_anchor_from(table, used)):
+        d2 = ON.disc_forward(p2, xo, ext)
+    assert used == set(table)
+    OL.bce_logits_const(d2, 1.0).backward()
+    worst = _compare_grads(model.named_parameters(), {k: v.grad for k, v in p2.items()})
+    e_dx = rel_err(x.grad, xo.grad)
+    assert e_dx < TOL, e_dx
+    print("worst parameter gradient error %s %.2e, dx %.2e" % (worst[0], worst[1], e_dx))
+
+
+@pytest.mark.parametrize("ft,ext,b,seed", [(False, False, 16, 1300), (True, True, 12, 1310), (False, False, 4, 1320)])
+def test_pointnet_cls_backward_shared_routing(dev, ft, ext, b, seed):
+    """PointNetCls (T-Nets, k=1 convolutions + BatchNorm1d + ReLU, max over points, FC + BatchNorm1d) with the ReLU
+    masks and the max-over-points argmax shared"""
+    from oracle import losses as OL
+    from oracle import nets as ON
+    from pointcloududa_amd.networks import PointNetCls
+    from pointcloududa_amd.utils import loss as L
+    params = ON.make_params(ON.pointnet_cls_param_shapes(ft, ext=ext), seed)
+    model = _load(PointNetCls(feature_transform=ft, ext=ext, drop=0.0), params, dev)
+    model._keep_trace = True
+    rng = np.random.default_rng(seed + 1)
+    xn = rng.random((b, 3, 300), dtype=np.float32)
+    x = torch.from_numpy(xn).to(dev).requires_grad_(True)
+    y, _, _ = model(x)
+    L.bce_logits_const(y, 0.0).backward()
+    table = {}
+    for k, v in model._last_trace.items():
+        table[k] = (v[0], True) if (isinstance(v, tuple) and v[1]) else (v[0] if isinstance(v, tuple) else v)
+        if not isinstance(table[k], tuple):
+            table[k] = table[k].detach().float().cpu()
+    p2 = {k: (v.clone().requires_grad_(True) if ON.is_trainable(k) else v.clone()) for k, v in params.items()}
+    xo = torch.from_numpy(xn).requires_grad_(True)
+    used = set()
+    with ON.anchored(_anchor_from(table, used)):
+        y2, _, _ = ON.pointnet_cls_forward(p2, xo, feature_transform=ft, ext=ext, drop=0.0, training=True)
+    assert used == set(table), set(table) - used
+    OL.bce_logits_const(y2, 0.0).backward()
+    ref = {k: v.grad for k, v in p2.items() if ON.is_trainable(k)}
+    worst = _compare_grads(model.named_parameters(), ref)
+    e_dx = rel_err(x.grad, xo.grad)
+    assert e_dx < TOL, e_dx
+    print("worst parameter gradient error %s %.2e, dx %.2e" % (worst[0], worst[1], e_dx))
