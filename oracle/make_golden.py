@@ -392,6 +392,7 @@ def ref_step_mscmrseg(gen, d1, d2, d4, opt_g, opt1, opt2, opt4, batch, dr, wp):
         a1 = dr * F.binary_cross_entropy_with_logits(do, torch.FloatTensor(do.data.size()).fill_(1))
     adv = a2 + a4 + a1
     res["adv_loss"] = adv.item()
+    res["adv2"], res["adv4"], res["adv1"] = float(a2), float(a4), float(a1)     # (dr-scaled, as the script sums them)
     adv.backward()
     res["grad_total"] = {k: p.grad.clone() for k, p in gen.named_parameters() if p.grad is not None}
     opt_g.step()
@@ -428,20 +429,42 @@ def ref_step_mscmrseg(gen, d1, d2, d4, opt_g, opt1, opt2, opt4, batch, dr, wp):
     return res
 
 
-def gold_step(tag, cfg: ON.SegCfg, b, hw, seed, n_steps=2, full=True):
-    scfg = StepCfg(variant="mscmrseg", d1=True, d2=True, d4=True, n_class=cfg.n_class)
+def post_step_samples(out, prefix, nets, grads, params0):
+    """strided samples of every float state entry after the optimiser steps (``ps/``), of the gradient each
+    optimiser consumed (``gs/``), and the parameter sums (``psum/``) -- what tests/test_step_gpu.py checks the
+    update direction and size against"""
+    for nm, m in nets:
+        if m is None:
+            continue
+        for k, v in m.state_dict().items():
+            if not v.dtype.is_floating_point:
+                continue
+            out["%sps/%s/%s" % (prefix, nm, k)] = sample(v, 256)
+            if "%spsum/%s/%s" % (prefix, nm, k) not in out:
+                out["%spsum/%s/%s" % (prefix, nm, k)] = np.float64(v.double().sum().item())
+        for k, g in grads[nm].items():
+            out["%sgs/%s/%s" % (prefix, nm, k)] = sample(g, 256)
+
+
+def gold_step(tag, cfg: ON.SegCfg, b, hw, seed, n_steps=2, full=True, d1=True, d2=True, d4=True):
+    scfg = StepCfg(variant="mscmrseg", d1=d1, d2=d2, d4=d4, n_class=cfg.n_class)
+    assert cfg.pointnet == d4, "train_mscmrseg.py:414 builds the point head iff -d4"
     pg = ON.make_params(ON.seg_param_shapes(cfg), seed)
-    p1 = ON.make_params(ON.disc_param_shapes(cfg.n_class), seed + 1, std=0.02)
-    p2 = ON.make_params(ON.disc_param_shapes(cfg.n_class), seed + 2, std=0.02)
-    p4 = ON.make_params(ON.pointnet_cls_param_shapes(), seed + 3)
+    p1 = ON.make_params(ON.disc_param_shapes(cfg.n_class), seed + 1, std=0.02) if d1 else None
+    p2 = ON.make_params(ON.disc_param_shapes(cfg.n_class), seed + 2, std=0.02) if d2 else None
+    p4 = ON.make_params(ON.pointnet_cls_param_shapes(), seed + 3) if d4 else None
     gen = load_into(ref_seg(cfg), pg).train()
-    d1 = load_into(UncertaintyDiscriminator(in_channel=cfg.n_class), p1).train()
-    d2 = load_into(UncertaintyDiscriminator(in_channel=cfg.n_class), p2).train()
-    d4 = load_into(PointNetCls(drop=0.0), p4).train()
+    d1 = load_into(UncertaintyDiscriminator(in_channel=cfg.n_class), p1).train() if d1 else None
+    d2 = load_into(UncertaintyDiscriminator(in_channel=cfg.n_class), p2).train() if d2 else None
+    d4 = load_into(PointNetCls(drop=0.0), p4).train() if d4 else None
     og = torch.optim.Adam(gen.parameters(), lr=scfg.lr, betas=(0.9, 0.99))
-    mk = lambda m, lr: torch.optim.SGD(m.parameters(), lr=lr, momentum=.99, weight_decay=.0005)
+    mk = lambda m, lr: None if m is None else torch.optim.SGD(m.parameters(), lr=lr, momentum=.99, weight_decay=.0005)
     o1, o2, o4 = mk(d1, scfg.d1lr), mk(d2, scfg.d2lr), mk(d4, scfg.d4lr)
     orc = OracleTrainer(cfg, scfg, pg, p1, p2, p4)
+    keys = ["seg_loss", "adv_loss"] + (["ver_s_loss", "ver_t_loss"] if d4 is not None else [])
+    for nm, m in (("d2", d2), ("d1", d1), ("d4", d4)):
+        if m is not None:
+            keys += [nm + "_loss_src", nm + "_loss_tgt"]
 
     out = {"seed": np.int64(seed), "b": np.int64(b), "hw": np.int64(hw), "n_steps": np.int64(n_steps)}
     for it in range(n_steps):
@@ -453,26 +476,32 @@ def gold_step(tag, cfg: ON.SegCfg, b, hw, seed, n_steps=2, full=True):
         # sign-sensitive for near-zero gradients) and BatchNorm over a tiny batch, so rounding
         # differences are amplified: only the scalars are recorded, and compared loosely.
         tight = it == 0
-        for k in ("seg_loss", "ver_s_loss", "ver_t_loss", "adv_loss", "d2_loss_src", "d1_loss_src",
-                  "d4_loss_src", "d2_loss_tgt", "d1_loss_tgt", "d4_loss_tgt"):
+        for k in keys:
+            close(torch.tensor(q[k]), torch.tensor(r[k]), 2e-5 if tight else 5e-2, "%s step%d %s" % (tag, it, k))
+            out["s%d/%s" % (it, k)] = np.float64(r[k])
+        for k in ("adv1", "adv2", "adv4"):
             close(torch.tensor(q[k]), torch.tensor(r[k]), 2e-5 if tight else 5e-2, "%s step%d %s" % (tag, it, k))
             out["s%d/%s" % (it, k)] = np.float64(r[k])
         out["s%d/seg_dice" % it] = np.float64(q["seg_dice"])     # numpy restatement, pinned by hand cases in tests
         if not tight:
             continue
         close(orc.kept["oS"], r["oS"], 1e-4, tag + " oS"); close(orc.kept["oT"], r["oT"], 1e-4, tag + " oT")
-        close(orc.kept["vertS"], r["vertS"], 1e-4, tag + " vertS")
+        if r["vertS"] is not None:
+            close(orc.kept["vertS"], r["vertS"], 1e-4, tag + " vertS")
         for nm in ("grad_seg", "grad_total", "grad_d1", "grad_d2", "grad_d4"):
-            for k, g in r[nm].items():
+            for k, g in r.get(nm, {}).items():
                 close(orc.kept[nm][k], g, 1e-3, "%s step%d %s %s" % (tag, it, nm, k))
                 out["s%d/%s_norm/%s" % (it, nm, k)] = np.float64(g.double().norm().item())
         if full:
             out["s%d/oS" % it] = r["oS"].numpy(); out["s%d/oT" % it] = r["oT"].numpy()
         else:
             out["s%d/oS_s" % it] = sample(r["oS"]); out["s%d/oT_s" % it] = sample(r["oT"])
-        out["s%d/vertS" % it] = r["vertS"].numpy(); out["s%d/vertT" % it] = r["vertT"].numpy()
+        if r["vertS"] is not None:
+            out["s%d/vertS" % it] = r["vertS"].numpy(); out["s%d/vertT" % it] = r["vertT"].numpy()
         # parameter checksums after the optimiser steps
         for nm, m, pd in (("gen", gen, orc.gen), ("d1", d1, orc.dis1), ("d2", d2, orc.dis2), ("d4", d4, orc.dis4)):
+            if m is None:
+                continue
             for k, v in m.state_dict().items():
                 if v.dtype.is_floating_point:
                     # Adam's first update is lr*sign(g) for |g| >> eps: a near-zero gradient whose sign is
@@ -480,30 +509,38 @@ def gold_step(tag, cfg: ON.SegCfg, b, hw, seed, n_steps=2, full=True):
                     close(pd[k], v, 2.5e-3, "%s step%d param %s.%s" % (tag, it, nm, k))
                     out["s%d/psum/%s/%s" % (it, nm, k)] = np.float64(v.double().sum().item())
                     out["s%d/pabs/%s/%s" % (it, nm, k)] = np.float64(v.double().abs().sum().item())
+        post_step_samples(out, "s%d/" % it, (("gen", gen), ("d1", d1), ("d2", d2), ("d4", d4)),
+                          {"gen": r["grad_total"], "d1": r.get("grad_d1", {}), "d2": r.get("grad_d2", {}),
+                           "d4": r.get("grad_d4", {})}, None)
     np.savez_compressed(os.path.join(GOLD, tag + ".npz"), **out)
     print(tag, "ok")
 
 
 def ref_step_mmwhs(gen, d1, d2, d4, opt_g, opt1, opt2, opt4, batch, dr, wp, w1, w2, w4):
     """One iteration of train_epoch's loop, re-typed from train_mmwhs.py:187-360 around the imported reference
-    modules (-softmax, no -etpls/-Tetpls/-d4aux; CPU tensors instead of .cuda(); host metrics omitted)."""
+    modules (-softmax, no -etpls/-Tetpls/-d4aux; CPU tensors instead of .cuda(); host metrics omitted).  Any of the
+    discriminators may be None (their flags off); with none at all the adversarial backward is skipped by the
+    script's ``if loss_adv_diff != 0`` guard (:271) and phases 3-5 by ``if args.d1 or args.d2 or args.d4`` (:282)."""
     import math
     img_a, mask_a, vert_a, img_b, vert_b = batch
     smooth = 1e-7
     res = {}
     opt_g.zero_grad()
     for o, m in ((opt1, d1), (opt2, d2), (opt4, d4)):
-        o.zero_grad()
-        for p in m.parameters():
-            p.requires_grad = False
+        if m is not None:
+            o.zero_grad()
+            for p in m.parameters():
+                p.requires_grad = False
     for p in gen.parameters():
         p.requires_grad = True
     o_s, _, v_s = gen(torch.from_numpy(img_a).float())
     pred_s = F.softmax(o_s, dim=1)
     l_seg = F.cross_entropy(pred_s, torch.from_numpy(np.argmax(mask_a, axis=1)).long())
     l_seg2 = ref_loss.jaccard_loss(logits=pred_s, true=torch.from_numpy(mask_a).float(), activation=False)
-    l_seg3 = ref_loss.batch_NN_loss(x=v_s, y=torch.from_numpy(vert_a).float())
-    res["ver_s_loss"] = l_seg3.item()
+    l_seg3 = 0
+    if d4 is not None:
+        l_seg3 = ref_loss.batch_NN_loss(x=v_s, y=torch.from_numpy(vert_a).float())
+        res["ver_s_loss"] = l_seg3.item()
     c = pred_s.size()[1]
     emap_s = -1.0 * pred_s * torch.log(pred_s + smooth) / math.log(c)
     res["entropy_s"] = torch.mean(torch.sum(emap_s, dim=1)).item()
@@ -514,77 +551,106 @@ def ref_step_mmwhs(gen, d1, d2, d4, opt_g, opt1, opt2, opt4, batch, dr, wp, w1, 
     pred_t = F.softmax(o_t, dim=1)
     emap_t = -1.0 * pred_t * torch.log(pred_t + smooth) / math.log(pred_t.size()[1])
     res["entropy_t"] = torch.mean(torch.sum(emap_t, dim=1)).item()
-    do = d2(emap_t)
-    a2 = dr * F.binary_cross_entropy_with_logits(do, torch.FloatTensor(do.data.size()).fill_(1))
-    res["ver_t_loss"] = ref_loss.batch_NN_loss(x=v_t, y=torch.from_numpy(vert_b).float()).item()
-    do = d4(v_t.transpose(2, 1))[0]
-    a4 = dr * F.binary_cross_entropy_with_logits(do, torch.FloatTensor(do.data.size()).fill_(1))
-    do = d1(pred_t)
-    a1 = dr * F.binary_cross_entropy_with_logits(do, torch.FloatTensor(do.data.size()).fill_(1))
-    adv = 0 + w2 * a2 + w4 * a4 + w1 * a1
-    res["adv_loss"] = adv.item()
-    adv.backward()
+    adv = 0
+    if d1 is not None or d2 is not None or d4 is not None:
+        a2 = a4 = a1 = 0
+        if d2 is not None:
+            do = d2(emap_t)
+            a2 = dr * F.binary_cross_entropy_with_logits(do, torch.FloatTensor(do.data.size()).fill_(1))
+        if d4 is not None:
+            res["ver_t_loss"] = ref_loss.batch_NN_loss(x=v_t, y=torch.from_numpy(vert_b).float()).item()
+            do = d4(v_t.transpose(2, 1))[0]
+            a4 = dr * F.binary_cross_entropy_with_logits(do, torch.FloatTensor(do.data.size()).fill_(1))
+        if d1 is not None:
+            do = d1(pred_t)
+            a1 = dr * F.binary_cross_entropy_with_logits(do, torch.FloatTensor(do.data.size()).fill_(1))
+        adv += w2 * a2 + w4 * a4 + w1 * a1
+        res["adv2"], res["adv4"], res["adv1"] = float(a2), float(a4), float(a1)
+    res["adv_loss"] = float(adv)
+    if torch.is_tensor(adv):           # `if loss_adv_diff != 0:` (:271)
+        adv.backward()
     res["grad_total"] = {k: p.grad.clone() for k, p in gen.named_parameters() if p.grad is not None}
     opt_g.step()
-    for m in (d1, d2, d4):
-        for p in m.parameters():
-            p.requires_grad = True
-    for p in gen.parameters():
-        p.requires_grad = False
-    for tag, lbl, em, pr, vx in (("src", 1, emap_s, pred_s, v_s), ("tgt", 0, emap_t, pred_t, v_t)):
-        do = d2(em.detach())
-        l = F.binary_cross_entropy_with_logits(do, torch.FloatTensor(do.data.size()).fill_(lbl)); l.backward()
-        res["d2_loss_" + tag] = l.item()
-        do = d1(pr.detach())
-        l = F.binary_cross_entropy_with_logits(do, torch.FloatTensor(do.data.size()).fill_(lbl)); l.backward()
-        res["d1_loss_" + tag] = l.item()
-        do = d4(vx.detach().transpose(2, 1))[0]
-        l = F.binary_cross_entropy_with_logits(do, torch.FloatTensor(do.data.size()).fill_(lbl)); l.backward()
-        res["d4_loss_" + tag] = l.item()
-    for nm, m in (("grad_d1", d1), ("grad_d2", d2), ("grad_d4", d4)):
-        res[nm] = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
-    for o in (opt1, opt2, opt4):
-        o.step()
+    if d1 is not None or d2 is not None or d4 is not None:
+        for m in (d1, d2, d4):
+            if m is not None:
+                for p in m.parameters():
+                    p.requires_grad = True
+        for p in gen.parameters():
+            p.requires_grad = False
+        for tag, lbl, em, pr, vx in (("src", 1, emap_s, pred_s, v_s), ("tgt", 0, emap_t, pred_t, v_t)):
+            if d2 is not None:
+                do = d2(em.detach())
+                l = F.binary_cross_entropy_with_logits(do, torch.FloatTensor(do.data.size()).fill_(lbl)); l.backward()
+                res["d2_loss_" + tag] = l.item()
+            if d1 is not None:
+                do = d1(pr.detach())
+                l = F.binary_cross_entropy_with_logits(do, torch.FloatTensor(do.data.size()).fill_(lbl)); l.backward()
+                res["d1_loss_" + tag] = l.item()
+            if d4 is not None:
+                do = d4(vx.detach().transpose(2, 1))[0]
+                l = F.binary_cross_entropy_with_logits(do, torch.FloatTensor(do.data.size()).fill_(lbl)); l.backward()
+                res["d4_loss_" + tag] = l.item()
+        for nm, m in (("grad_d1", d1), ("grad_d2", d2), ("grad_d4", d4)):
+            if m is not None:
+                res[nm] = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+        for o, m in ((opt1, d1), (opt2, d2), (opt4, d4)):
+            if m is not None:
+                o.step()
     res["oS"], res["oT"] = o_s.detach(), o_t.detach()
-    res["vertS"], res["vertT"] = v_s.detach(), v_t.detach()
+    res["vertS"] = None if v_s is None else v_s.detach()
+    res["vertT"] = None if v_t is None else v_t.detach()
     return res
 
 
-def gold_step_mmwhs(tag, cfg: ON.SegCfg, b, hw, seed):
+def gold_step_mmwhs(tag, cfg: ON.SegCfg, b, hw, seed, d1=True, d2=True, d4=True):
     """The MM-WHS loop (train_mmwhs.py:187-360, optimisers :453-489) with the repository README's point-cloud
     discriminator PointNetCls(feature_transform=True, ext=True): one step from identical parameters."""
-    scfg = StepCfg(variant="mmwhs", d1=True, d2=True, d4=True, n_class=cfg.n_class, softmax=True, d_momentum=0.95,
+    scfg = StepCfg(variant="mmwhs", d1=d1, d2=d2, d4=d4, n_class=cfg.n_class, softmax=True, d_momentum=0.95,
                    pn_feature_transform=True, pn_ext=True)
+    assert cfg.pointnet == d4
     pg = ON.make_params(ON.seg_param_shapes(cfg), seed)
-    p1 = ON.make_params(ON.disc_param_shapes(cfg.n_class), seed + 1, std=0.02)
-    p2 = ON.make_params(ON.disc_param_shapes(cfg.n_class), seed + 2, std=0.02)
-    p4 = ON.make_params(ON.pointnet_cls_param_shapes(feature_transform=True, ext=True), seed + 3)
+    p1 = ON.make_params(ON.disc_param_shapes(cfg.n_class), seed + 1, std=0.02) if d1 else None
+    p2 = ON.make_params(ON.disc_param_shapes(cfg.n_class), seed + 2, std=0.02) if d2 else None
+    p4 = ON.make_params(ON.pointnet_cls_param_shapes(feature_transform=True, ext=True), seed + 3) if d4 else None
     gen = load_into(ref_seg(cfg), pg).train()
-    d1 = load_into(UncertaintyDiscriminator(in_channel=cfg.n_class), p1).train()
-    d2 = load_into(UncertaintyDiscriminator(in_channel=cfg.n_class), p2).train()
-    d4 = load_into(PointNetCls(feature_transform=True, ext=True, drop=0.0), p4).train()
+    d1 = load_into(UncertaintyDiscriminator(in_channel=cfg.n_class), p1).train() if d1 else None
+    d2 = load_into(UncertaintyDiscriminator(in_channel=cfg.n_class), p2).train() if d2 else None
+    d4 = load_into(PointNetCls(feature_transform=True, ext=True, drop=0.0), p4).train() if d4 else None
     og = torch.optim.Adam(gen.parameters(), lr=scfg.lr, betas=(0.9, 0.99))
-    mk = lambda m, lr: torch.optim.SGD(m.parameters(), lr=lr, momentum=.95, weight_decay=.0005)
+    mk = lambda m, lr: None if m is None else torch.optim.SGD(m.parameters(), lr=lr, momentum=.95, weight_decay=.0005)
     o1, o2, o4 = mk(d1, scfg.d1lr), mk(d2, scfg.d2lr), mk(d4, scfg.d4lr)
     orc = OracleTrainer(cfg, scfg, pg, p1, p2, p4)
     batch = synth_batch(b, cfg.in_channels, cfg.n_class, hw, seed=seed + 100)
     r = ref_step_mmwhs(gen, d1, d2, d4, og, o1, o2, o4, batch, scfg.dr, scfg.wp, scfg.w1, scfg.w2, scfg.w4)
     q = orc.step(*batch, keep=True)
     out = {"seed": np.int64(seed), "b": np.int64(b), "hw": np.int64(hw)}
-    for k in ("seg_loss", "ver_s_loss", "ver_t_loss", "adv_loss", "d2_loss_src", "d1_loss_src", "d4_loss_src",
-              "d2_loss_tgt", "d1_loss_tgt", "d4_loss_tgt"):
+    keys = ["seg_loss", "adv_loss"] + (["ver_s_loss", "ver_t_loss", "d4_loss_src", "d4_loss_tgt"] if d4 is not None else [])
+    keys += (["d2_loss_src", "d2_loss_tgt"] if d2 is not None else []) + (["d1_loss_src", "d1_loss_tgt"] if d1 is not None else [])
+    keys += [k for k in ("adv1", "adv2", "adv4") if k in r]
+    for k in keys:
         close(torch.tensor(q[k]), torch.tensor(r[k]), 2e-5, "%s %s" % (tag, k))
         out[k] = np.float64(r[k])
     close(orc.kept["oS"], r["oS"], 1e-4, tag + " oS"); close(orc.kept["oT"], r["oT"], 1e-4, tag + " oT")
-    close(orc.kept["vertS"], r["vertS"], 1e-4, tag + " vertS")
+    if r["vertS"] is not None:
+        close(orc.kept["vertS"], r["vertS"], 1e-4, tag + " vertS")
     for nm in ("grad_seg", "grad_total", "grad_d1", "grad_d2", "grad_d4"):
-        for k, g in r[nm].items():
+        for k, g in r.get(nm, {}).items():
             close(orc.kept[nm][k], g, 1e-3, "%s %s %s" % (tag, nm, k))
             out["%s_norm/%s" % (nm, k)] = np.float64(g.double().norm().item())
     out["oS_s"], out["oT_s"] = sample(r["oS"]), sample(r["oT"])      # strided samples keep the fixture small
-    out["vertS"], out["vertT"] = r["vertS"].numpy(), r["vertT"].numpy()
+    if r["vertS"] is not None:
+        out["vertS"], out["vertT"] = r["vertS"].numpy(), r["vertT"].numpy()
+    for nm, m, pd in (("gen", gen, orc.gen), ("d1", d1, orc.dis1), ("d2", d2, orc.dis2), ("d4", d4, orc.dis4)):
+        if m is not None:
+            for k, v in m.state_dict().items():
+                if v.dtype.is_floating_point:
+                    close(pd[k], v, 2.5e-3, "%s param %s.%s" % (tag, nm, k))
+    post_step_samples(out, "", (("gen", gen), ("d1", d1), ("d2", d2), ("d4", d4)),
+                      {"gen": r["grad_total"], "d1": r.get("grad_d1", {}), "d2": r.get("grad_d2", {}),
+                       "d4": r.get("grad_d4", {})}, None)
     np.savez_compressed(os.path.join(GOLD, tag + ".npz"), **out)
-    print(tag, "ok", {k: round(float(out[k]), 5) for k in ("seg_loss", "adv_loss", "d4_loss_src")})
+    print(tag, "ok", {k: round(float(out[k]), 5) for k in ("seg_loss", "adv_loss")})
 
 
 
@@ -638,6 +704,12 @@ def main():
     gold_valid("valid_small", small, b=3, hw=128, seed=700)
     gold_step_mmwhs("step_mmwhs_small", ON.SegCfg(filters=4, in_channels=3, n_class=5, pointnet=True, fc_inch=9), b=8,
                     hw=128, seed=800)
+    # BASELINE config 2 in miniature (train_mscmrseg.py -d2 only: no point head, one entropy-map discriminator) and
+    # the segmenter-only loop (train_mmwhs.py with no discriminator flag: the `loss_adv_diff != 0` guard at :271)
+    gold_step("step_d2only_small", ON.SegCfg(filters=4, in_channels=1, n_class=4, pointnet=False), b=4, hw=128,
+              seed=900, n_steps=2, full=True, d1=False, d2=True, d4=False)
+    gold_step_mmwhs("step_segonly_small", ON.SegCfg(filters=4, in_channels=3, n_class=5, pointnet=False), b=4, hw=128,
+                    seed=950, d1=False, d2=False, d4=False)
     if os.environ.get("GOLDEN_FULL", "1") == "1":
         full = ON.SegCfg(filters=32, in_channels=1, n_class=4, pointnet=True, fc_inch=121)
         gold_seg("seg_full256", full, b=2, hw=256, seed=500, full_tensors=False)

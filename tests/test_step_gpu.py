@@ -16,21 +16,24 @@ from conftest import GOLD, rel_err
 pytestmark = pytest.mark.gpu
 
 
-def _build(cfg_kw, seed, dev):
+def _build(cfg_kw, seed, dev, d1=True, d2=True, d4=True, variant="mscmrseg", pn_kw=None, momentum=0.99):
     from oracle import nets as ON
     from pointcloududa_amd.networks import PointNetCls, Segmentation_model_Point, UncertaintyDiscriminator
     from pointcloududa_amd.train_step import AdversarialTrainer, TrainCfg
     cfg = ON.SegCfg(**cfg_kw)
+    pn_kw = pn_kw or {}
     pg = ON.make_params(ON.seg_param_shapes(cfg), seed)
     p1 = ON.make_params(ON.disc_param_shapes(cfg.n_class), seed + 1, std=0.02)
     p2 = ON.make_params(ON.disc_param_shapes(cfg.n_class), seed + 2, std=0.02)
-    p4 = ON.make_params(ON.pointnet_cls_param_shapes(), seed + 3)
+    p4 = ON.make_params(ON.pointnet_cls_param_shapes(**pn_kw), seed + 3)
     load = lambda m, p: (m.load_state_dict({k: v.clone() for k, v in p.items()}), m.to(dev).train())[1]
     gen = load(Segmentation_model_Point(**cfg_kw), pg)
-    d1 = load(UncertaintyDiscriminator(in_channel=cfg.n_class), p1)
-    d2 = load(UncertaintyDiscriminator(in_channel=cfg.n_class), p2)
-    d4 = load(PointNetCls(drop=0.0), p4)
-    tr = AdversarialTrainer(gen, d1, d2, d4, TrainCfg(variant="mscmrseg", n_class=cfg.n_class))
+    m1 = load(UncertaintyDiscriminator(in_channel=cfg.n_class), p1) if d1 else None
+    m2 = load(UncertaintyDiscriminator(in_channel=cfg.n_class), p2) if d2 else None
+    m4 = load(PointNetCls(drop=0.0, **pn_kw), p4) if d4 else None
+    tr = AdversarialTrainer(gen, m1, m2, m4, TrainCfg(variant=variant, n_class=cfg.n_class, d1=d1, d2=d2, d4=d4,
+                                                      d_momentum=momentum))
+    tr._p0 = {"gen": pg, "d1": p1, "d2": p2, "d4": p4}
     return cfg, tr
 
 
@@ -44,29 +47,133 @@ def _flat_norms(opt, module):
     return out
 
 
-@pytest.mark.parametrize("tag,cfg_kw,full", [
-    ("step_small", dict(filters=4, in_channels=1, n_class=4, pointnet=True, fc_inch=9), True),
-    ("step_full256", dict(filters=32, in_channels=1, n_class=4, pointnet=True, fc_inch=121), False),
+def _sample(t, n=256):
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n].double().cpu().numpy()
+
+
+# Loss scalars, per key.  1e-3 (the north-star figure) for everything that does not pass through the point-cloud
+# discriminator; d4 normalises over the batch of 4-8 point clouds with BatchNorm1d right behind a max over 300 points,
+# which turns 1e-6 input differences into percents (test_pointnet_cls_vs_reference_golden), so the three d4-derived
+# scalars (and d4's share of the summed adversarial loss) keep a 2e-2 bound.
+TIGHT, LOOSE = 1e-3, 2e-2
+
+
+def _check_losses(h, g, pre, cfg, it):
+    ms = cfg.variant == "mscmrseg"
+    tight = TIGHT if it == 0 else 2e-2       # step 1 starts from Adam-updated parameters (sign-sensitive): see below
+    loose = LOOSE if it == 0 else 1e-1
+    worst = 0.0
+    for k in ("seg_loss", "ver_s_loss", "ver_t_loss", "d1_loss_src", "d1_loss_tgt", "d2_loss_src", "d2_loss_tgt",
+              "d4_loss_src", "d4_loss_tgt"):
+        if pre + k not in g:
+            assert k not in h, k
+            continue
+        ref, tol = float(g[pre + k]), (loose if k.startswith("d4") else tight)
+        err = abs(h[k] - ref) / max(1e-3, abs(ref))
+        assert err <= tol, (it, k, h[k], ref)
+        if not k.startswith("d4"):
+            worst = max(worst, err)
+    # the three adversarial terms (dr- and w-scaled as the scripts sum them) and their sum
+    parts = {}
+    for k, w in (("adv1", 1.0 if ms else cfg.w1), ("adv2", 1.0 if ms else cfg.w2), ("adv4", 1.0 if ms else cfg.w4)):
+        if k in h:
+            got, ref = cfg.dr * h[k], float(g[pre + k])
+            tol = loose if k == "adv4" else tight
+            assert abs(got - ref) <= tol * max(1e-5, abs(ref)), (it, k, got, ref)
+            parts[k] = (abs(ref) * w, tol)
+    ref = float(g[pre + "adv_loss"])
+    assert abs(h["adv_loss"] - ref) <= sum(a * t for a, t in parts.values()) + 1e-9, (it, "adv_loss", h["adv_loss"], ref)
+    return worst
+
+
+def _check_updates(tr, g, pre):
+    """Parameters after the optimiser steps against golden strided samples of the reference's.
+    Adam's first step moves a parameter by -lr * g / (|g| + eps): the update DIRECTION must match wherever the
+    reference gradient is clear of the gradient noise floor, and both implementations must have moved by lr.
+    SGD (discriminators): (p1 - p0) / lr = -(g + wd * p0) is linear in the gradient and is compared as a tensor."""
+    from oracle import nets as ON
+    lr = tr.cfg.lr
+    n_conf = n_conf_ok = n_all = n_all_ok = 0
+    for k, v in tr.gen.state_dict().items():
+        key = pre + "ps/gen/" + k
+        if key not in g or not v.dtype.is_floating_point:
+            continue
+        got, ref = _sample(v), g[key].astype(np.float64)
+        if not ON.is_trainable(k):
+            assert np.abs(got - ref).max() <= 1e-3 * max(np.abs(ref).max(), 1e-3), (k, np.abs(got - ref).max())
+            continue
+        if pre + "gs/gen/" + k not in g:
+            assert np.array_equal(got, _sample(tr._p0["gen"][k])), k        # no gradient (encoder.conv1_1): untouched
+            continue
+        p0, gr = _sample(tr._p0["gen"][k]), g[pre + "gs/gen/" + k].astype(np.float64)
+        u_got, u_ref = (got - p0) / lr, (ref - p0) / lr
+        assert np.abs(u_got).max() <= 1.0 + 1e-3 and np.abs(u_ref).max() <= 1.0 + 1e-3, k
+        scale = np.abs(gr).max()
+        if scale < 1e-12:
+            continue
+        conf, some = np.abs(gr) >= 0.2 * scale, np.abs(gr) >= 0.02 * scale
+        ok = np.abs(u_got - u_ref) <= 0.1                       # same sign AND a full-size step on both sides
+        n_conf += int(conf.sum()); n_conf_ok += int((conf & ok).sum())
+        n_all += int(some.sum()); n_all_ok += int((some & ok).sum())
+        # sum of the parameter: at most 15 % of the elements may have stepped the other way (2 * lr each)
+        ps_ref, ps_got = float(g[pre + "psum/gen/" + k]), float(v.double().sum())
+        assert abs(ps_got - ps_ref) <= 0.15 * v.numel() * 2 * lr + 1e-5 * abs(ps_ref), (k, ps_got, ps_ref)
+    assert n_conf >= 500, n_conf                                 # not vacuous
+    assert n_conf_ok >= 0.98 * n_conf, (n_conf_ok, n_conf)
+    assert n_all_ok >= 0.90 * n_all, (n_all_ok, n_all)
+    rates = {"adam_conf": n_conf_ok / n_conf, "adam_all": n_all_ok / max(n_all, 1)}
+    for nm, mod, opt, tol in (("d1", tr.dis1, tr.opt_d1, 2e-2), ("d2", tr.dis2, tr.opt_d2, 2e-2), ("d4", tr.dis4, tr.opt_d4, 0.3)):
+        if mod is None:
+            continue
+        worst = 0.0
+        for k, v in mod.state_dict().items():
+            key = pre + "ps/%s/%s" % (nm, k)
+            if key not in g or not v.dtype.is_floating_point or ".in" in k or k.startswith("in"):
+                continue
+            got, ref = _sample(v), g[key].astype(np.float64)
+            if not ON.is_trainable(k):
+                lim = 1e-3 if nm != "d4" else 5e-2
+                assert np.abs(got - ref).max() <= lim * max(np.abs(ref).max(), 1e-3), (nm, k)
+                continue
+            p0 = _sample(tr._p0[nm][k])
+            u_got, u_ref = (got - p0) / opt.lr, (ref - p0) / opt.lr
+            floor = 4e-9 / opt.lr * max(np.abs(p0).max(), 1e-3) / 0.02       # one fp32 ulp of the parameter, in update units
+            e = np.abs(u_got - u_ref).max() / max(np.abs(u_ref).max(), 1e-30)
+            assert np.abs(u_got - u_ref).max() <= tol * np.abs(u_ref).max() + floor, (nm, k, e)
+            worst = max(worst, e)
+            ps_ref, ps_got = float(g[pre + "psum/%s/%s" % (nm, k)]), float(v.double().sum())
+            assert abs(ps_got - ps_ref) <= opt.lr * tol * float(np.abs(u_ref).mean()) * v.numel() + v.numel() * floor * opt.lr, (nm, k)
+        rates["sgd_" + nm] = worst
+    return rates
+
+
+@pytest.mark.parametrize("tag,cfg_kw,full,dflags", [
+    ("step_small", dict(filters=4, in_channels=1, n_class=4, pointnet=True, fc_inch=9), True, (True, True, True)),
+    ("step_full256", dict(filters=32, in_channels=1, n_class=4, pointnet=True, fc_inch=121), False, (True, True, True)),
+    # BASELINE config 2 in miniature: train_mscmrseg.py -d2 (no point head, the entropy-map discriminator only)
+    ("step_d2only_small", dict(filters=4, in_channels=1, n_class=4, pointnet=False), True, (False, True, False)),
 ])
-def test_train_step_vs_reference_golden(dev, tag, cfg_kw, full):
+def test_train_step_vs_reference_golden(dev, tag, cfg_kw, full, dflags):
     from oracle.synth import synth_batch
     from pointcloududa_amd.train_step import AdversarialTrainer
     g = np.load(os.path.join(GOLD, tag + ".npz"))
     seed, b, hw, n_steps = int(g["seed"]), int(g["b"]), int(g["hw"]), int(g["n_steps"])
-    cfg, tr = _build(cfg_kw, seed, dev)
+    d1, d2, d4 = dflags
+    cfg, tr = _build(cfg_kw, seed, dev, d1=d1, d2=d2, d4=d4)
     for it in range(n_steps):
         batch = synth_batch(b, cfg.in_channels, cfg.n_class, hw, seed=seed + 100 + it)
         img_a, mask_a, vert_a, img_b, vert_b = [torch.from_numpy(t).to(dev) for t in batch]
         out = tr.step(img_a, mask_a, vert_a, img_b, vert_b, keep=(it == 0))
         h = AdversarialTrainer.to_host(out, tr.cfg)
-        tol = 2e-2 if it == 0 else 1e-1     # step 0: d4 (BatchNorm1d over the batch of 2-4) limits this
-        for k in ("seg_loss", "ver_s_loss", "ver_t_loss", "adv_loss", "d2_loss_src", "d1_loss_src", "d4_loss_src",
-                  "d2_loss_tgt", "d1_loss_tgt", "d4_loss_tgt"):
-            ref = float(g["s%d/%s" % (it, k)])
-            assert abs(h[k] - ref) <= tol * max(1e-3, abs(ref)), (it, k, h[k], ref)
+        worst = _check_losses(h, g, "s%d/" % it, tr.cfg, it)
         assert abs(h["seg_dice"] - float(g["s%d/seg_dice" % it])) < (1e-4 if it == 0 else 5e-2)
-        for d in ("dis1", "dis2", "dis4"):
-            assert 0.0 <= h[d + "_acc1"] <= 1.0 and 0.0 <= h[d + "_acc2"] <= 1.0
+        for d, on in (("dis1", d1), ("dis2", d2), ("dis4", d4)):
+            if on:
+                assert 0.0 <= h[d + "_acc1"] <= 1.0 and 0.0 <= h[d + "_acc2"] <= 1.0
+            else:
+                assert d + "_acc1" not in h
         if it > 0:
             continue
         last = tr.last
@@ -76,11 +183,19 @@ def test_train_step_vs_reference_golden(dev, tag, cfg_kw, full):
             from test_networks_gpu import _strided
             assert rel_err(_strided(last["oS"]), g["s0/oS_s"]) < 1e-3
             assert rel_err(_strided(last["oT"]), g["s0/oT_s"]) < 1e-3
-        assert rel_err(last["vertS"], g["s0/vertS"]) < 1e-3 and rel_err(last["vertT"], g["s0/vertT"]) < 1e-3
-        # gradient norms per parameter after phase 1 (seg) and phase 2 (seg + adversarial), and of the D's
+        if d4:
+            assert rel_err(last["vertS"], g["s0/vertS"]) < 1e-3 and rel_err(last["vertT"], g["s0/vertT"]) < 1e-3
+        else:
+            assert last["vertS"] is None and last["vertT"] is None
+        # gradient norms per parameter after phase 1 (seg) and phase 2 (seg + adversarial), and of the D's.  (Independent
+        # forward passes: routing flips limit these to ~1e-2, see test_backward_exact_gpu.py for the 1e-4 checks with
+        # the routing shared.)  d4's BatchNorm1d over 4 samples limits what passes through it.
         for nm, mod, snap in (("grad_seg", tr.gen, last["grad_seg"]), ("grad_total", tr.gen, last["grad_total"]),
-                              ("grad_d1", tr.dis1, last["grad_d1"]), ("grad_d2", tr.dis2, last["grad_d2"]),
-                              ("grad_d4", tr.dis4, last["grad_d4"])):
+                              ("grad_d1", tr.dis1, last.get("grad_d1")), ("grad_d2", tr.dis2, last.get("grad_d2")),
+                              ("grad_d4", tr.dis4, last.get("grad_d4"))):
+            if mod is None:
+                continue
+            via_d4 = nm == "grad_d4" or (nm == "grad_total" and d4)
             tot_ref = tot_got = 0.0
             floor = 1e-3 * sum(float(g[kk]) ** 2 for kk in g.files if kk.startswith("s0/%s_norm/" % nm)) ** 0.5
             for k, (off, n) in _flat_norms(None, mod).items():
@@ -90,22 +205,87 @@ def test_train_step_vs_reference_golden(dev, tag, cfg_kw, full):
                     continue
                 ref, got = float(g[key]), float(snap[off:off + n].double().norm())
                 tot_ref += ref * ref; tot_got += got * got
-                # the point-cloud discriminator normalises over a batch of 2-4 samples: its gradients
-                # (and what they send back into the segmenter) are only reproducible to a few percent
-                lim = 0.3 if nm in ("grad_d4", "grad_total") else 1e-1
+                lim = 0.3 if via_d4 else 1e-1
                 assert abs(got - ref) <= lim * ref + floor, (nm, k, got, ref)
-            assert abs(tot_got ** 0.5 - tot_ref ** 0.5) <= (0.15 if nm in ("grad_d4", "grad_total") else 3e-2) * tot_ref ** 0.5, nm
-        # parameters after the optimiser steps: checksums of the reference's state_dict
-        for nm, mod in (("gen", tr.gen), ("d1", tr.dis1), ("d2", tr.dis2), ("d4", tr.dis4)):
-            for k, v in mod.state_dict().items():
-                if not v.dtype.is_floating_point or k.endswith("running_var") or ".in" in k or k.startswith("in"):
-                    continue
-                ref_abs = float(g["s0/pabs/%s/%s" % (nm, k)])
-                got_abs = float(v.double().abs().sum())
-                # Adam's first update is lr*sign(g): parameters whose gradient is rounding noise may move
-                # by up to 2*lr in either implementation -> allow half the elements to do so
-                slack = 0.5 * v.numel() * 2 * tr.cfg.lr if nm == "gen" else 0.0
-                assert abs(got_abs - ref_abs) <= 2e-3 * max(ref_abs, 1e-3) + 1e-6 + slack, (nm, k, got_abs, ref_abs)
+            assert abs(tot_got ** 0.5 - tot_ref ** 0.5) <= (0.15 if via_d4 else 3e-2) * tot_ref ** 0.5, nm
+        rates = _check_updates(tr, g, "s0/")
+        print(tag, "worst non-d4 loss error %.2e; update checks %s" % (worst, {k: round(v, 4) for k, v in rates.items()}))
+
+
+def test_segmenter_only_step_vs_reference_golden(dev):
+    """train_mmwhs.py with no discriminator flag: the adversarial backward is skipped by the script's
+    ``if loss_adv_diff != 0`` guard (:271), phases 3-5 by ``if args.d1 or args.d2 or args.d4`` (:282); the step is
+    source forward/backward + target forward + Adam -- the seg-only branch of AdversarialTrainer._phase345."""
+    from oracle.synth import synth_batch
+    from pointcloududa_amd.train_step import AdversarialTrainer
+    from test_networks_gpu import _strided
+    g = np.load(os.path.join(GOLD, "step_segonly_small.npz"))
+    seed, b, hw = int(g["seed"]), int(g["b"]), int(g["hw"])
+    cfg, tr = _build(dict(filters=4, in_channels=3, n_class=5, pointnet=False), seed, dev, d1=False, d2=False, d4=False,
+                     variant="mmwhs", momentum=0.95)
+    batch = [torch.from_numpy(t).to(dev) for t in synth_batch(b, 3, 5, hw, seed=seed + 100)]
+    out = tr.step(*batch, keep=True)
+    h = AdversarialTrainer.to_host(out, tr.cfg)
+    assert abs(h["seg_loss"] - float(g["seg_loss"])) <= TIGHT * abs(float(g["seg_loss"]))
+    assert h["adv_loss"] == 0.0 and float(g["adv_loss"]) == 0.0
+    assert not any(k.startswith(("d1_", "d2_", "d4_", "adv1", "adv2", "adv4")) for k in h)
+    assert rel_err(_strided(tr.last["oS"]), g["oS_s"]) < 1e-3 and rel_err(_strided(tr.last["oT"]), g["oT_s"]) < 1e-3
+    # no adversarial pass: the gradient Adam consumed is the supervised one
+    assert torch.equal(tr.last["grad_seg"], tr.last["grad_total"])
+    rates = _check_updates(tr, g, "")
+    print("seg-only update checks", rates)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_config2_full_size_step(dev, precision):
+    """BASELINE config 2 at full size (UNet without point head + the entropy-map discriminator, B = 16, 256x256,
+    32 filters; `d1 = d4 = False`) in both MFMA modes.  No full-size reference run fits a fixture, so the checks are
+    size-independent properties: the bf16x3 trajectory is bit-reproducible and its first-step losses equal the CPU
+    restatement's on the first two samples' worth of statistics-free quantities; the single-bf16 throughput mode stays
+    within its stated 2e-2 of the parity mode on every loss over three steps, and both leave d1 / d4 untouched."""
+    import pointcloududa_amd as P
+    from oracle.synth import synth_batch
+    cfg_kw = dict(filters=32, in_channels=1, n_class=4, pointnet=False)
+    batches = [[torch.from_numpy(t).to(dev) for t in synth_batch(16, 1, 4, 256, seed=1500 + i)] for i in range(3)]
+    runs = {}
+    try:
+        for prec in ("bf16x3", precision) if precision != "bf16x3" else ("bf16x3", "bf16x3"):
+            P.set_precision(prec)
+            _, tr = _build(cfg_kw, 31, dev, d1=False, d2=True, d4=False)
+            hs = []
+            for bt in batches:
+                out = tr.step(*bt)
+                hs.append(tr.to_host(out, tr.cfg))
+            torch.cuda.synchronize()
+            runs.setdefault(prec, []).append((tr, hs))
+    finally:
+        P.set_precision("bf16x3")
+    ref_tr, ref_hs = runs["bf16x3"][0]
+    assert ref_tr.dis1 is None and ref_tr.dis4 is None and ref_tr.opt_d1 is None and ref_tr.opt_d4 is None
+    for h in ref_hs:
+        assert set(k for k in h if k.startswith(("d1_", "d4_", "adv1", "adv4", "ver_"))) == set()
+        assert all(np.isfinite(v) for v in h.values())
+    if precision == "bf16x3":
+        tr2, hs2 = runs["bf16x3"][1]
+        assert hs2 == ref_hs
+        assert torch.equal(tr2.opt_gen.p, ref_tr.opt_gen.p) and torch.equal(tr2.opt_d2.p, ref_tr.opt_d2.p)
+        # the first step's losses against the CPU restatement of the reference step on the same batch (B = 16 through
+        # the fp32 oracle costs ~20 s of CPU: one step only)
+        from oracle import nets as ON
+        from oracle.step import OracleTrainer, StepCfg
+        cfg = ON.SegCfg(**cfg_kw)
+        orc = OracleTrainer(cfg, StepCfg(variant="mscmrseg", d1=False, d2=True, d4=False, n_class=4),
+                            ref_tr._p0["gen"], None, ref_tr._p0["d2"], None)
+        q = orc.step(*synth_batch(16, 1, 4, 256, seed=1500))
+        for k in ("seg_loss", "adv_loss", "d2_loss_src", "d2_loss_tgt"):
+            assert abs(ref_hs[0][k] - q[k]) <= TIGHT * max(1e-3, abs(q[k])), (k, ref_hs[0][k], q[k])
+        assert abs(ref_hs[0]["seg_dice"] - q["seg_dice"]) < 1e-4
+    else:
+        tr2, hs2 = runs["bf16"][0]
+        for it, (ha, hb) in enumerate(zip(hs2, ref_hs)):
+            for k in ("seg_loss", "adv_loss", "d2_loss_src", "d2_loss_tgt"):
+                assert abs(ha[k] - hb[k]) <= 2e-2 * max(1e-3, abs(hb[k])), (it, k, ha[k], hb[k])
+        assert rel_err(tr2.opt_d2.p, ref_tr.opt_d2.p) < 1e-3
 
 
 def test_graph_replay_matches_eager_steps(dev):
@@ -132,29 +312,17 @@ def test_mmwhs_variant_step_vs_reference_golden(dev):
     """The MM-WHS loop (train_mmwhs.py:187-360; SURVEY config 4 in miniature: 3-channel input, 5 classes, softmax
     mode, PointNetCls(feature_transform=True, ext=True), discriminator momentum 0.95) on the HIP kernels against
     the loop re-typed around the reference modules."""
-    from oracle import nets as ON
     from oracle.synth import synth_batch
-    from pointcloududa_amd.networks import PointNetCls, Segmentation_model_Point, UncertaintyDiscriminator
-    from pointcloududa_amd.train_step import AdversarialTrainer, TrainCfg
+    from pointcloududa_amd.train_step import AdversarialTrainer
     from test_networks_gpu import _strided
     g = np.load(os.path.join(GOLD, "step_mmwhs_small.npz"))
     seed, b, hw = int(g["seed"]), int(g["b"]), int(g["hw"])
     cfg_kw = dict(filters=4, in_channels=3, n_class=5, pointnet=True, fc_inch=9)
-    cfg = ON.SegCfg(**cfg_kw)
-    load = lambda m, p: (m.load_state_dict({k: v.clone() for k, v in p.items()}), m.to(dev).train())[1]
-    gen = load(Segmentation_model_Point(**cfg_kw), ON.make_params(ON.seg_param_shapes(cfg), seed))
-    d1 = load(UncertaintyDiscriminator(in_channel=5), ON.make_params(ON.disc_param_shapes(5), seed + 1, std=0.02))
-    d2 = load(UncertaintyDiscriminator(in_channel=5), ON.make_params(ON.disc_param_shapes(5), seed + 2, std=0.02))
-    d4 = load(PointNetCls(feature_transform=True, ext=True, drop=0.0),
-              ON.make_params(ON.pointnet_cls_param_shapes(feature_transform=True, ext=True), seed + 3))
-    tr = AdversarialTrainer(gen, d1, d2, d4, TrainCfg(variant="mmwhs", n_class=5, softmax=True, d_momentum=0.95))
+    cfg, tr = _build(cfg_kw, seed, dev, variant="mmwhs", pn_kw=dict(feature_transform=True, ext=True), momentum=0.95)
     batch = [torch.from_numpy(t).to(dev) for t in synth_batch(b, 3, 5, hw, seed=seed + 100)]
     out = tr.step(*batch, keep=True)
     h = AdversarialTrainer.to_host(out, tr.cfg)
-    for k in ("seg_loss", "ver_s_loss", "ver_t_loss", "adv_loss", "d2_loss_src", "d1_loss_src", "d4_loss_src",
-              "d2_loss_tgt", "d1_loss_tgt", "d4_loss_tgt"):
-        ref = float(g[k])
-        assert abs(h[k] - ref) <= 2e-2 * max(1e-3, abs(ref)), (k, h[k], ref)
+    worst = _check_losses(h, g, "", tr.cfg, 0)
     last = tr.last
     assert rel_err(_strided(last["oS"]), g["oS_s"]) < 1e-3 and rel_err(_strided(last["oT"]), g["oT_s"]) < 1e-3
     assert rel_err(last["vertS"], g["vertS"]) < 1e-3 and rel_err(last["vertT"], g["vertT"]) < 1e-3
@@ -166,6 +334,8 @@ def test_mmwhs_variant_step_vs_reference_golden(dev):
             if key in g:
                 tot_ref += float(g[key]) ** 2; tot_got += float(snap[off:off + n].double().norm()) ** 2
         assert abs(tot_got ** 0.5 - tot_ref ** 0.5) <= lim * tot_ref ** 0.5, (nm, tot_got ** 0.5, tot_ref ** 0.5)
+    rates = _check_updates(tr, g, "")
+    print("mmwhs worst non-d4 loss error %.2e; update checks %s" % (worst, {k: round(v, 4) for k, v in rates.items()}))
 
 
 def test_step_with_rccl_collectives_in_a_one_rank_group(dev, monkeypatch):
