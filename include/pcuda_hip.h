@@ -182,6 +182,12 @@ int pcuda_maxpool2_bwd(const float* dy, long long dy_sn, long long dy_sc, const 
 /* dx[h][w] (+)= sum of the 2x2 block of dy[2h][2w] (nearest-upsample backward) */
 int pcuda_upsample2_bwd(const float* dy, long long dy_sn, long long dy_sc, float* dx, long long dx_sn,
                         long long dx_sc, int accumulate, int n, int c, int h, int w, pcuda_stream_t s);
+/* bilinear resize, align_corners = True (nn.UpsamplingBilinear2d(size=(224, 224)) in OutputDiscriminator, GAN.py:57,78):
+ * y dense [n][c][oh][ow]; ATen's arithmetic (src = dst * (in-1)/(out-1)).  bwd: dx = J^T dy, gather form (deterministic) */
+int pcuda_bilinear_fwd(const float* x, long long x_sn, long long x_sc, int n, int c, int h, int w, float* y, int oh,
+                       int ow, pcuda_stream_t s);
+int pcuda_bilinear_bwd(const float* dy, int n, int c, int oh, int ow, float* dx, long long dx_sn, long long dx_sc,
+                       int h, int w, pcuda_stream_t s);
 /* taps unfolded into channels (u: dense [n][c*k*k][oh][ow]); a k x k layer over few input channels becomes a 1x1
  * layer over c*k*k of them (the discriminators' first layer, GAN.py:96 / :120-124) */
 int pcuda_unfold_taps(const float* x, long long x_sn, long long x_sc, int n, int c, int h, int w, int k, int stride,
@@ -261,6 +267,15 @@ int pcuda_max_points_bwd(const float* dy, const int* idx, int b, int c, int l, f
 /* batched small matmul C[b] = op(A[b]) . op(B[b]); A [m][k] (or [k][m] when ta), B [k][n] (or [n][k] when tb) */
 int pcuda_bmm(const float* a, const float* bmat, float* c, int batch, int m, int k, int n, int ta, int tb,
               int accumulate, pcuda_stream_t s);
+
+/* jaccard_loss(true, logits=probabilities, eps, activation=False) as a free-standing function (utils/loss.py:5-37 the way
+ * train_mscmrseg.py:203 / train_mmwhs.py:218 call it): probs fp32 dense [n][c][hw]; truth one-hot, fp32 or uint8;
+ * loss = 1 - mean_c I_c / (S_c - I_c + eps).  bwd: dprobs = gout * d loss / d probs (workspace of the forward call) */
+size_t pcuda_jaccard_workspace_size(int c);
+int pcuda_jaccard_fwd(const float* probs, const void* truth, int truth_is_u8, int n, int c, long long hw, float eps,
+                      float* loss, void* workspace, size_t workspace_bytes, pcuda_stream_t s);
+int pcuda_jaccard_bwd(const void* truth, int truth_is_u8, int n, int c, long long hw, float eps, const float* gout,
+                      float* dprobs, const void* workspace, pcuda_stream_t s);
 
 /* ------------------------------------------------------------------------------------
  * mask -> surface point cloud sampler (utils/npy2point.py:7-18,101-125)

@@ -29,6 +29,21 @@ def jaccard_loss(true, probs, eps: float = 1e-7):
     return 1.0 - (inter / (card - inter + eps)).mean()
 
 
+def jaccard_loss_ref_signature(true, logits, eps: float = 1e-7, activation: bool = True):
+    """loss.py:5-37 with every branch: C > 1 with ``activation`` (softmax over channels) or without; C == 1:
+    probabilities [sigmoid, 1 - sigmoid].  NB the one-hot the C == 1 branch builds (:15-19) is dead code: line 27,
+    ``true_1_hot = true.type(probas.type())``, replaces it with ``true`` itself, which then BROADCASTS over the two
+    probability channels -- restated as the reference executes, not as it reads."""
+    c = logits.shape[1]
+    if c == 1:
+        pos = torch.sigmoid(logits)
+        probs = torch.cat([pos, 1 - pos], dim=1)                                           # :20-22
+        true = true.to(probs.dtype).expand_as(probs)                                       # :27 + broadcasting in :31,33
+    else:
+        probs = F.softmax(logits, dim=1) if activation else logits                         # :24
+    return jaccard_loss(true, probs, eps)
+
+
 def batch_nn_loss(x, y):
     """loss.py:40-76.  x,y: [B,N,3].  P[b,i,j] = |x_i|^2 + |y_j|^2 - 2 x_i.y_j (three bmm's,
     so NOT clamped at 0), d = sqrt(P + 1e-5); mean_i min_j d  +  mean_j min_i d, averaged over B.

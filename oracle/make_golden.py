@@ -35,7 +35,7 @@ from oracle.synth import synth_batch                                # noqa: E402
 
 import utils.loss as ref_loss                                       # noqa: E402
 ref_loss.torch.cuda.LongTensor = torch.LongTensor                   # CPU shim for loss.py:59
-from networks.GAN import UncertaintyDiscriminator                   # noqa: E402
+from networks.GAN import Discriminator, OutputDiscriminator, UncertaintyDiscriminator   # noqa: E402
 from networks.PointNetCls import PointNetCls                        # noqa: E402
 from networks.unet import Segmentation_model_Point                  # noqa: E402
 from utils.npy2point import graipher                                # noqa: E402
@@ -105,6 +105,16 @@ def gold_param_counts():
     assert rows["seg_pointnet_fc81"] == 19013990 and rows["seg_nopoint"] == 13483844
     assert rows["seg_5class_fc121"] == 19014143 and rows["disc4"] == 2764800
     assert rows["disc5_ext"] == 9839616 and rows["pncls"] == 1604106 and rows["pncls_ft_ext"] == 4021178
+    # batch size 1: the reference's InstanceNorm branch (PointNetCls.py:47-55) raises inside the reference itself
+    raised = 0
+    for mode in ("train", "eval"):
+        m = getattr(PointNetCls(), mode)()
+        try:
+            m(torch.rand(1, 3, 300))
+        except (RuntimeError, ValueError):
+            raised += 1
+    rows["pncls_batch1_raises"] = raised
+    assert raised == 2
     np.savez(os.path.join(GOLD, "param_counts.npz"), **{k: np.int64(v) for k, v in rows.items()})
     print("param counts ok", rows)
 
@@ -213,6 +223,48 @@ def gold_disc(tag, inch, ext, b, hw, seed):
     print(tag, "ok", tuple(d.shape))
 
 
+def gold_unused_discs(seed=250):
+    """GAN.py's two discriminators the train scripts never instantiate: OutputDiscriminator (:52-86) and the fully
+    connected Discriminator (:7-49).  Outputs, input gradient and per-parameter gradient norms under the domain loss."""
+    out = {"seed": np.int64(seed)}
+    rng = np.random.default_rng(seed + 1)
+    for tag, softmax in (("out", False), ("out_sm", True)):
+        params = ON.make_params(ON.disc_param_shapes(4, False), seed, std=0.02)
+        x = torch.from_numpy(rng.normal(0, 1, (2, 4, 96, 80)).astype(np.float32))
+        ref = load_into(OutputDiscriminator(in_channel=4, softmax=softmax), params).train()
+        xr = x.clone().requires_grad_(True)
+        d = ref(xr)
+        F.binary_cross_entropy_with_logits(d, torch.zeros_like(d)).backward()
+        p2 = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        xo = x.clone().requires_grad_(True)
+        d2 = ON.output_disc_forward(p2, xo, softmax)
+        OL.bce_logits_const(d2, 0.0).backward()
+        close(d2, d, 1e-5, tag); close(xo.grad, xr.grad, 1e-4, tag + " dx")
+        out[tag + "/x"] = x.numpy(); out[tag + "/y"] = d.detach().numpy(); out[tag + "/dx"] = xr.grad.numpy()
+        for k, p in ref.named_parameters():
+            close(p2[k].grad, p.grad, 2e-4, tag + " grad " + k)
+            out["%s/gnorm/%s" % (tag, k)] = np.float64(p.grad.double().norm().item())
+            out["%s/gs/%s" % (tag, k)] = sample(p.grad, 256)
+    params = ON.make_params(ON.fc_disc_param_shapes(), seed + 5, std=0.02)
+    x = torch.from_numpy(rng.normal(0, 1, (3, 24576)).astype(np.float32))
+    ref = load_into(Discriminator(), params).train()
+    xr = x.clone().requires_grad_(True)
+    d = ref(xr)
+    F.binary_cross_entropy_with_logits(d, torch.ones_like(d)).backward()
+    p2 = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    xo = x.clone().requires_grad_(True)
+    d2 = ON.fc_disc_forward(p2, xo)
+    OL.bce_logits_const(d2, 1.0).backward()
+    close(d2, d, 1e-5, "fc disc"); close(xo.grad, xr.grad, 1e-4, "fc disc dx")
+    out["fc/y"] = d.detach().numpy(); out["fc/dx_s"] = sample(xr.grad, 1024)
+    for k, p in ref.named_parameters():
+        close(p2[k].grad, p.grad, 2e-4, "fc grad " + k)
+        out["fc/gnorm/" + k] = np.float64(p.grad.double().norm().item())
+        out["fc/gs/" + k] = sample(p.grad, 256)
+    np.savez_compressed(os.path.join(GOLD, "unused_discs.npz"), **out)
+    print("unused discriminators ok")
+
+
 # --------------------------------------------------------------------------- #
 def gold_pncls(tag, ft, ext, b, seed):
     params = ON.make_params(ON.pointnet_cls_param_shapes(ft, ext=ext), seed)
@@ -284,6 +336,16 @@ def gold_losses(seed=7):
     (c2 + j2).backward()
     close(c2, ce, 1e-6, "ce"); close(j2, jac, 1e-6, "jac sm"); close(lo.grad, lr.grad, 1e-5, "seg sm grad")
     out.update(ce=np.float64(ce.item()), jac_sm=np.float64(jac.item()), dlogits_sm=lr.grad.numpy())
+
+    # jaccard_loss with the reference's own signature, every branch (loss.py:5-37)
+    for name, tr_, lg_, act in (("jacfn_probs", yf, torch.sigmoid(logits), False), ("jacfn_softmax", yf, logits, True),
+                                ("jacfn_c1", torch.from_numpy((lab > 1).astype(np.int64))[:, None], logits[:, :1], True)):
+        lr = lg_.clone().requires_grad_(True)
+        jr = ref_loss.jaccard_loss(tr_, lr, 1e-7, act); jr.backward()
+        lo = lg_.clone().requires_grad_(True)
+        jo = OL.jaccard_loss_ref_signature(tr_, lo, 1e-7, act); jo.backward()
+        close(jo, jr, 1e-6, name); close(lo.grad, lr.grad, 1e-5, name + " grad")
+        out[name] = np.float64(jr.item()); out[name + "_grad"] = lr.grad.numpy()
 
     # entropy maps: mscmrseg (train_mscmrseg.py:222) and mmwhs (train_mmwhs.py:224,242)
     import math
@@ -698,6 +760,9 @@ def main():
              seed=110, full_tensors=True, softmax=True)
     gold_disc("disc_small", 4, False, b=2, hw=64, seed=200)
     gold_disc("disc_ext_small", 5, True, b=2, hw=128, seed=210)
+    gold_unused_discs()
+    gold_seg("seg_small_extpn", ON.SegCfg(filters=4, in_channels=1, n_class=4, pointnet=True, fc_inch=9, extpn=True), b=2,
+             hw=128, seed=120, full_tensors=True)
     gold_pncls("pncls", False, False, b=16, seed=300)
     gold_pncls("pncls_ft_ext", True, True, b=12, seed=310)
     gold_step("step_small", small, b=4, hw=128, seed=400, n_steps=2, full=True)

@@ -337,6 +337,32 @@ def disc_forward(p: Params, x, ext: bool = False):
     return _anc("conv5", F.conv2d(x, p["conv5.weight"], None, stride=2, padding=2))
 
 
+def output_disc_forward(p: Params, x, softmax: bool = False):
+    """OutputDiscriminator.forward (GAN.py:77-86): bilinear resize to 224x224 (align_corners=True), optional channel
+    softmax, then the same five 4x4 s2 p2 layers."""
+    x = F.interpolate(x, size=(224, 224), mode="bilinear", align_corners=True)    # nn.UpsamplingBilinear2d
+    if softmax:
+        x = F.softmax(x, dim=1)
+    return disc_forward(p, x, ext=False)
+
+
+def fc_disc_param_shapes() -> Dict[str, Tuple[int, ...]]:
+    """Discriminator (GAN.py:7-18)"""
+    s, cin = {}, 24576
+    for i, co in enumerate((4096, 2048, 1024, 1)):
+        s["fc%d.weight" % (i + 1)] = (co, cin)
+        s["fc%d.bias" % (i + 1)] = (co,)
+        cin = co
+    return s
+
+
+def fc_disc_forward(p: Params, x):
+    """Discriminator.forward (GAN.py:42-49)"""
+    for i in (1, 2, 3):
+        x = F.leaky_relu(_anc("fc%d" % i, F.linear(x, p["fc%d.weight" % i], p["fc%d.bias" % i])), 0.2)
+    return _anc("fc4", F.linear(x, p["fc4.weight"], p["fc4.bias"]))
+
+
 # --------------------------------------------------------------------------- #
 # point-cloud discriminator
 # --------------------------------------------------------------------------- #

@@ -65,6 +65,8 @@ _PROTOS = {
     "pcuda_maxpool2_fwd": (i32, [vp, i64, i64, vp, vp, vp, i64, i64, vp, i32, i32, i32, i32, vp]),
     "pcuda_maxpool2_bwd": (i32, [vp, i64, i64, vp, i64, i64, vp, vp, i64, i64, i32, i32, i32, i32, i32, vp]),
     "pcuda_upsample2_bwd": (i32, [vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, i32, vp]),
+    "pcuda_bilinear_fwd": (i32, [vp, i64, i64, i32, i32, i32, i32, vp, i32, i32, vp]),
+    "pcuda_bilinear_bwd": (i32, [vp, i32, i32, i32, i32, vp, i64, i64, i32, i32, vp]),
     "pcuda_unfold_taps": (i32, [vp, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
     "pcuda_add4": (i32, [vp, vp, vp, vp, vp, i64, vp]),
     "pcuda_mul": (i32, [vp, vp, vp, i64, vp]),
@@ -73,6 +75,9 @@ _PROTOS = {
     "pcuda_seg_loss_workspace_size": (sz, [i32, i32, i64]),
     "pcuda_seg_loss_fwd": (i32, [vp, vp, i32, i32, i32, i64, vp, vp, sz, vp]),
     "pcuda_seg_loss_bwd": (i32, [vp, vp, i32, i32, i32, i64, vp, vp, vp, vp, vp]),
+    "pcuda_jaccard_workspace_size": (sz, [i32]),
+    "pcuda_jaccard_fwd": (i32, [vp, vp, i32, i32, i32, i64, f32, vp, vp, sz, vp]),
+    "pcuda_jaccard_bwd": (i32, [vp, i32, i32, i32, i64, f32, vp, vp, vp, vp]),
     "pcuda_bce_const_fwd": (i32, [vp, i64, f32, vp, vp, vp]),
     "pcuda_bce_const_bwd": (i32, [vp, i64, f32, vp, f32, vp, vp]),
     "pcuda_nn_loss_fwd": (i32, [vp, vp, i32, i32, vp, vp, vp, vp]),

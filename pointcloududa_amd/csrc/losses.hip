@@ -462,6 +462,107 @@ extern "C" int pcuda_seg_loss_bwd(const float* logits, const uint8_t* onehot, in
   return PCUDA_OK;
 }
 
+// ---------------------------------------------------------------------------- Jaccard on given probabilities
+// utils/loss.py:5-37 as a free-standing function (the fused seg_loss above is what the train step uses): per class
+// I_c = sum p*y, S_c = sum (p + y) over (batch, pixels); loss = 1 - mean_c I_c / (S_c - I_c + eps).
+// ws (doubles): [c] I, [c] S, then float partials [JAC_BLOCKS][c][2]
+#define JAC_BLOCKS 256
+__global__ __launch_bounds__(256) void jaccard_partial_kernel(const float* __restrict__ p, const float* __restrict__ tf,
+                                                              const uint8_t* __restrict__ tu, int c, long long hw,
+                                                              long long npix, float* __restrict__ part) {
+  __shared__ float sh[4][2];
+  const int k = blockIdx.y;
+  float a0 = 0.f, a1 = 0.f;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < npix; i += 256ll * gridDim.x) {
+    const long long n = i / hw, px = i - n * hw;
+    const long long o = (n * c + k) * hw + px;
+    const float pr = p[o], y = tf ? tf[o] : (float)tu[o];
+    a0 += pr * y;
+    a1 += pr + y;
+  }
+  a0 = wave_sum(a0); a1 = wave_sum(a1);
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6][0] = a0; sh[threadIdx.x >> 6][1] = a1; }
+  __syncthreads();
+  if (threadIdx.x < 2)
+    part[((long long)blockIdx.x * c + k) * 2 + threadIdx.x] =
+        (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+__global__ void jaccard_final_kernel(const float* __restrict__ part, int nblocks, int c, float eps,
+                                     double* __restrict__ sums, float* __restrict__ loss) {
+  __shared__ double tot[2 * MAXC];
+  if ((int)threadIdx.x < 2 * c) {
+    const int k = threadIdx.x >> 1, which = threadIdx.x & 1;
+    double s = 0;
+    for (int b = 0; b < nblocks; ++b) s += (double)part[((long long)b * c + k) * 2 + which];   // fixed order
+    tot[which * c + k] = s;
+    sums[which * c + k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double j = 0;
+    for (int k = 0; k < c; ++k) j += tot[k] / (tot[c + k] - tot[k] + (double)eps);
+    loss[0] = (float)(1.0 - j / c);
+  }
+}
+
+// d loss / d p = -(1/C) * (y * (U + eps) - I * (1 - y)) / (U + eps)^2,   U = S - I
+__global__ __launch_bounds__(256) void jaccard_bwd_kernel(const float* __restrict__ tf, const uint8_t* __restrict__ tu,
+                                                          int c, long long hw, long long npix, float eps,
+                                                          const double* __restrict__ sums,
+                                                          const float* __restrict__ gout, float* __restrict__ dp) {
+  const int k = blockIdx.y;
+  const double I = sums[k], U = sums[c + k] - I + (double)eps;
+  const float g = (gout ? *gout : 1.f) / (float)c;
+  const float a = (float)(1.0 / U), b = (float)(I / (U * U));
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < npix; i += 256ll * gridDim.x) {
+    const long long n = i / hw, px = i - n * hw;
+    const long long o = (n * c + k) * hw + px;
+    const float y = tf ? tf[o] : (float)tu[o];
+    dp[o] = -g * (y * a - (1.f - y) * b);
+  }
+}
+
+extern "C" size_t pcuda_jaccard_workspace_size(int c) {
+  return (size_t)2 * MAXC * sizeof(double) + (size_t)JAC_BLOCKS * (c > 0 ? c : 1) * 2 * sizeof(float);
+}
+
+extern "C" int pcuda_jaccard_fwd(const float* probs, const void* truth, int truth_is_u8, int n, int c, long long hw,
+                                 float eps, float* loss, void* workspace, size_t workspace_bytes, pcuda_stream_t s) {
+  if (!probs || !truth || !loss || n <= 0 || c <= 0 || c > MAXC || hw <= 0)
+    PCUDA_FAIL(PCUDA_E_BADARG, "jaccard_fwd: bad arguments");
+  if (!workspace || workspace_bytes < pcuda_jaccard_workspace_size(c))
+    PCUDA_FAIL(PCUDA_E_WORKSPACE, "jaccard_fwd: workspace too small");
+  const long long npix = (long long)n * hw;
+  int blocks = grid_for(npix);
+  if (blocks > JAC_BLOCKS) blocks = JAC_BLOCKS;
+  double* sums = (double*)workspace;
+  float* part = (float*)((char*)workspace + 2 * MAXC * sizeof(double));
+  ProfScope prof(PCUDA_FAM_POINTWISE, 8.0 * npix * c, (hipStream_t)s);
+  hipLaunchKernelGGL(jaccard_partial_kernel, dim3(blocks, c), dim3(256), 0, (hipStream_t)s, probs,
+                     truth_is_u8 ? nullptr : (const float*)truth, truth_is_u8 ? (const uint8_t*)truth : nullptr, c, hw,
+                     npix, part);
+  PCUDA_CHECK_LAUNCH("jaccard_partial_kernel");
+  hipLaunchKernelGGL(jaccard_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, (const float*)part, blocks, c, eps, sums,
+                     loss);
+  PCUDA_CHECK_LAUNCH("jaccard_final_kernel");
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_jaccard_bwd(const void* truth, int truth_is_u8, int n, int c, long long hw, float eps,
+                                 const float* gout, float* dprobs, const void* workspace, pcuda_stream_t s) {
+  if (!truth || !dprobs || !workspace || n <= 0 || c <= 0 || c > MAXC || hw <= 0)
+    PCUDA_FAIL(PCUDA_E_BADARG, "jaccard_bwd: bad arguments");
+  const long long npix = (long long)n * hw;
+  int blocks = grid_for(npix);
+  ProfScope prof(PCUDA_FAM_POINTWISE, 8.0 * npix * c, (hipStream_t)s);
+  hipLaunchKernelGGL(jaccard_bwd_kernel, dim3(blocks, c), dim3(256), 0, (hipStream_t)s,
+                     truth_is_u8 ? nullptr : (const float*)truth, truth_is_u8 ? (const uint8_t*)truth : nullptr, c, hw,
+                     npix, eps, (const double*)workspace, gout, dprobs);
+  PCUDA_CHECK_LAUNCH("jaccard_bwd_kernel");
+  return PCUDA_OK;
+}
+
 extern "C" int pcuda_bce_const_fwd(const float* x, long long numel, float label, float* loss, float* acc,
                                    pcuda_stream_t s) {
   if (!x || !loss || numel <= 0) PCUDA_FAIL(PCUDA_E_BADARG, "bce_const_fwd: bad arguments");

@@ -376,6 +376,65 @@ __global__ __launch_bounds__(256) void unfold_taps_kernel(const float* __restric
   }
 }
 
+// bilinear resize with align_corners=True (nn.UpsamplingBilinear2d, GAN.py:57,78): ATen's upsample_bilinear2d
+// arithmetic -- src = dst * (in - 1) / (out - 1); i0 = (int)src; i1 = i0 + (i0 < in - 1); l1 = src - i0; l0 = 1 - l1
+__device__ __forceinline__ void bil_src(int o, float scale, int in, int& i0, int& i1, float& l0, float& l1) {
+  const float src = scale * (float)o;
+  i0 = (int)src;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restrict__ x, long long x_sn, long long x_sc,
+                                                           int h, int w, float* __restrict__ y, int oh, int ow,
+                                                           float sy, float sx) {
+  const int ch = blockIdx.y, n = blockIdx.z;
+  const float* px = x + n * x_sn + ch * x_sc;
+  float* py = y + ((long long)n * gridDim.y + ch) * oh * ow;
+  const int total = oh * ow;
+  for (int o = blockIdx.x * PCH + threadIdx.x; o < min(total, (int)(blockIdx.x + 1) * PCH); o += 256) {
+    const int oy = o / ow, ox = o - oy * ow;
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    bil_src(oy, sy, h, y0, y1, ly0, ly1);
+    bil_src(ox, sx, w, x0, x1, lx0, lx1);
+    py[o] = ly0 * (lx0 * px[(long long)y0 * w + x0] + lx1 * px[(long long)y0 * w + x1]) +
+            ly1 * (lx0 * px[(long long)y1 * w + x0] + lx1 * px[(long long)y1 * w + x1]);
+  }
+}
+// gather form of the backward pass (deterministic, no atomics): input pixel (iy, ix) collects every output pixel whose
+// (y0 | y1, x0 | x1) names it; candidates come from a conservative window around iy / scale
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dy, int oh, int ow,
+                                                           float* __restrict__ dx, long long dx_sn, long long dx_sc,
+                                                           int h, int w, float sy, float sx) {
+  const int ch = blockIdx.y, n = blockIdx.z;
+  const float* pd = dy + ((long long)n * gridDim.y + ch) * oh * ow;
+  float* px = dx + n * dx_sn + ch * dx_sc;
+  const int total = h * w;
+  const float isy = sy > 0.f ? 1.f / sy : 0.f, isx = sx > 0.f ? 1.f / sx : 0.f;
+  for (int o = blockIdx.x * PCH + threadIdx.x; o < min(total, (int)(blockIdx.x + 1) * PCH); o += 256) {
+    const int iy = o / w, ix = o - iy * w;
+    const int oy_lo = sy > 0.f ? max(0, (int)((iy - 1) * isy) - 1) : 0, oy_hi = sy > 0.f ? min(oh - 1, (int)((iy + 1) * isy) + 1) : oh - 1;
+    const int ox_lo = sx > 0.f ? max(0, (int)((ix - 1) * isx) - 1) : 0, ox_hi = sx > 0.f ? min(ow - 1, (int)((ix + 1) * isx) + 1) : ow - 1;
+    float acc = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1;
+      float ly0, ly1;
+      bil_src(oy, sy, h, y0, y1, ly0, ly1);
+      const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
+      if (wy == 0.f && y0 != iy && y1 != iy) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1;
+        float lx0, lx1;
+        bil_src(ox, sx, w, x0, x1, lx0, lx1);
+        const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
+        acc += wy * wx * pd[(long long)oy * ow + ox];
+      }
+    }
+    px[o] = acc;
+  }
+}
+
 __global__ __launch_bounds__(256) void add4_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                    const float* __restrict__ c, const float* __restrict__ d,
                                                    float* __restrict__ y, long long numel) {
@@ -571,6 +630,30 @@ extern "C" int pcuda_unfold_taps(const float* x, long long x_sn, long long x_sc,
   hipLaunchKernelGGL(unfold_taps_kernel, plane_grid(n, c * k * k, (long long)oh * ow), dim3(256), 0, (hipStream_t)s, x,
                      x_sn, x_sc, h, w, k, stride, pad, dil, u, oh, ow);
   PCUDA_CHECK_LAUNCH("unfold_taps_kernel");
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_bilinear_fwd(const float* x, long long x_sn, long long x_sc, int n, int c, int h, int w, float* y,
+                                  int oh, int ow, pcuda_stream_t s) {
+  if (!x || !y || h < 1 || w < 1 || oh < 1 || ow < 1 || !dims_ok(n, c, (long long)oh * ow))
+    PCUDA_FAIL(PCUDA_E_BADARG, "bilinear_fwd: bad arguments");
+  const float sy = oh > 1 ? (float)(h - 1) / (float)(oh - 1) : 0.f, sx = ow > 1 ? (float)(w - 1) / (float)(ow - 1) : 0.f;
+  ProfScope prof(PCUDA_FAM_POINTWISE, 20.0 * n * c * (double)oh * ow, (hipStream_t)s);
+  hipLaunchKernelGGL(bilinear_fwd_kernel, plane_grid(n, c, (long long)oh * ow), dim3(256), 0, (hipStream_t)s, x, x_sn,
+                     x_sc, h, w, y, oh, ow, sy, sx);
+  PCUDA_CHECK_LAUNCH("bilinear_fwd_kernel");
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_bilinear_bwd(const float* dy, int n, int c, int oh, int ow, float* dx, long long dx_sn,
+                                  long long dx_sc, int h, int w, pcuda_stream_t s) {
+  if (!dy || !dx || h < 1 || w < 1 || oh < 1 || ow < 1 || !dims_ok(n, c, (long long)h * w))
+    PCUDA_FAIL(PCUDA_E_BADARG, "bilinear_bwd: bad arguments");
+  const float sy = oh > 1 ? (float)(h - 1) / (float)(oh - 1) : 0.f, sx = ow > 1 ? (float)(w - 1) / (float)(ow - 1) : 0.f;
+  ProfScope prof(PCUDA_FAM_POINTWISE, 20.0 * n * c * (double)h * w, (hipStream_t)s);
+  hipLaunchKernelGGL(bilinear_bwd_kernel, plane_grid(n, c, (long long)h * w), dim3(256), 0, (hipStream_t)s, dy, oh, ow,
+                     dx, dx_sn, dx_sc, h, w, sy, sx);
+  PCUDA_CHECK_LAUNCH("bilinear_bwd_kernel");
   return PCUDA_OK;
 }
 

@@ -321,6 +321,25 @@ def upsample2_bwd(dy):
     return dx
 
 
+def bilinear_fwd(x, oh, ow):
+    """[n,c,h,w] -> [n,c,oh,ow], align_corners=True (nn.UpsamplingBilinear2d)"""
+    n, c, _, xsn, xsc = _planes(x)
+    h, w = x.shape[2], x.shape[3]
+    y = torch.empty((n, c, oh, ow), dtype=torch.float32, device=x.device)
+    check(L.lib().pcuda_bilinear_fwd(x.data_ptr(), xsn, xsc, n, c, h, w, y.data_ptr(), oh, ow, _stream()), "bilinear_fwd")
+    return y
+
+
+def bilinear_bwd(dy, h, w):
+    _req(dy)
+    dy = dy.contiguous()
+    n, c, oh, ow = dy.shape
+    dx = torch.empty((n, c, h, w), dtype=torch.float32, device=dy.device)
+    check(L.lib().pcuda_bilinear_bwd(dy.data_ptr(), n, c, oh, ow, dx.data_ptr(), dx.stride(0), dx.stride(1), h, w,
+                                     _stream()), "bilinear_bwd")
+    return dx
+
+
 def unfold_taps(x, k, stride, pad, dil=1):
     """[n,c,h,w] -> [n,c*k*k,oh,ow]: every tap of a k x k window as its own channel (zero outside the image)"""
     n, c, _, xsn, xsc = _planes(x)
@@ -406,6 +425,37 @@ def seg_loss_bwd(logits, onehot, mode, ws, g_main=None, g_jac=None):
     check(L.lib().pcuda_seg_loss_bwd(logits.data_ptr(), onehot.data_ptr(), _mode(mode), n, c, hw, _ptr(g_main),
                                      _ptr(g_jac), d.data_ptr(), ws.data_ptr(), _stream()), "seg_loss_bwd")
     return d
+
+
+def jaccard_fwd(probs, truth, eps):
+    """probs fp32 [n,c,...]; truth one-hot, fp32 or uint8, same shape -> (loss scalar, workspace)"""
+    _req(probs)
+    if truth.dtype not in (torch.float32, torch.uint8):
+        raise TypeError("jaccard: `true` must be a float32 or uint8 one-hot tensor")
+    _req(truth, truth.dtype)
+    if truth.shape != probs.shape:
+        raise ValueError("jaccard: `true` %r and probabilities %r differ in shape" % (tuple(truth.shape), tuple(probs.shape)))
+    probs, truth = probs.contiguous(), truth.contiguous()
+    n, c = probs.shape[:2]
+    hw = probs.numel() // (n * c)
+    lib = L.lib()
+    nb = lib.pcuda_jaccard_workspace_size(c)
+    ws = torch.empty(nb, dtype=torch.uint8, device=probs.device)
+    loss = torch.empty((), dtype=torch.float32, device=probs.device)
+    check(lib.pcuda_jaccard_fwd(probs.data_ptr(), truth.data_ptr(), 1 if truth.dtype == torch.uint8 else 0, n, c, hw,
+                                float(eps), loss.data_ptr(), ws.data_ptr(), nb, _stream()), "jaccard_fwd")
+    return loss, ws, truth
+
+
+def jaccard_bwd(truth, shape, eps, ws, gout):
+    n, c = shape[:2]
+    hw = 1
+    for d in shape[2:]:
+        hw *= d
+    dp = torch.empty(shape, dtype=torch.float32, device=truth.device)
+    check(L.lib().pcuda_jaccard_bwd(truth.data_ptr(), 1 if truth.dtype == torch.uint8 else 0, n, c, hw, float(eps),
+                                    _ptr(gout), dp.data_ptr(), ws.data_ptr(), _stream()), "jaccard_bwd")
+    return dp
 
 
 def bce_const_fwd(x, label, want_acc=False):

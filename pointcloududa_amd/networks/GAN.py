@@ -16,36 +16,38 @@ from torch import nn
 
 from .. import kernels as K
 from ..kernels import ConvOp
-from ._holders import Conv2d, LeakyReLU, Linear, ensure_grad
+from ._holders import Conv2d, LeakyReLU, Linear, Marker, ensure_grad
 
 
 class _ConvChainFn(torch.autograd.Function):
-    """x -> [conv -> LeakyReLU(slope)]* -> conv   over a list of bias-free Conv2d holders"""
+    """x -> [conv (+bias) -> LeakyReLU(slope)]* -> conv (+bias)   over a list of Conv2d / Linear holders.
+    ``wb``: the chain's weights followed by its biases (None where a layer has none)."""
 
     @staticmethod
-    def forward(ctx, module, x, *weights):
+    def forward(ctx, module, x, *wb):
         if not x.is_cuda:
             raise RuntimeError("discriminators run on HIP devices only (no CPU fallback)")
         x = x.contiguous().float()
+        nl = len(module._chain)
+        weights, biases = wb[:nl], wb[nl:]
         acts, sizes = [x], []
         h, w = x.shape[2], x.shape[3]
         cur = x
-        nl = len(module._chain)
         for li, (name, op) in enumerate(module._chain):
             slope = module._slope if li < nl - 1 else 1.0
             sizes.append((h, w))
+            wt = weights[li].view(op.cout, op.cin, op.k, op.k)
             if li == 0 and module._fold1 is not None:
                 # a handful of input channels: unfold the taps into channels and run the layer as a 1x1 convolution
                 # whose 32-deep reduction chunks are full (16 taps x 4 of 32 channels otherwise)
                 unfolded = K.unfold_taps(cur, op.k, op.stride, op.pad, op.dil)
                 oh, ow = op.out_hw(h, w)
-                wt = weights[0]
-                cur, _, _ = module._fold1.forward(unfolded, wt.view(wt.shape[0], -1, 1, 1), None, slope, oh, ow)
+                cur, _, _ = module._fold1.forward(unfolded, wt.view(wt.shape[0], -1, 1, 1), biases[0], slope, oh, ow)
             else:
-                cur, _, _ = op.forward(cur, weights[li], None, slope, h, w)
+                cur, _, _ = op.forward(cur, wt, biases[li], slope, h, w)
             h, w = op.out_hw(h, w)
             acts.append(cur)
-        ctx.module, ctx.acts, ctx.sizes, ctx.weights = module, acts, sizes, weights
+        ctx.module, ctx.acts, ctx.sizes, ctx.weights, ctx.biases = module, acts, sizes, weights, biases
         if getattr(module, "_keep_acts", False):      # tests (shared-routing backward checks)
             module._last_acts = list(acts)
         ctx.set_materialize_grads(False)
@@ -56,18 +58,19 @@ class _ConvChainFn(torch.autograd.Function):
         nin = len(ctx.needs_input_grad)
         if d_out is None:
             return (None,) * nin
-        module, acts, sizes, weights = ctx.module, ctx.acts, ctx.sizes, ctx.weights
+        module, acts, sizes, weights, biases = ctx.module, ctx.acts, ctx.sizes, ctx.weights, ctx.biases
         nl = len(module._chain)
         dz = d_out.contiguous()
         dx = None
         for li in reversed(range(nl)):
             name, op = module._chain[li]
             h, w = sizes[li]
-            wt = weights[li]
+            wt = weights[li].view(op.cout, op.cin, op.k, op.k)
             if ctx.needs_input_grad[2 + li]:
                 # (the first layer's weight gradient stays on the k x k kernel: the one-tap form of the weight-gradient
                 # kernel stages a tile per tap and measured 0.40 ms against 0.25 ms for this layer)
-                op.wgrad(acts[li], dz, ensure_grad(wt), None, h, w)
+                db = ensure_grad(biases[li]) if (biases[li] is not None and ctx.needs_input_grad[2 + nl + li]) else None
+                op.wgrad(acts[li], dz, ensure_grad(weights[li]).view(op.cout, op.cin, op.k, op.k), db, h, w)
             if li > 0:
                 d_a = op.dgrad(dz, wt, h, w)
                 dz = K.lrelu_bwd(d_a, acts[li], module._slope)
@@ -84,15 +87,19 @@ class _ConvChain(nn.Module):
         chain = []
         for n in names:
             m = getattr(self, n)
-            op = ConvOp(m.in_channels, m.out_channels, m.kernel_size[0], stride=m.stride[0], pad=m.padding[0],
-                        dil=m.dilation[0])
+            if isinstance(m, nn.Linear):        # a fully connected layer = a 1x1 convolution over a 1x1 image
+                op = ConvOp(m.in_features, m.out_features, 1)
+            else:
+                op = ConvOp(m.in_channels, m.out_channels, m.kernel_size[0], stride=m.stride[0], pad=m.padding[0],
+                            dil=m.dilation[0])
             op.owner = self
             chain.append((n, op))
         self._chain = chain
         # first layer over <= 8 input channels (4 / 5 class maps, 1- or 3-channel boundary maps): tap-unfolded 1x1 form
         m0 = getattr(self, names[0])
         self._fold1 = None
-        if m0.in_channels <= 8 and m0.kernel_size[0] > 1 and os.environ.get("PCUDA_NOFOLD", "0") != "1":
+        if (isinstance(m0, nn.Conv2d) and m0.in_channels <= 8 and m0.kernel_size[0] > 1
+                and os.environ.get("PCUDA_NOFOLD", "0") != "1"):
             self._fold1 = ConvOp(m0.in_channels * m0.kernel_size[0] ** 2, m0.out_channels, 1)
             self._fold1.owner = self
             self._fold1.pack_dgrad_with_fwd = False      # the input gradient stays with the k x k operator
@@ -107,7 +114,8 @@ class _ConvChain(nn.Module):
 
     def forward(self, x):
         ws = [getattr(self, n).weight for n, _ in self._chain]
-        return _ConvChainFn.apply(self, x, *ws)
+        bs = [getattr(self, n).bias for n, _ in self._chain]
+        return _ConvChainFn.apply(self, x, *(ws + bs))
 
 
 class UncertaintyDiscriminator(_ConvChain):
@@ -154,18 +162,49 @@ class BoundaryEntDiscriminator(BoundaryDiscriminator):
     _in = 3
 
 
-class OutputDiscriminator(nn.Module):
-    """GAN.py:52-86.  Not instantiated by the reference's train scripts (d1 is an
-    UncertaintyDiscriminator there); it needs a bilinear resize to 224x224 that has no HIP kernel yet."""
+class _BilinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, oh, ow):
+        if not x.is_cuda:
+            raise RuntimeError("discriminators run on HIP devices only (no CPU fallback)")
+        x = x.float()
+        ctx.hw = (x.shape[2], x.shape[3])
+        return K.bilinear_fwd(x, oh, ow)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return K.bilinear_bwd(dy, *ctx.hw), None, None
+
+
+class OutputDiscriminator(_ConvChain):
+    """GAN.py:52-86 (not instantiated by the reference's train scripts, which use UncertaintyDiscriminator for d1):
+    bilinear resize to 224x224 (align_corners=True), optional channel softmax, then the five 4x4 stride-2 layers."""
 
     def __init__(self, in_channel=2, softmax=False, init=False):
         super().__init__()
-        raise NotImplementedError("OutputDiscriminator is unused by train_mscmrseg.py / train_mmwhs.py and is "
-                                  "not built; use UncertaintyDiscriminator (what the scripts use for d1)")
+        self._softmax = softmax
+        f = [64, 128, 256, 512, 1]
+        self.upsample = Marker("UpsamplingBilinear2d(size=(224, 224)): pcuda_bilinear_fwd / _bwd")
+        cin = in_channel
+        for i, co in enumerate(f):
+            setattr(self, "conv%d" % (i + 1), Conv2d(cin, co, kernel_size=4, stride=2, padding=2, bias=False))
+            cin = co
+        self.leakyrelu = LeakyReLU(negative_slope=0.2)
+        if init:
+            self._init_conv()
+        self._build_chain(["conv1", "conv2", "conv3", "conv4", "conv5"])
+
+    def forward(self, x):
+        from ..utils.loss import entropy_map
+        x = _BilinearFn.apply(x, 224, 224)
+        if self._softmax:
+            x = entropy_map(x, "softmax", False, want_prob=True)[1]
+        return super().forward(x)
 
 
-class Discriminator(nn.Module):
-    """GAN.py:7-49: fully connected 24576-4096-2048-1024-1 with LeakyReLU(0.2); unused by the scripts."""
+class Discriminator(_ConvChain):
+    """GAN.py:7-49: fully connected 24576-4096-2048-1024-1 with LeakyReLU(0.2) (unused by the scripts).  Each layer
+    runs as a 1x1 convolution over a 1x1 image on the MFMA kernels (bias and LeakyReLU in the epilogue)."""
 
     def __init__(self):
         super().__init__()
@@ -179,6 +218,9 @@ class Discriminator(nn.Module):
             if isinstance(m, nn.Linear):
                 m.weight.data.normal_(0.0, 0.02)
                 m.bias.data.zero_()
+        self._build_chain(["fc1", "fc2", "fc3", "fc4"])
 
     def forward(self, x):
-        raise NotImplementedError("the fully connected Discriminator is unused by the reference scripts")
+        lead = x.shape[:-1]
+        y = super().forward(x.reshape(-1, x.shape[-1], 1, 1))
+        return y.reshape(*lead, 1)

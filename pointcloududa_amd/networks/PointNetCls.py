@@ -7,8 +7,9 @@ the BatchNorm1d partial statistics taken from the convolution epilogue; Linear l
 is one autograd node with a recorded tape of backward steps; parameter gradients are accumulated
 into ``param.grad`` directly.
 
-Batch size 1 takes the reference down an InstanceNorm path (PointNetCls.py:47-55, 210-212); that
-path is not built: per-rank batches must be >= 2, as SURVEY section 7 notes for data parallelism.
+Batch size 1 takes the reference down an InstanceNorm path (PointNetCls.py:47-55, 210-212) that raises inside
+the reference itself (InstanceNorm1d on the 2-D output of fc1): the same RuntimeError is raised here, and per-rank
+batches must be >= 2, as SURVEY section 7 notes for data parallelism.
 """
 from __future__ import annotations
 
@@ -186,10 +187,17 @@ class _Tape:
 class _PointNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, x, drop_mask, *params):
+        if x.shape[0] < 2:
+            # The reference's batch-1 branch (PointNetCls.py:47-55) hands the 2-D [1, 512] output of fc1 to
+            # InstanceNorm1d(512): torch 1.4 (the reference's version) raises "InstanceNorm1d returns 0-filled tensor
+            # to 2D tensor", current torch raises "running_mean should contain 1 elements not 512" -- the branch cannot
+            # execute in the reference either (pinned in tests/golden/param_counts.npz: pncls_batch1_raises).  Same
+            # error behaviour here: a RuntimeError naming the layer.
+            raise RuntimeError("PointNetCls: batch size 1 takes the reference's InstanceNorm1d branch, which fails in "
+                               "the reference too (feat.stn.in4 on a 2-D [1, 512] tensor: running_mean should contain "
+                               "1 elements not 512); use a per-rank batch of at least 2")
         if not x.is_cuda:
             raise RuntimeError("PointNetCls runs on HIP devices only (no CPU fallback)")
-        if x.shape[0] < 2:
-            raise NotImplementedError("batch size 1 (InstanceNorm path, PointNetCls.py:47-55) is not built")
         tape = _Tape(module, module.training)
         xin = _Var(x.contiguous().float())
         y, trans, trans_feat = module._run(tape, xin, drop_mask)

@@ -27,10 +27,11 @@ SLOPE = 0.01   # nn.LeakyReLU() default used throughout unet.py
 class _SegEngine:
     """forward / hand-written backward of Segmentation_model_Point over a name->tensor dict"""
 
-    def __init__(self, filters, in_channels, n_block, depth, n_class, pointnet, fc_inch):
+    def __init__(self, filters, in_channels, n_block, depth, n_class, pointnet, fc_inch, extpn=False):
         f = filters
         self.f, self.cin, self.nb, self.depth, self.ncls, self.pointnet, self.fc_inch = \
             f, in_channels, n_block, depth, n_class, pointnet, fc_inch
+        self.extpn = bool(extpn and pointnet)
         self.after_deep_grads = None      # optional hook of the backward pass (see ``backward``)
         ops = {}
         for i in range(n_block):
@@ -47,7 +48,11 @@ class _SegEngine:
             ops["bottleneck.bottleneck%d.0" % (j + 1)] = ConvOp(ci, co, 3, pad=d, dil=d)
             ci = co
         if pointnet:
-            ops["pointNet.final_conv"] = ConvOp(512 * f // 32, 300, 6)
+            ch = 512 * f // 32
+            if self.extpn:                                            # unet.py:81-83
+                ops["pointNet.conv1"] = ConvOp(ch, 2 * ch, 3, pad=1)
+                ops["pointNet.conv2"] = ConvOp(2 * ch, ch, 3, pad=1)
+            ops["pointNet.final_conv"] = ConvOp(ch, 300, 6)
         for i in range(n_block):
             co = f * 2 ** i
             ops["decoder.decoder1_%d.1" % (i + 1)] = ConvOp(2 * co, co, 3, pad=1, in_up=True)
@@ -140,13 +145,20 @@ class _SegEngine:
         S["bott_outs"] = outs
         verts = None
         if self.pointnet:                                             # unet.py:89-96
-            hc, _, _ = self.ops["pointNet.final_conv"].forward(bsum, P["pointNet.final_conv.weight"],
+            hin, ext_acts = bsum, []
+            if self.extpn:                                            # :90-92: two 3x3 convs + LeakyReLU in front
+                for nm in ("pointNet.conv1", "pointNet.conv2"):
+                    o, _, _ = self.ops[nm].forward(hin, P[nm + ".weight"], P[nm + ".bias"], SLOPE, h, w)
+                    ext_acts.append((nm, hin, o))
+                    hin = o
+            S["head_ext"] = ext_acts
+            hc, _, _ = self.ops["pointNet.final_conv"].forward(hin, P["pointNet.final_conv.weight"],
                                                                P["pointNet.final_conv.bias"], SLOPE, h, w)
             flat = hc.view(n * 300, -1)
             if flat.shape[1] != self.fc_inch:
                 raise ValueError("fc_inch=%d does not match the %dx%d head output" % (self.fc_inch, h - 5, w - 5))
             verts = K.linear_fwd(flat, P["pointNet.final_fc.weight"], P["pointNet.final_fc.bias"]).view(n, 300, 3)
-            S["head"] = (bsum, hc, flat)
+            S["head"] = (hin, hc, flat)
         prev, ph, pw = bsum, h, w
         for i in reversed(range(nb)):                                 # unet.py:128-136
             up = "decoder.decoder1_%d.1" % (i + 1)
@@ -188,19 +200,25 @@ class _SegEngine:
             d_bsum = d_cur
         h, w = H >> nb, W >> nb
         if self.pointnet and d_verts is not None:
-            bsum, hc, flat = S["head"]
+            hin, hc, flat = S["head"]
             d_v = d_verts.contiguous().view(n * 300, 3)
             if G("pointNet.final_fc.weight") is not None:
                 K.linear_bwd_w(d_v, flat, G("pointNet.final_fc.weight"), G("pointNet.final_fc.bias"))
             d_hc = K.linear_bwd_x(d_v, P["pointNet.final_fc.weight"]).view(hc.shape)
             dzc = K.lrelu_bwd(d_hc, hc, SLOPE)
-            op = self.ops["pointNet.final_conv"]
+            op, op_name = self.ops["pointNet.final_conv"], "pointNet.final_conv"
             if G("pointNet.final_conv.weight") is not None:
-                op.wgrad(bsum, dzc, G("pointNet.final_conv.weight"), G("pointNet.final_conv.bias"), h, w)
+                op.wgrad(hin, dzc, G("pointNet.final_conv.weight"), G("pointNet.final_conv.bias"), h, w)
+            for nm, xin, o in reversed(S["head_ext"]):                # extpn: back through conv2, conv1
+                d_o = op.dgrad(dzc, P[op_name + ".weight"], h, w)
+                dzc = K.lrelu_bwd(d_o, o, SLOPE)
+                op, op_name = self.ops[nm], nm
+                if G(nm + ".weight") is not None:
+                    op.wgrad(xin, dzc, G(nm + ".weight"), G(nm + ".bias"), h, w)
             if d_bsum is None:
-                d_bsum = op.dgrad(dzc, P["pointNet.final_conv.weight"], h, w)
+                d_bsum = op.dgrad(dzc, P[op_name + ".weight"], h, w)
             else:
-                op.dgrad(dzc, P["pointNet.final_conv.weight"], h, w, dx=d_bsum, accumulate=True)
+                op.dgrad(dzc, P[op_name + ".weight"], h, w, dx=d_bsum, accumulate=True)
         if d_bsum is None:
             return None
         outs, g_next = S["bott_outs"], None
@@ -295,10 +313,11 @@ class Bottleneck(nn.Module):
 class PointNet(nn.Module):
     def __init__(self, num_points=300, fc_inch=81, conv_inch=512, ext=False):
         super().__init__()
-        if ext:
-            raise NotImplementedError("extpn=True (two extra 3x3 convs in the point head) is not built yet")
         self.num_points = num_points
         self.ReLU = LeakyReLU(inplace=True)
+        if ext:                                                       # unet.py:81-83
+            self.conv1 = Conv2d(conv_inch, conv_inch * 2, kernel_size=3, padding=1)
+            self.conv2 = Conv2d(conv_inch * 2, conv_inch, kernel_size=3, padding=1)
         self.final_conv = Conv2d(conv_inch, self.num_points, kernel_size=6)
         self.final_fc = Linear(fc_inch, 3)
         self._ext = ext
@@ -346,7 +365,7 @@ class Segmentation_model_Point(nn.Module):
         self.classifier = Conv2d(filters, n_class, kernel_size=(1, 1))
         self._initialize_weights(heinit=heinit)
         self._multicuda = False
-        self._engine = _SegEngine(filters, in_channels, n_block, bottleneck_depth, n_class, pointnet, fc_inch)
+        self._engine = _SegEngine(filters, in_channels, n_block, bottleneck_depth, n_class, pointnet, fc_inch, extpn)
         for op in self._engine.ops.values():
             op.owner = self
 

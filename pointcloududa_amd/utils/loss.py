@@ -46,13 +46,39 @@ def seg_loss(logits, onehot_u8, mode="sigmoid"):
     return _SegLossFn.apply(logits, onehot_u8, mode)
 
 
+class _JaccardFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, probs, true, eps):
+        loss, ws, truth = K.jaccard_fwd(probs, true, eps)
+        ctx.truth, ctx.ws, ctx.eps, ctx.shape = truth, ws, eps, tuple(probs.shape)
+        ctx.set_materialize_grads(False)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        if gout is None:
+            return None, None, None
+        return K.jaccard_bwd(ctx.truth, ctx.shape, ctx.eps, ctx.ws, gout.contiguous()), None, None
+
+
 def jaccard_loss(true, logits, eps=1e-7, activation=True):
-    """Reference signature (loss.py:5-37) for the way the scripts call it: C > 1 probabilities in,
-    ``activation=False``; ``true`` one-hot.  Only the fused form is built: the probabilities must come
-    from ``torch.sigmoid``/``softmax`` of logits the caller still has -> use ``seg_loss`` instead."""
-    raise NotImplementedError("jaccard_loss on detached probabilities is not built; use "
-                              "pointcloududa_amd.utils.loss.seg_loss(logits, onehot, mode), which returns "
-                              "(bce|ce, jaccard) fused as the train scripts combine them")
+    """Reference signature and semantics (loss.py:5-37).  ``logits``: [B,C,H,W]; with ``activation=False`` (how
+    train_mscmrseg.py:203 and train_mmwhs.py:218 call it) they already are probabilities, with ``activation=True``
+    they go through a softmax over the channels first; ``true``: one-hot [B,C,H,W] (float or uint8).  Differentiable
+    w.r.t. ``logits`` (through whatever produced them: the result is an ordinary autograd node on the HIP kernels).
+    The reference's C == 1 branch pairs [sigmoid, 1 - sigmoid] with ``true`` BROADCAST over both channels (the
+    one-hot it builds at loss.py:15-19 is overwritten at :27): reproduced as executed.
+    The train step itself uses the fused ``seg_loss`` below (one pass over the logits for both loss terms)."""
+    num_classes = logits.shape[1]
+    if num_classes == 1:
+        pos = entropy_map(logits, "sigmoid", False, want_prob=True)[1]
+        probas = torch.cat([pos, 1 - pos], dim=1)                                     # loss.py:20-22
+        return _JaccardFn.apply(probas, true.float().expand_as(probas).contiguous(), float(eps))   # :27
+    if activation:
+        probas = entropy_map(logits, "softmax", False, want_prob=True)[1]
+    else:
+        probas = logits
+    return _JaccardFn.apply(probas, true, float(eps))
 
 
 class _EntropyFn(torch.autograd.Function):

@@ -44,3 +44,16 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert lib.pcuda_conv2d_wgrad_workspace_size(ctypes.byref(g2)) > 0
     assert lib.pcuda_conv2d_fwd_tiles(ctypes.byref(g2), 0) == 2
     assert lib.pcuda_seg_loss_workspace_size(2, 4, 256) > 0
+
+
+def test_pointnet_cls_batch_of_one_raises_like_the_reference():
+    """The reference's batch-1 branch cannot execute (InstanceNorm1d on the 2-D output of fc1; pinned by
+    make_golden.py in param_counts.npz); the HIP module raises a RuntimeError too, before touching the device"""
+    import numpy as np
+    import torch
+    from conftest import GOLD
+    from pointcloududa_amd.networks import PointNetCls
+    g = np.load(os.path.join(GOLD, "param_counts.npz"))
+    assert int(g["pncls_batch1_raises"]) == 2
+    with pytest.raises(RuntimeError, match="batch size 1"):
+        PointNetCls()(torch.rand(1, 3, 300))

@@ -71,6 +71,7 @@ def _compare_grads(named_hip, grads_ref, tol=TOL):
     (dict(filters=4, in_channels=1, n_class=4, pointnet=True, fc_inch=9), False, 2, 128, 1100),
     (dict(filters=8, in_channels=3, n_class=5, pointnet=False), True, 2, 64, 1110),
     (dict(filters=16, in_channels=1, n_class=4, pointnet=True, fc_inch=9), False, 3, 128, 1120),
+    (dict(filters=4, in_channels=1, n_class=4, pointnet=True, fc_inch=9, extpn=True), False, 2, 128, 1130),
 ])
 def test_segmenter_backward_shared_routing(dev, cfg_kw, softmax, b, hw, seed):
     """encoder blocks + max-pool + dense-skip 1x1 convs, the dilated bottleneck and its running sum, the point head,
@@ -107,6 +108,8 @@ def test_segmenter_backward_shared_routing(dev, cfg_kw, softmax, b, hw, seed):
         table["bottleneck.bottleneck%d.0" % (j + 1)] = _unlrelu(o, 0.01)
     if cfg.pointnet:
         table["pointNet.final_conv"] = _unlrelu(S["head"][1], 0.01)
+        for nm, _, o in S["head_ext"]:
+            table[nm] = _unlrelu(o, 0.01)
         table["pointNet.final_fc"] = verts.detach().float().cpu()
 
     p2 = {k: (v.clone().requires_grad_(True) if ON.is_trainable(k) else v.clone()) for k, v in params.items()}

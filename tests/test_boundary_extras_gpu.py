@@ -1,0 +1,108 @@
+"""The parts of the reference's module surface that its train scripts never reach (SURVEY section 8b lists them in the
+contract): ``jaccard_loss`` with its own signature, ``OutputDiscriminator`` (bilinear resize to 224x224), the fully
+connected ``Discriminator``, the ``extpn`` point head -- each on the HIP kernels against golden vectors produced by
+the REFERENCE (oracle/make_golden.py: gold_losses, gold_unused_discs, gold_seg('seg_small_extpn'))."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(mod, params, dev):
+    mod.load_state_dict({k: v.clone() for k, v in params.items()}, strict=True)
+    return mod.to(dev).train()
+
+
+def test_jaccard_loss_reference_signature(dev):
+    """jaccard_loss(true, logits, eps, activation) (loss.py:5-37): probabilities in (how the scripts call it), softmax
+    inside (activation=True), and the one-channel branch; value 1e-5, gradient 1e-5 of its scale"""
+    from pointcloududa_amd.utils.loss import jaccard_loss
+    g = np.load(os.path.join(GOLD, "losses.npz"))
+    rng = np.random.default_rng(int(g["seed"]))
+    b, c, hw = 2, 4, 32
+    logits = torch.from_numpy(rng.normal(0, 2, (b, c, hw, hw)).astype(np.float32))
+    lab = rng.integers(0, c, (b, hw, hw))
+    onehot = torch.from_numpy(np.moveaxis(np.eye(c, dtype=np.uint8)[lab], -1, 1).copy())
+    # (a) probabilities, activation=False; `true` as float (the scripts) and as uint8 (the loader's dtype)
+    for true in (onehot.float().to(dev), onehot.to(dev)):
+        lo = logits.to(dev).requires_grad_(True)
+        j = jaccard_loss(true, torch.sigmoid(lo), 1e-7, False)      # torch's sigmoid: "whatever produced them"
+        j.backward()
+        assert abs(float(j) - float(g["jacfn_probs"])) < 1e-5
+        # golden gradient is w.r.t. the probabilities' pre-image sigmoid(logits) taken as a leaf: chain by hand
+        p = torch.sigmoid(logits)
+        assert rel_err(lo.grad, torch.from_numpy(g["jacfn_probs_grad"]) * p * (1 - p)) < 1e-5
+    # (b) activation=True: softmax inside
+    lo = logits.to(dev).requires_grad_(True)
+    j = jaccard_loss(onehot.float().to(dev), lo, 1e-7, True)
+    j.backward()
+    assert abs(float(j) - float(g["jacfn_softmax"])) < 1e-5 and rel_err(lo.grad, g["jacfn_softmax_grad"]) < 1e-5
+    # (c) one channel
+    lo = logits[:, :1].to(dev).contiguous().requires_grad_(True)
+    true = torch.from_numpy((lab > 1).astype(np.int64))[:, None].to(dev)
+    j = jaccard_loss(true, lo, 1e-7, True)
+    j.backward()
+    assert abs(float(j) - float(g["jacfn_c1"])) < 1e-5 and rel_err(lo.grad, g["jacfn_c1_grad"]) < 1e-5
+
+
+@pytest.mark.parametrize("tag,softmax", [("out", False), ("out_sm", True)])
+def test_output_discriminator_vs_reference_golden(dev, tag, softmax):
+    from oracle import nets as ON
+    from pointcloududa_amd.networks.GAN import OutputDiscriminator
+    from pointcloududa_amd.utils import loss as L
+    g = np.load(os.path.join(GOLD, "unused_discs.npz"))
+    params = ON.make_params(ON.disc_param_shapes(4, False), int(g["seed"]), std=0.02)
+    model = _load(OutputDiscriminator(in_channel=4, softmax=softmax), params, dev)
+    x = torch.from_numpy(g[tag + "/x"]).to(dev).requires_grad_(True)
+    d = model(x)
+    L.bce_logits_const(d, 0.0).backward()
+    assert rel_err(d, g[tag + "/y"]) < 1e-3
+    assert rel_err(x.grad, g[tag + "/dx"]) < 1e-2
+    for k, p in model.named_parameters():
+        ref = float(g["%s/gnorm/%s" % (tag, k)])
+        assert abs(float(p.grad.double().norm()) - ref) <= 1e-2 * ref, k
+
+
+def test_bilinear_resize_kernels_vs_torch(dev):
+    """pcuda_bilinear_fwd / _bwd against F.interpolate(align_corners=True) on the CPU: down- and up-sampling, odd sizes"""
+    import torch.nn.functional as F
+    from pointcloududa_amd import kernels as K
+    rng = np.random.default_rng(3)
+    for (h, w, oh, ow) in ((256, 256, 224, 224), (33, 47, 224, 224), (7, 5, 1, 9), (1, 1, 4, 4), (300, 20, 224, 224)):
+        x = torch.from_numpy(rng.normal(0, 1, (2, 3, h, w)).astype(np.float32)).requires_grad_(True)
+        y = F.interpolate(x, size=(oh, ow), mode="bilinear", align_corners=True)
+        gy = torch.from_numpy(rng.normal(0, 1, y.shape).astype(np.float32))
+        y.backward(gy)
+        yh = K.bilinear_fwd(x.detach().to(dev), oh, ow)
+        dxh = K.bilinear_bwd(gy.to(dev), h, w)
+        assert rel_err(yh, y) < 1e-6, (h, w, oh, ow)
+        assert rel_err(dxh, x.grad) < 1e-5, (h, w, oh, ow)
+
+
+def test_fc_discriminator_vs_reference_golden(dev):
+    from oracle import nets as ON
+    from pointcloududa_amd.networks.GAN import Discriminator
+    from pointcloududa_amd.utils import loss as L
+    from test_networks_gpu import _strided
+    g = np.load(os.path.join(GOLD, "unused_discs.npz"))
+    seed = int(g["seed"])
+    params = ON.make_params(ON.fc_disc_param_shapes(), seed + 5, std=0.02)
+    model = _load(Discriminator(), params, dev)
+    rng = np.random.default_rng(seed + 1)
+    for _ in range(2):                                     # replay the draws gold_unused_discs made before this one
+        rng.normal(0, 1, (2, 4, 96, 80))
+    x = torch.from_numpy(rng.normal(0, 1, (3, 24576)).astype(np.float32)).to(dev).requires_grad_(True)
+    d = model(x)
+    assert tuple(d.shape) == (3, 1)
+    L.bce_logits_const(d, 1.0).backward()
+    assert rel_err(d, g["fc/y"]) < 1e-3
+    assert rel_err(_strided(x.grad, 1024), g["fc/dx_s"]) < 1e-2
+    for k, p in model.named_parameters():
+        ref = float(g["fc/gnorm/" + k])
+        assert abs(float(p.grad.double().norm()) - ref) <= 1e-2 * ref, k
+        assert rel_err(_strided(p.grad, 256), g["fc/gs/" + k]) < 2e-2, k

@@ -117,9 +117,10 @@ def _check_updates(tr, g, pre):
         ok = np.abs(u_got - u_ref) <= 0.1                       # same sign AND a full-size step on both sides
         n_conf += int(conf.sum()); n_conf_ok += int((conf & ok).sum())
         n_all += int(some.sum()); n_all_ok += int((some & ok).sum())
-        # sum of the parameter: at most 15 % of the elements may have stepped the other way (2 * lr each)
+        # sum of the parameter: at most 15 % of the elements (+ 3: tensors of 4 elements) may have stepped the other
+        # way (2 * lr each)
         ps_ref, ps_got = float(g[pre + "psum/gen/" + k]), float(v.double().sum())
-        assert abs(ps_got - ps_ref) <= 0.15 * v.numel() * 2 * lr + 1e-5 * abs(ps_ref), (k, ps_got, ps_ref)
+        assert abs(ps_got - ps_ref) <= (0.15 * v.numel() + 3) * 2 * lr + 1e-5 * abs(ps_ref), (k, ps_got, ps_ref)
     assert n_conf >= 500, n_conf                                 # not vacuous
     assert n_conf_ok >= 0.98 * n_conf, (n_conf_ok, n_conf)
     assert n_all_ok >= 0.90 * n_all, (n_all_ok, n_all)
