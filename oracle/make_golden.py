@@ -491,13 +491,19 @@ def ref_step_mscmrseg(gen, d1, d2, d4, opt_g, opt1, opt2, opt4, batch, dr, wp):
     return res
 
 
-def post_step_samples(out, prefix, nets, grads, params0):
+def post_step_samples(out, prefix, nets, grads, opts):
     """strided samples of every float state entry after the optimiser steps (``ps/``), of the gradient each
-    optimiser consumed (``gs/``), and the parameter sums (``psum/``) -- what tests/test_step_gpu.py checks the
-    update direction and size against"""
+    optimiser consumed (``gs/``), of the discriminators' SGD momentum buffers (``mb/``: after the first step they
+    hold g + wd * p, the update direction at full precision -- the parameters themselves move by about one fp32 ulp)
+    and the parameter sums (``psum/``) -- what tests/test_step_gpu.py checks the update direction and size against"""
     for nm, m in nets:
         if m is None:
             continue
+        if opts.get(nm) is not None:
+            for k, p in m.named_parameters():
+                st = opts[nm].state.get(p, {})
+                if st.get("momentum_buffer") is not None:
+                    out["%smb/%s/%s" % (prefix, nm, k)] = sample(st["momentum_buffer"], 256)
         for k, v in m.state_dict().items():
             if not v.dtype.is_floating_point:
                 continue
@@ -573,7 +579,7 @@ def gold_step(tag, cfg: ON.SegCfg, b, hw, seed, n_steps=2, full=True, d1=True, d
                     out["s%d/pabs/%s/%s" % (it, nm, k)] = np.float64(v.double().abs().sum().item())
         post_step_samples(out, "s%d/" % it, (("gen", gen), ("d1", d1), ("d2", d2), ("d4", d4)),
                           {"gen": r["grad_total"], "d1": r.get("grad_d1", {}), "d2": r.get("grad_d2", {}),
-                           "d4": r.get("grad_d4", {})}, None)
+                           "d4": r.get("grad_d4", {})}, {"d1": o1, "d2": o2, "d4": o4})
     np.savez_compressed(os.path.join(GOLD, tag + ".npz"), **out)
     print(tag, "ok")
 
@@ -710,7 +716,7 @@ def gold_step_mmwhs(tag, cfg: ON.SegCfg, b, hw, seed, d1=True, d2=True, d4=True)
                     close(pd[k], v, 2.5e-3, "%s param %s.%s" % (tag, nm, k))
     post_step_samples(out, "", (("gen", gen), ("d1", d1), ("d2", d2), ("d4", d4)),
                       {"gen": r["grad_total"], "d1": r.get("grad_d1", {}), "d2": r.get("grad_d2", {}),
-                       "d4": r.get("grad_d4", {})}, None)
+                       "d4": r.get("grad_d4", {})}, {"d1": o1, "d2": o2, "d4": o4})
     np.savez_compressed(os.path.join(GOLD, tag + ".npz"), **out)
     print(tag, "ok", {k: round(float(out[k]), 5) for k in ("seg_loss", "adv_loss")})
 

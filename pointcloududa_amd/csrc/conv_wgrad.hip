@@ -74,6 +74,12 @@ WgradPlan plan_wgrad(const pcuda_conv_geom* g) {
       if (th < 1) continue;
       const int span = (g->k - 1) * g->dil;
       const long long halo = (long long)((th - 1) * g->stride + span + 1) * ((tw - 1) * g->stride + span + 1);
+      {   // the staged input tile (clipped to the image where that halves it) + the dZ rows must fit LDS in bf16x3
+        const long long ih = (th - 1) * g->stride + span + 1, iw = (tw - 1) * g->stride + span + 1;
+        const long long clipped = (ih < g->in_h ? ih : g->in_h) * (iw < g->in_w ? iw : g->in_w) + 1;
+        const long long cap = halo < clipped ? halo : clipped;
+        if (cap * IG_REC_BYTES * 2 + (long long)w.co_tile * WG_ZROW * 2 > (long long)LDS_HARD) continue;
+      }
       const long long key = ((long long)cdiv(g->out_w, tw) * cdiv(g->out_h, th) << 24) + ((tw & 31) ? (1ll << 20) : 0) + halo;
       if (best_key < 0 || key < best_key) { best_key = key; w.tw = tw; w.th = th; }
     }

@@ -125,28 +125,41 @@ def _check_updates(tr, g, pre):
     assert n_conf_ok >= 0.98 * n_conf, (n_conf_ok, n_conf)
     assert n_all_ok >= 0.90 * n_all, (n_all_ok, n_all)
     rates = {"adam_conf": n_conf_ok / n_conf, "adam_all": n_all_ok / max(n_all, 1)}
-    for nm, mod, opt, tol in (("d1", tr.dis1, tr.opt_d1, 2e-2), ("d2", tr.dis2, tr.opt_d2, 2e-2), ("d4", tr.dis4, tr.opt_d4, 0.3)):
+    # SGD with momentum, first step: buf = g + wd * p0 and p1 = p0 - lr * buf.  lr * buf is about ONE fp32 ulp of a
+    # discriminator weight, so the direction is read from the momentum buffer (full precision) and the parameters
+    # are only required to have moved by that much (+- 1 ulp).  d1 / d2: elementwise 2e-2.  d4 sits behind
+    # BatchNorm1d over the batch of 4-8 (see _check_losses): its buffer is held to 0.35 in norm per tensor and to a
+    # cosine of 0.9 with the reference's over all sampled elements.
+    for nm, mod, opt in (("d1", tr.dis1, tr.opt_d1), ("d2", tr.dis2, tr.opt_d2), ("d4", tr.dis4, tr.opt_d4)):
         if mod is None:
             continue
-        worst = 0.0
-        for k, v in mod.state_dict().items():
+        worst, dot, n_got, n_ref = 0.0, 0.0, 0.0, 0.0
+        for (k, v), (off, n, shp) in zip(mod.named_parameters(), opt._slices()):
+            key = pre + "mb/%s/%s" % (nm, k)
+            assert key in g, key
+            got, ref = _sample(opt.buf[off:off + n]), g[key].astype(np.float64)
+            scale = max(np.abs(ref).max(), 1e-30)
+            if nm == "d4":
+                dot += float(got @ ref); n_got += float(got @ got); n_ref += float(ref @ ref)
+            else:
+                e = np.abs(got - ref).max() / scale
+                assert e <= 2e-2, (nm, k, e)
+                worst = max(worst, e)
+            p0, p1, p1_ref = _sample(tr._p0[nm][k]), _sample(v), g[pre + "ps/%s/%s" % (nm, k)].astype(np.float64)
+            ulp = np.spacing(np.abs(p0).astype(np.float32)).astype(np.float64)
+            assert np.all(np.abs((p1 - p0) + opt.lr * got) <= 1.01 * ulp), (nm, k)          # moved by lr * buf
+            assert np.all(np.abs(p1 - p1_ref) <= opt.lr * np.abs(got - ref) + 2.01 * ulp), (nm, k)
+        if nm == "d4":
+            cos = dot / max((n_got * n_ref) ** 0.5, 1e-30)
+            assert cos >= 0.9 and abs(n_got ** 0.5 - n_ref ** 0.5) <= 0.35 * n_ref ** 0.5, (cos, n_got, n_ref)
+            rates["sgd_d4_cos"] = cos
+        else:
+            rates["sgd_" + nm] = worst
+        for k, v in mod.state_dict().items():               # BatchNorm running statistics
             key = pre + "ps/%s/%s" % (nm, k)
-            if key not in g or not v.dtype.is_floating_point or ".in" in k or k.startswith("in"):
-                continue
-            got, ref = _sample(v), g[key].astype(np.float64)
-            if not ON.is_trainable(k):
-                lim = 1e-3 if nm != "d4" else 5e-2
-                assert np.abs(got - ref).max() <= lim * max(np.abs(ref).max(), 1e-3), (nm, k)
-                continue
-            p0 = _sample(tr._p0[nm][k])
-            u_got, u_ref = (got - p0) / opt.lr, (ref - p0) / opt.lr
-            floor = 4e-9 / opt.lr * max(np.abs(p0).max(), 1e-3) / 0.02       # one fp32 ulp of the parameter, in update units
-            e = np.abs(u_got - u_ref).max() / max(np.abs(u_ref).max(), 1e-30)
-            assert np.abs(u_got - u_ref).max() <= tol * np.abs(u_ref).max() + floor, (nm, k, e)
-            worst = max(worst, e)
-            ps_ref, ps_got = float(g[pre + "psum/%s/%s" % (nm, k)]), float(v.double().sum())
-            assert abs(ps_got - ps_ref) <= opt.lr * tol * float(np.abs(u_ref).mean()) * v.numel() + v.numel() * floor * opt.lr, (nm, k)
-        rates["sgd_" + nm] = worst
+            if key in g and v.dtype.is_floating_point and not ON.is_trainable(k) and ".in" not in k and not k.startswith("in"):
+                got, ref = _sample(v), g[key].astype(np.float64)
+                assert np.abs(got - ref).max() <= 5e-2 * max(np.abs(ref).max(), 1e-3), (nm, k)
     return rates
 
 
