@@ -62,10 +62,39 @@ def test_output_discriminator_vs_reference_golden(dev, tag, softmax):
     d = model(x)
     L.bce_logits_const(d, 0.0).backward()
     assert rel_err(d, g[tag + "/y"]) < 1e-3
-    assert rel_err(x.grad, g[tag + "/dx"]) < 1e-2
+    # independent forward passes: LeakyReLU routing flips on the 113^2 ... 8^2 maps limit the input gradient to a few
+    # percent of its largest entry (observed 3.5e-2 / 4.7e-2); with the routing shared it is 1e-4 (next test)
+    assert rel_err(x.grad, g[tag + "/dx"]) < 1e-1
     for k, p in model.named_parameters():
         ref = float(g["%s/gnorm/%s" % (tag, k)])
         assert abs(float(p.grad.double().norm()) - ref) <= 1e-2 * ref, k
+
+
+@pytest.mark.parametrize("softmax", [False, True])
+def test_output_discriminator_backward_shared_routing(dev, softmax):
+    """bilinear-resize backward + [softmax backward] + the conv chain, anchored to the HIP forward pass: 1e-4"""
+    from oracle import losses as OL
+    from oracle import nets as ON
+    from pointcloududa_amd.networks.GAN import OutputDiscriminator
+    from pointcloududa_amd.utils import loss as L
+    from test_backward_exact_gpu import _anchor_from, _compare_grads, _unlrelu
+    params = ON.make_params(ON.disc_param_shapes(4, False), 1400, std=0.02)
+    model = _load(OutputDiscriminator(in_channel=4, softmax=softmax), params, dev)
+    model._keep_acts = True
+    xn = np.random.default_rng(1401).normal(0, 1, (2, 4, 70, 100)).astype(np.float32)
+    x = torch.from_numpy(xn).to(dev).requires_grad_(True)
+    L.bce_logits_const(model(x), 1.0).backward()
+    names = [n for n, _ in model._chain]
+    table = {n: _unlrelu(model._last_acts[i + 1], 0.2 if i < len(names) - 1 else 1.0) for i, n in enumerate(names)}
+    p2 = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    xo = torch.from_numpy(xn).requires_grad_(True)
+    used = set()
+    with ON.anchored(_anchor_from(table, used)):
+        d2 = ON.output_disc_forward(p2, xo, softmax)
+    assert used == set(table)
+    OL.bce_logits_const(d2, 1.0).backward()
+    _compare_grads(model.named_parameters(), {k: v.grad for k, v in p2.items()})
+    assert rel_err(x.grad, xo.grad) < 1e-4
 
 
 def test_bilinear_resize_kernels_vs_torch(dev):

@@ -127,7 +127,9 @@ def _check_updates(tr, g, pre):
     rates = {"adam_conf": n_conf_ok / n_conf, "adam_all": n_all_ok / max(n_all, 1)}
     # SGD with momentum, first step: buf = g + wd * p0 and p1 = p0 - lr * buf.  lr * buf is about ONE fp32 ulp of a
     # discriminator weight, so the direction is read from the momentum buffer (full precision) and the parameters
-    # are only required to have moved by that much (+- 1 ulp).  d1 / d2: elementwise 2e-2.  d4 sits behind
+    # are only required to have moved by that much (+- 1 ulp).  d1 / d2: elementwise 6e-2 of the tensor's largest entry
+    # (independent forward passes: a few LeakyReLU(0.2) routing flips in the 129^2 ... 9^2 maps; observed <= 3.8e-2; the
+    # 1e-4 check with the routing shared is test_discriminator_backward_shared_routing).  d4 sits behind
     # BatchNorm1d over the batch of 4-8 (see _check_losses): its buffer is held to 0.35 in norm per tensor and to a
     # cosine of 0.9 with the reference's over all sampled elements.
     for nm, mod, opt in (("d1", tr.dis1, tr.opt_d1), ("d2", tr.dis2, tr.opt_d2), ("d4", tr.dis4, tr.opt_d4)):
@@ -143,7 +145,7 @@ def _check_updates(tr, g, pre):
                 dot += float(got @ ref); n_got += float(got @ got); n_ref += float(ref @ ref)
             else:
                 e = np.abs(got - ref).max() / scale
-                assert e <= 2e-2, (nm, k, e)
+                assert e <= 6e-2, (nm, k, e)
                 worst = max(worst, e)
             p0, p1, p1_ref = _sample(tr._p0[nm][k]), _sample(v), g[pre + "ps/%s/%s" % (nm, k)].astype(np.float64)
             ulp = np.spacing(np.abs(p0).astype(np.float32)).astype(np.float64)
