@@ -148,8 +148,9 @@ def _check_updates(tr, g, pre):
                 assert e <= 6e-2, (nm, k, e)
                 worst = max(worst, e)
             p0, p1, p1_ref = _sample(tr._p0[nm][k]), _sample(v), g[pre + "ps/%s/%s" % (nm, k)].astype(np.float64)
-            ulp = np.spacing(np.abs(p0).astype(np.float32)).astype(np.float64)
-            assert np.all(np.abs((p1 - p0) + opt.lr * got) <= 1.01 * ulp), (nm, k)          # moved by lr * buf
+            big = np.maximum(np.maximum(np.abs(p0), np.abs(p1)), np.abs(opt.lr * got))
+            ulp = np.spacing(big.astype(np.float32)).astype(np.float64)
+            assert np.all(np.abs((p1 - p0) + opt.lr * got) <= 1.51 * ulp), (nm, k)          # moved by lr * buf
             assert np.all(np.abs(p1 - p1_ref) <= opt.lr * np.abs(got - ref) + 2.01 * ulp), (nm, k)
         if nm == "d4":
             cos = dot / max((n_got * n_ref) ** 0.5, 1e-30)
