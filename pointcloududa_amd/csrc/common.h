@@ -46,12 +46,12 @@ __device__ __forceinline__ float bf16_hi_as_float(float a) {
   __bf16 h = (__bf16)a;
   return (float)h;
 }
-// hi/lo packs of two floats: hi = bf16(a), lo = bf16(a - hi)
+// hi/lo packs of two floats: hi = bf16(a), lo = bf16(a - hi).  Written on the packed word (one conversion per
+// pair, shift / mask back to fp32): 6 VALU per pair; the per-element form compiled to 8.
 __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
-  bf16x2 ph = {(__bf16)a, (__bf16)b};
-  hi = __builtin_bit_cast(uint32_t, ph);
-  float ra = a - (float)ph[0], rb = b - (float)ph[1];
-  lo = pack_bf16x2(ra, rb);
+  hi = pack_bf16x2(a, b);
+  const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xffff0000u);
+  lo = pack_bf16x2(a - ha, b - hb);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -76,6 +76,15 @@ __device__ __forceinline__ float half_wave_sum_hi16(float v) {
   v += dpp_mov0<0x141, 0xF>(v);   // row_half_mirror
   v += dpp_mov0<0x140, 0xF>(v);   // row_mirror: every lane of a 16-lane row holds the row's sum
   v += dpp_mov0<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3: lanes 16..31 / 48..63 hold the 32-lane sum
+  return v;
+}
+// sum over each aligned group of N = 16 or 8 lanes (a DPP row or half a row); every lane of the group holds it
+template <int N>
+__device__ __forceinline__ float row_sum(float v) {
+  v += dpp_mov0<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov0<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov0<0x141, 0xF>(v);   // row_half_mirror: lanes 0..7 / 8..15 of a row hold their half's sum
+  if (N == 16) v += dpp_mov0<0x140, 0xF>(v);   // row_mirror
   return v;
 }
 // sum over the 32 lanes that share (lane >> 5)

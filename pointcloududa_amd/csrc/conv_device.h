@@ -152,6 +152,7 @@ template <int PF>
 struct XFast {
   float v[PF][32];
   bool inb[PF];
+  bool anyout;   // quad path, wave-uniform: some staged quad of this wave lies outside the image (needs the zero select)
 };
 
 // issue: npix halo pixels x (8*ngroups) channels of chunk `chunk`, image n; values stay in registers
@@ -268,6 +269,7 @@ __device__ __forceinline__ void xq_issue(XFast<PF>& pre, const pcuda_src& x, int
   const int lead = ox0 & 3, nq = (tw + lead + 3) >> 2, nitems = th * nq;
   const int qmagic = (1 << 16) / nq + 1;   // exact for item < 1024, nq <= 80
   unsigned off[PF];
+  bool outside = false;
 #pragma unroll
   for (int s = 0; s < PF; ++s) {
     const int item = lane + IS * s;
@@ -275,7 +277,9 @@ __device__ __forceinline__ void xq_issue(XFast<PF>& pre, const pcuda_src& x, int
     const int gy = oy0 + iy, gx = ox0 - lead + 4 * q;
     pre.inb[s] = (item < nitems) & ((unsigned)gy < (unsigned)in_h) & ((unsigned)gx < (unsigned)in_w);
     off[s] = pre.inb[s] ? (unsigned)(gy * in_w + gx) * 4u : 0u;
+    outside |= (item < nitems) & !pre.inb[s];
   }
+  pre.anyout = __builtin_amdgcn_ballot_w64(outside) != 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const char* plane = (const char*)(base + (long long)min(cl0 + j, csrc - 1) * sc);   // wave-uniform, clamped
@@ -303,28 +307,34 @@ __device__ __forceinline__ void xq_commit(XFast<PF>& pre, unsigned char* __restr
   const int cl0 = (first ? c0 : c0 - x.c1) + w * 8 + opaque_zero();
   const int lead = ox0 & 3, nq = (tw + lead + 3) >> 2, nitems = th * nq;
   const int qmagic = (1 << 16) / nq + 1;
-  float sc[8], sh[8];
-  bool cok[8];
+  // Uniform blocks instead of per-element selects: the lazy-BatchNorm affine only where the source has one (the
+  // gradient operands of dgrad do not), the zero select only on waves that staged a quad outside the image or a
+  // ragged channel group (about a third of the tiles of a 256x256 map).
+  if (scp) {
+    float sc[8], sh[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    cok[j] = cl0 + j < csrc;
-    sc[j] = 1.f; sh[j] = 0.f;
-    if (scp) { sc[j] = scp[min(cl0 + j, csrc - 1)]; sh[j] = shp[min(cl0 + j, csrc - 1)]; }
+    for (int j = 0; j < 8; ++j) { sc[j] = scp[min(cl0 + j, csrc - 1)]; sh[j] = shp[min(cl0 + j, csrc - 1)]; }
+#pragma unroll
+    for (int s = 0; s < PF; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pre.v[s][4 * j + e] = fmaf(pre.v[s][4 * j + e], sc[j], sh[j]);
+  }
+  if (pre.anyout | (cl0 + 8 > csrc)) {   // zero padding is applied AFTER the affine
+#pragma unroll
+    for (int s = 0; s < PF; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool ok = pre.inb[s] & (cl0 + j < csrc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pre.v[s][4 * j + e] = ok ? pre.v[s][4 * j + e] : 0.f;
+      }
   }
 #pragma unroll
   for (int s = 0; s < PF; ++s) {
     const int item = lane + IS * s;
     const int iy = (item * qmagic) >> 16, q = item - iy * nq;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const bool ok = pre.inb[s] & cok[j];   // zero padding is applied AFTER the affine
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float t = pre.v[s][4 * j + e];
-        if (scp) t = fmaf(t, sc[j], sh[j]);
-        pre.v[s][4 * j + e] = ok ? t : 0.f;
-      }
-    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int ix = 4 * q + e - lead;

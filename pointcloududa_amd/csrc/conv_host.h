@@ -124,5 +124,14 @@ struct IgemmPlan {
   size_t lds;
   int fat;   // one workgroup per CU, every (or many) taps of weights resident
   int w8;    // eight-wave kernel (one 512-thread workgroup per CU)
+  int te;    // transposed epilogue (16-byte row stores through a wave-local LDS transposition)
 };
+
+// transposed epilogue preconditions: unit x stride, rows and tiles of 4k pixels, 16-byte aligned planes
+static inline bool te_dst_ok(const pcuda_dst* y, int cout, int out_w, int lw, int tw, int ox_mul, int ox_off) {
+  if (ox_mul != 1 || ox_off != 0 || (tw & 3) || (out_w & 3) || (lw & 3)) return false;
+  if (((uintptr_t)y->p1 & 15) || (y->sc1 & 3) || (y->sn1 & 3)) return false;
+  if (y->c1 < cout && (((uintptr_t)y->p2 & 15) || (y->sc2 & 3) || (y->sn2 & 3))) return false;
+  return true;
+}
 

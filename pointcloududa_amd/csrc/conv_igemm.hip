@@ -283,6 +283,23 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
   // (the unpipelined fallback copies its weight groups in 512-vector passes: any tg of the plan works)
   const bool pipe = !nopipe && p.ntaps > 0 && fast_src_ok(&p.x, p.cin) && fast_dst_ok(&p.y, p.cout) &&
                     (pf <= 2 || (pf == 3 && !pl.w8 && (pl.npb == 1 || pl.fat)));
+  {   // transposed epilogue: its LDS scratch (4 waves x [32][32*npb] fp32 + the partial-sum slots) aliases the
+      // X / W slabs and must end in front of the tap table behind them
+    static int note = -1;
+    if (note < 0) { const char* e = getenv("PCUDA_NOTE"); note = e ? atoi(e) : 0; }
+    pl.te = (pipe && !pl.w8 && !note &&
+             te_dst_ok(&p.y, p.cout, p.out_w, p.lw, pl.tw, p.ox_mul, p.ox_off)) ? 1 : 0;
+    if (pl.te) {
+      const size_t mul = x3 ? 2 : 1, wtap = (size_t)co_tile * IG_REC_BYTES * mul;
+      const size_t need = (size_t)16384 * pl.npb + (size_t)co_tile * 32;
+      const size_t have = (size_t)pl.x_cap * IG_REC_BYTES * mul + (size_t)pl.tg * wtap;
+      if (have < need) {
+        const int add = (int)((need - have + IG_REC_BYTES * mul - 1) / (IG_REC_BYTES * mul));
+        pl.x_cap += add;
+        pl.lds += (size_t)add * IG_REC_BYTES * mul;
+      }
+    }
+  }
   return x3 ? igemm_dispatch_x3(p, pl, co_blks, pf, pipe, s) : igemm_dispatch_bf16(p, pl, co_blks, pf, pipe, s);
 }
 

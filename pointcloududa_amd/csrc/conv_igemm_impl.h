@@ -293,7 +293,7 @@ __device__ __forceinline__ TileGeom tile_decode(const IgemmParams& p, int L) {
 // resident (512 VGPRs per lane: the whole group sits in registers between its loads and its LDS
 // write) -- a stage then has one weight round trip, issued in front of the X prefetch, and no barrier
 // inside its MFMA phase.
-template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ, bool STATS>
+template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ, bool STATS, bool TE>
 __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const IgemmParams p, const int x_cap, const int total) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CO_TILE = 32 * CO_BLKS;
@@ -378,6 +378,18 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
     WPass<X3, WV> wp0;
     const int nvec0 = min(p.tg, p.ntaps) * CO_TILE * 5;
     wcopy_issue<X3, WV>(wp0, (const uint4*)wsrc, (const uint4*)(wsrc + p.w_lo_off), nvec0, 0, tid);
+    // second weight group (more taps than one LDS slab holds): requested here too, IN FRONT of the input prefetch, and
+    // parked in registers until the first group's MFMAs are done.  Requested behind the prefetch (vmcnt retires in
+    // order) its wait was a wait for the whole next input tile to arrive from HBM, in the middle of every stage.
+    // Unconditional (a single-group plan re-reads one vector of group 0): a branch around loads would turn the
+    // counted waits below into vmcnt(0).
+    WPass<X3, WV> wp1;
+    const bool two = !DB && CO_BLKS == 1 && p.ntaps > p.tg;   // (64-row tiles: five groups, and no registers to spare)
+    const int nvec1 = two ? min(p.tg, p.ntaps - p.tg) * CO_TILE * 5 : 1;
+    if (!DB && CO_BLKS == 1) {
+      const uint16_t* src1 = wsrc + (two ? (long long)p.tg * slab : 0);
+      wcopy_issue<X3, WV>(wp1, (const uint4*)src1, (const uint4*)(src1 + p.w_lo_off), nvec1, 0, tid);
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     // next stage: its loads stay in flight through everything below
@@ -419,10 +431,14 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
       const int tgc = min(p.tg, p.ntaps - t0);
       const bool more = t0 + p.tg < p.ntaps;
       const int nvecn = min(p.tg, p.ntaps - (t0 + p.tg)) * CO_TILE * 5;
-      if (!DB && t0 > 0) {   // later groups (more taps than fit): loaded behind the X prefetch, latency exposed
+      if (!DB && t0 > 0) {
         __syncthreads();
-        const uint16_t* src = wsrc + (long long)t0 * slab;
-        wcopy<X3, WV>(Whi, Wlo, (const uint4*)src, (const uint4*)(src + p.w_lo_off), tgc * CO_TILE * 5, 0, tid);
+        if (CO_BLKS == 1 && gi == 1) {   // the group parked in registers since the top of the stage
+          wcopy_commit<X3, WV>(wp1, Whi, Wlo, nvec1, 0, tid);
+        } else {         // third and later groups: loaded behind the X prefetch, latency exposed
+          const uint16_t* src = wsrc + (long long)t0 * slab;
+          wcopy<X3, WV>(Whi, Wlo, (const uint4*)src, (const uint4*)(src + p.w_lo_off), tgc * CO_TILE * 5, 0, tid);
+        }
         DBG_CLK(3)
         __syncthreads();
         DBG_CLK(4)
@@ -438,6 +454,10 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
       }
       const unsigned char* Wh = Whi + (DB ? (gi & 1) * wbuf_bytes : 0);
       const unsigned char* Wl = Wlo + (DB ? (gi & 1) * wbuf_bytes : 0);
+      // (Operand prefetch across k-steps was tried twice and reverted: two full fragment sets spilled 41-109 registers
+      // next to the 64 prefetch registers; a rotating form -- weights one step ahead in a second set, each pixel block's
+      // input fragments re-read under the other block's MFMAs -- fit, and measured 4 % SLOWER on the 3x3 layers: with two
+      // waves per SIMD the partner wave already covers the LDS round trip, and the schedule fences cost more.)
       int tv = taptab[t0];
       for (int tl = 0; tl < tgc; ++tl) {
         const int tcur = tv;
@@ -503,6 +523,117 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
       const int co0 = g.cot * CO_TILE;
       if (tid < CO_TILE) sbias[tid] = bias_r;
       __syncthreads();   // sbias visible; sred aliases the X tile: every wave's last fragment reads are done
+      if constexpr (TE) {
+        // Transposed epilogue (rows of 4k pixels, unit x stride): every wave turns its [32 rows][WPIX pixels]
+        // accumulator block through its own LDS scratch so that a lane holds 4 consecutive pixels of one channel:
+        // one 16-byte store per lane, a wave instruction writes whole 128-B row segments of CPI channels
+        // (8 / 4 stores per row block instead of 32 / 16 one-dword stores), and the BatchNorm partial sums of a
+        // channel come out of ONE 16- (8-) lane DPP reduction.  Wave-local: no workgroup barrier inside.
+        constexpr int WPIX = 32 * NPB, LPC = WPIX / 4, CPI = 64 / LPC, NIT = 32 / CPI;
+        float* const tsc = (float*)smem + w * (32 * WPIX);
+        float* const sred2 = (float*)smem + 4 * 32 * WPIX;   // [4 waves][CO_TILE][2], behind the scratch
+        const int q = lane & (LPC - 1), cs = lane / LPC;
+        const int slot = w * WPIX + 4 * q;
+        const int sl = min(slot, TPIX - 1);
+        const int qy = IG_TY(sl, p.tmagic), qx = sl - qy * TW;
+        const int ly = g.y0 + qy, lx = g.x0 + qx;
+        const bool pokq = (slot < TPIX) & (ly < p.lh) & (lx < p.lw);
+        const unsigned pixq = (unsigned)((ly * p.oy_mul + p.oy_off) * p.out_w + lx) * 4u;
+        const int c1 = min(p.y.c1, p.cout);
+        char* const yb1 = (char*)(p.y.p1 + (long long)g.n * p.y.sn1);
+        char* const yb2 = (char*)(p.y.p2 + (long long)g.n * p.y.sn2);
+        const unsigned pl1 = (unsigned)p.y.sc1 * 4u, pl2 = (unsigned)p.y.sc2 * 4u;
+#pragma unroll
+        for (int cb = 0; cb < CO_BLKS; ++cb) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int pb = 0; pb < NPB; ++pb)
+              tsc[((i & 3) + 8 * (i >> 2) + 4 * h) * WPIX + pb * 32 + r] = acc[cb][pb][i];
+          __builtin_amdgcn_wave_barrier();
+          // (two batches of HN store instructions: a whole row block at once kept 80 more registers live next to
+          // the next stage's prefetch and spilled)
+          constexpr int HN = NIT > 4 ? 4 : NIT;
+#pragma unroll
+          for (int ib = 0; ib < NIT; ib += HN) {
+            f32x4 v[HN];
+            float bia[HN];
+            char* dptr[HN];
+            bool ok[HN];
+#pragma unroll
+            for (int k = 0; k < HN; ++k) {
+              const int it = ib + k;
+              v[k] = *(const f32x4*)(tsc + (it * CPI + cs) * WPIX + 4 * q);
+              bia[k] = sbias[cb * 32 + it * CPI + cs];
+              const int cu = co0 + cb * 32 + it * CPI;               // uniform; the CPI channels lie in one destination
+              const bool first = cu < c1;
+              char* const base = first ? yb1 + (long long)cu * pl1 : yb2 + (long long)(cu - c1) * pl2;
+              dptr[k] = base + (size_t)((unsigned)cs * (first ? pl1 : pl2) + pixq);
+              ok[k] = pokq & (cu + cs < p.cout);
+            }
+            if (p.accumulate) {   // uniform: dgrad into a gradient that already holds another consumer's share
+              f32x4 o[HN];
+#pragma unroll
+              for (int k = 0; k < HN; ++k) {
+                o[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ok[k]) o[k] = *(const f32x4*)dptr[k];
+              }
+#pragma unroll
+              for (int k = 0; k < HN; ++k) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  float t = v[k][e] + bia[k];
+                  t = t > 0.f ? t : t * p.slope;
+                  v[k][e] = t + o[k][e];
+                }
+              }
+            } else {
+#pragma unroll
+              for (int k = 0; k < HN; ++k) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  float t = v[k][e] + bia[k];
+                  v[k][e] = t > 0.f ? t : t * p.slope;
+                }
+              }
+            }
+#pragma unroll
+            for (int k = 0; k < HN; ++k) {
+              if (ok[k]) *(f32x4*)dptr[k] = v[k];
+              if (STATS) {
+                float s1 = (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+                float s2 = (v[k][0] * v[k][0] + v[k][1] * v[k][1]) + (v[k][2] * v[k][2] + v[k][3] * v[k][3]);
+                s1 = ok[k] ? s1 : 0.f;
+                s2 = ok[k] ? s2 : 0.f;
+                s1 = row_sum<LPC>(s1);
+                s2 = row_sum<LPC>(s2);
+                if (q == 0) {
+                  const int row = cb * 32 + (ib + k) * CPI + cs;
+                  sred2[(w * CO_TILE + row) * 2 + 0] = s1;
+                  sred2[(w * CO_TILE + row) * 2 + 1] = s2;
+                }
+              }
+            }
+          }
+          __builtin_amdgcn_wave_barrier();   // the next row block's scratch writes stay behind these reads
+        }
+        if (STATS) {
+          __syncthreads();
+          if (tid < CO_TILE) {
+            const int co = g.cot * CO_TILE + tid;
+            if (co < p.cout) {
+              float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+              for (int ww = 0; ww < 4; ++ww) {
+                s1 += sred2[(ww * CO_TILE + tid) * 2 + 0];
+                s2 += sred2[(ww * CO_TILE + tid) * 2 + 1];
+              }
+              p.stats[((long long)g.pt * p.cout + co) * 2 + 0] = s1;
+              p.stats[((long long)g.pt * p.cout + co) * 2 + 1] = s2;
+            }
+          }
+        }
+      } else {
       unsigned pixo[NPB];
       bool pok[NPB];
 #pragma unroll
@@ -569,6 +700,7 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
           }
         }
       }
+          }
     }
     DBG_CLK(6)
     L = nL; chunk = nchunk; g = ng; have = nhave;
@@ -856,9 +988,9 @@ static int launch_igemm_c(const IgemmParams& p, const IgemmPlan& pl, hipStream_t
                      : launch_igemm_t<X3, CO_BLKS, false, 1>(p, pl.x_cap, pl.lds, s);
 }
 
-template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ, bool STATS>
+template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ, bool STATS, bool TE>
 static int launch_pipe_s(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
-  auto kern = igemm_pipe_kernel<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, STATS>;
+  auto kern = igemm_pipe_kernel<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, STATS, TE>;
   static size_t lds_set = 0;
   if (pl.lds > 32 * 1024 && pl.lds > lds_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HARD);
@@ -887,8 +1019,10 @@ static int launch_pipe_s(const IgemmParams& p, const IgemmPlan& pl, hipStream_t 
 
 template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ>
 static int launch_pipe_t(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
-  return p.stats ? launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, true>(p, pl, s)
-                 : launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, false>(p, pl, s);
+  if (pl.te) return p.stats ? launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, true, true>(p, pl, s)
+                            : launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, false, true>(p, pl, s);
+  return p.stats ? launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, true, false>(p, pl, s)
+                 : launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, false, false>(p, pl, s);
 }
 
 template <bool X3, int CO_BLKS, bool CLAMP, int NPB>
