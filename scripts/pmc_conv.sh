@@ -13,8 +13,9 @@ SETS=(
  "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_TCC_READ_REQ_sum"
  "GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_WRITE_REQ_LATENCY_sum TCP_TCC_WRITE_REQ_sum"
 )
+# NSETS=2: only the issue / MFMA sets (the per-layer-class table of profiles/rNN_mfma_counters.csv)
 i=0
-for set in "${SETS[@]}"; do
+for set in "${SETS[@]:0:${NSETS:-6}}"; do
   timeout ${PMC_TIMEOUT:-200} rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmcc/s$i -o $TAG -- python3 scripts/conv_micro.py ${CASES:-g32} > gpurun_out/pmcc_s$i.log 2>&1
   echo "set $i rc=$?"
   i=$((i+1))
