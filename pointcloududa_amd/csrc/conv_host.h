@@ -135,3 +135,13 @@ static inline bool te_dst_ok(const pcuda_dst* y, int cout, int out_w, int lw, in
   return true;
 }
 
+
+// direct (vector-ALU) kernels of the degenerate layers (conv_direct.hip); each returns 1 when it took the launch
+int direct_fwd_tiles(const pcuda_conv_geom* g);
+int direct_forward(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const void* packed_w, long long w_lo_off,
+                   const float* bias, float slope, const pcuda_dst* y, float* bn_partials, hipStream_t s, int* rc);
+int direct_dgrad(const pcuda_conv_geom* g, int prec, const pcuda_src* dy, const void* packed_w_dgrad, const pcuda_dst* dx,
+                 int accumulate, hipStream_t s, int* rc);
+size_t direct_wgrad_workspace(const pcuda_conv_geom* g);
+int direct_wgrad(const pcuda_conv_geom* g, const pcuda_src* x, const float* dz, long long dz_sn, long long dz_sc, float* dw,
+                 float* db, int accumulate, void* workspace, hipStream_t s, int* rc);

@@ -377,6 +377,7 @@ extern "C" int pcuda_conv2d_pack_all(const pcuda_conv_geom* g, int prec, const f
 
 extern "C" int pcuda_conv2d_fwd_tiles(const pcuda_conv_geom* g, int prec) {
   if (!geom_ok(g)) return 0;
+  if (const int d = direct_fwd_tiles(g)) return d;
   TapSet t = fwd_taps(g);
   IgemmPlan pl;
   if (plan_igemm(g->cout, g->cin, g->n, g->out_h, g->out_w, g->in_h, g->in_w, g->stride, t, prec == PCUDA_PREC_BF16X3, &pl) < 0)
@@ -390,6 +391,12 @@ extern "C" int pcuda_conv2d_forward(const pcuda_conv_geom* g, int prec, const pc
   if (!geom_ok(g)) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_forward: inconsistent geometry");
   if (!src_ok(x, g->cin) || !dst_ok(y, g->cout) || !packed_w) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_forward: bad tensors");
   if (prec != PCUDA_PREC_BF16X3 && prec != PCUDA_PREC_BF16) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_forward: bad precision");
+  {
+    int rc;
+    if (direct_forward(g, prec, x, packed_w, (long long)packed_elems(g->cout, g->cin, g->k * g->k), bias, slope, y,
+                       bn_partials, (hipStream_t)s, &rc))
+      return rc;
+  }
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.x = *x; p.cin = g->cin;
@@ -411,6 +418,10 @@ extern "C" int pcuda_conv2d_dgrad(const pcuda_conv_geom* g, int prec, const pcud
   if (!geom_ok(g)) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_dgrad: inconsistent geometry");
   if (!src_ok(dy, g->cout) || !dst_ok(dx, g->cin) || !packed_w_dgrad) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_dgrad: bad tensors");
   if (prec != PCUDA_PREC_BF16X3 && prec != PCUDA_PREC_BF16) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_dgrad: bad precision");
+  {
+    int rc;
+    if (direct_dgrad(g, prec, dy, packed_w_dgrad, dx, accumulate, (hipStream_t)s, &rc)) return rc;
+  }
   const uint16_t* wp = (const uint16_t*)packed_w_dgrad;
   const int st = g->stride;
   for (int ry = 0; ry < st; ++ry)

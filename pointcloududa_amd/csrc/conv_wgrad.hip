@@ -108,7 +108,9 @@ WgradPlan plan_wgrad(const pcuda_conv_geom* g) {
 extern "C" size_t pcuda_conv2d_wgrad_workspace_size(const pcuda_conv_geom* g) {
   if (!geom_ok(g)) return 0;
   WgradPlan w = plan_wgrad(g);
-  return ((size_t)w.ksplit * g->cout * g->cin * g->k * g->k + (size_t)w.ksplit * g->cout) * sizeof(float) + 256;
+  const size_t need = ((size_t)w.ksplit * g->cout * g->cin * g->k * g->k + (size_t)w.ksplit * g->cout) * sizeof(float) + 256;
+  const size_t dneed = direct_wgrad_workspace(g);
+  return need > dneed ? need : dneed;
 }
 
 int wgrad_dispatch_x3(const WgradParams& p, int co_blks, bool clamp, int taps_max, int pf, int x_cap, size_t lds,
@@ -126,6 +128,10 @@ extern "C" int pcuda_conv2d_wgrad(const pcuda_conv_geom* g, int prec, const pcud
   if (!workspace || workspace_bytes < pcuda_conv2d_wgrad_workspace_size(g))
     PCUDA_FAIL(PCUDA_E_WORKSPACE, "conv2d_wgrad: workspace too small (%zu < %zu)", workspace_bytes,
                pcuda_conv2d_wgrad_workspace_size(g));
+  {
+    int rc;
+    if (direct_wgrad(g, x, dy, dy_sn, dy_sc, dw, db, accumulate, workspace, s, &rc)) return rc;
+  }
   const bool x3 = prec == PCUDA_PREC_BF16X3;
   WgradPlan w = plan_wgrad(g);
   TapSet t = fwd_taps(g);

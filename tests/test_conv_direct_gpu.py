@@ -1,0 +1,79 @@
+"""Direct (vector-ALU) kernels of the degenerate layers (csrc/conv_direct.hip): the segmenter's 1-channel first
+convolution (unet.py:23; forward with BatchNorm partial sums, weight gradient) and the 1x1 classifier
+(unet.py:178; forward with a lazy-BatchNorm input, data gradient into a split destination), each against a plain
+PyTorch-CPU fp32 reference of the same op, through the same C-ABI entry points as every other layer.  The weights
+are the packed hi + lo bf16 pair (2^-17 relative), the arithmetic fp32 FMA: tolerance 1e-4 of the output scale."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 64, 64), (3, 8, 36, 20), (2, 64, 16, 256), (1, 5, 10, 12)])
+@pytest.mark.parametrize("stats", [True, False])
+def test_first_layer_forward_and_wgrad(dev, shape, stats):
+    from pointcloududa_amd import kernels as K
+    n, cout, h, w_ = shape
+    rng = np.random.default_rng(n * 1000 + cout + h)
+    x = torch.from_numpy(rng.uniform(0, 1, (n, 1, h, w_)).astype(np.float32))
+    w = torch.from_numpy(rng.normal(0, 0.1, (cout, 1, 3, 3)).astype(np.float32)).requires_grad_(True)
+    b = torch.from_numpy(rng.normal(0, 0.1, (cout,)).astype(np.float32)).requires_grad_(True)
+    z = F.conv2d(x, w, b, padding=1)
+    y_ref = F.leaky_relu(z, 0.01)
+    gz = torch.from_numpy(rng.normal(0, 1, z.shape).astype(np.float32))
+    z.backward(gz)
+    op = K.ConvOp(1, cout, 3, pad=1)
+    y, part, nt = op.forward(x.to(dev), w.detach().to(dev), b.detach().to(dev), 0.01, h, w_, want_stats=stats)
+    assert rel_err(y, y_ref) < 1e-4
+    if stats:
+        s = part[:nt].double().sum(0).cpu()
+        assert rel_err(s[:, 0], y_ref.double().sum((0, 2, 3))) < 1e-4
+        assert rel_err(s[:, 1], (y_ref.double() ** 2).sum((0, 2, 3))) < 1e-4
+    dw = torch.full((cout, 1, 3, 3), 7.0, device=dev)
+    db = torch.full((cout,), 7.0, device=dev)
+    op.wgrad(x.to(dev), gz.to(dev), dw, db, h, w_, accumulate=False)
+    assert rel_err(dw, w.grad) < 1e-4 and rel_err(db, b.grad) < 1e-4
+    op.wgrad(x.to(dev), gz.to(dev), dw, db, h, w_, accumulate=True)
+    assert rel_err(dw, 2 * w.grad) < 1e-4 and rel_err(db, 2 * b.grad) < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 4, 64, 64), (2, 48, 5, 12, 20), (1, 64, 8, 8, 8), (2, 16, 1, 16, 16)])
+def test_classifier_forward_and_dgrad(dev, shape):
+    """input = cat(lazy-BatchNorm tensor, plain tensor) as two sources; dgrad accumulates into a split destination"""
+    from pointcloududa_amd import kernels as K
+    from pointcloududa_amd.kernels import TA
+    n, cin, cout, h, w_ = shape
+    c1 = cin // 2 if cin >= 32 else cin
+    rng = np.random.default_rng(cin * 100 + cout)
+    a = torch.from_numpy(rng.normal(0, 1, (n, c1, h, w_)).astype(np.float32))
+    sc = torch.from_numpy(rng.normal(1, 0.2, (c1,)).astype(np.float32))
+    sf = torch.from_numpy(rng.normal(0, 0.2, (c1,)).astype(np.float32))
+    parts = [a * sc[None, :, None, None] + sf[None, :, None, None]]
+    b2 = None
+    if c1 < cin:
+        b2 = torch.from_numpy(rng.normal(0, 1, (n, cin - c1, h, w_)).astype(np.float32))
+        parts.append(b2)
+    xin = torch.cat(parts, 1).requires_grad_(True)
+    w = torch.from_numpy(rng.normal(0, 0.1, (cout, cin, 1, 1)).astype(np.float32))
+    bias = torch.from_numpy(rng.normal(0, 0.1, (cout,)).astype(np.float32))
+    z = F.conv2d(xin, w, bias)
+    gz = torch.from_numpy(rng.normal(0, 1, z.shape).astype(np.float32))
+    z.backward(gz)
+    op = K.ConvOp(cin, cout, 1)
+    src = TA(a.to(dev), sc.to(dev), sf.to(dev))
+    y, _, _ = op.forward(src, w.to(dev), bias.to(dev), 1.0, h, w_, x2=None if b2 is None else b2.to(dev))
+    assert rel_err(y, z) < 1e-4
+    y2, _, _ = op.forward(src, w.to(dev), bias.to(dev), 0.2, h, w_, x2=None if b2 is None else b2.to(dev))
+    assert rel_err(y2, F.leaky_relu(z, 0.2)) < 1e-4
+    d1 = torch.ones((n, c1, h, w_), device=dev)
+    d2 = torch.ones((n, cin - c1, h, w_), device=dev) if c1 < cin else None
+    op.dgrad(gz.to(dev), w.to(dev), h, w_, dx=d1, dx2=d2, accumulate=True)
+    got = d1 if d2 is None else torch.cat([d1, d2], 1)
+    assert rel_err(got - 1.0, xin.grad) < 1e-4
+    op.dgrad(gz.to(dev), w.to(dev), h, w_, dx=d1, dx2=d2, accumulate=False)
+    got = d1 if d2 is None else torch.cat([d1, d2], 1)
+    assert rel_err(got, xin.grad) < 1e-4

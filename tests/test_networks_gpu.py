@@ -29,7 +29,12 @@ def _strided(t, n=4096):
 def _check_grads(mod, g, tol, tol_elem=None):
     """per-parameter gradient norms (and samples) against the reference's.  Parameters whose reference
     gradient is rounding noise (a bias feeding a BatchNorm has an exactly-zero true gradient) are only
-    required to be equally negligible: the floor is 1e-3 of the model's total gradient norm."""
+    required to be equally negligible: the floor is 1e-3 of the model's total gradient norm.
+
+    Where the golden file carries the reference's OWN gradient spread (``gspread/``, ``gnspread/``: the reference
+    re-run with 2^-17 relative noise on every convolution output, oracle/make_golden.py), the bound of a parameter is
+    max(2e-2, 3 x that spread) instead of the flat ``tol`` / ``tol_elem``: tight where the reference is
+    well-conditioned, and no tighter than the reference can reproduce itself where it is not."""
     worst = 0.0
     tol_elem = tol if tol_elem is None else tol_elem
     total = sum(float(g[k]) ** 2 for k in g.files if k.startswith("gnorm/")) ** 0.5
@@ -42,15 +47,17 @@ def _check_grads(mod, g, tol, tol_elem=None):
             continue
         ref_norm = float(g["gnorm/" + k])
         got_norm = float(p.grad.double().norm())
-        assert abs(got_norm - ref_norm) <= tol * ref_norm + floor, (k, got_norm, ref_norm)
+        tn = max(2e-2, 3.0 * float(g["gnspread/" + k])) if "gnspread/" + k in g else tol
+        te = max(2e-2, 3.0 * float(g["gspread/" + k])) if "gspread/" + k in g else tol_elem
+        assert abs(got_norm - ref_norm) <= tn * ref_norm + floor, (k, got_norm, ref_norm, tn)
         if ref_norm < 10 * floor:
             continue
         if "g/" + k in g:
-            e = rel_err(p.grad, g["g/" + k]); worst = max(worst, e)
-            assert e < tol_elem, (k, e)
+            e = rel_err(p.grad, g["g/" + k]); worst = max(worst, e / te)
+            assert e < te, (k, e, te)
         elif "gs/" + k in g:
-            e = rel_err(_strided(p.grad, len(g["gs/" + k])), g["gs/" + k]); worst = max(worst, e)
-            assert e < tol_elem, (k, e)
+            e = rel_err(_strided(p.grad, len(g["gs/" + k])), g["gs/" + k]); worst = max(worst, e / te)
+            assert e < te, (k, e, te)
     return worst
 
 
@@ -64,7 +71,8 @@ def _check_grads(mod, g, tol, tol_elem=None):
 def test_segmenter_vs_reference_golden(dev, tag, cfg_kw, softmax):
     """forward + backward under the reference's own supervised loss (train_mscmrseg.py:202-209 /
     train_mmwhs.py:212-218).  Outputs and loss: 1e-3 (north-star); observed ~1e-4.
-    Gradients: 5e-2 on norms / 1e-1 elementwise.  The reference network's gradients are discontinuous
+    Gradients: per parameter max(2e-2, 3 x the reference's own spread under 2^-17 relative noise on every convolution output) -- see _check_grads;
+    the golden files record spreads of up to 20 % (encoder4, 16x16 level).  The reference network's gradients are discontinuous
     in its activations (max-pool argmax, LeakyReLU sign): scripts/gradient_conditioning.py shows that
     1e-6 relative noise on the FIRST conv output of the fp32 oracle already moves some weight gradients
     by 1-2 % (one routing flip at the 8x8 level is 1/128 of a sum), so no two fp32-class
@@ -93,12 +101,13 @@ def test_segmenter_vs_reference_golden(dev, tag, cfg_kw, softmax):
         seeds.append(l_pt); grads.append(one); total += float(l_pt.detach())
     torch.autograd.backward(seeds, grads)
     assert abs(total - float(g["loss"])) < 1e-4 * max(1.0, abs(float(g["loss"])))
+    tdx = max(2e-2, 3.0 * float(g["dxspread"]))
     if "logits" in g:
         assert rel_err(logits, g["logits"]) < 1e-3
-        assert rel_err(x.grad, g["dx"]) < 1e-1
+        assert rel_err(x.grad, g["dx"]) < tdx
     else:
         assert rel_err(_strided(logits), g["logits_s"]) < 1e-3
-        assert rel_err(_strided(x.grad), g["dx_s"]) < 1e-1
+        assert rel_err(_strided(x.grad), g["dx_s"]) < tdx
     if cfg.pointnet:
         assert rel_err(verts, g["verts"]) < 1e-3
     _check_grads(model, g, 5e-2, 1e-1)
