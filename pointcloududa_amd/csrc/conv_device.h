@@ -5,19 +5,21 @@
 // ------------------------------------------------------------------------------------------
 // stage one 32-channel chunk of a haloed input tile into LDS, pixel-major, bf16 hi (+ lo)
 // ------------------------------------------------------------------------------------------
-template <bool X3>
-__device__ __forceinline__ void stage_write(unsigned char* __restrict__ xhi, unsigned char* __restrict__ xlo,
+// REC = bytes per pixel record: 80 (one plane per record: bf16 mode, and both planes of the weight-gradient kernels)
+// or 144 (bf16x3 forward / dgrad: hi 64 B | lo 64 B | 16 pad in ONE record, xlo = xhi + 64)
+template <bool X3, int REC = IG_REC_BYTES>
+__device__ __forceinline__ void stage_write(unsigned char* xhi, unsigned char* xlo,
                                             const float (&v)[8], int pix, int g) {
   uint4 hi, lo;
   if (X3) {
     split2(v[0], v[1], hi.x, lo.x); split2(v[2], v[3], hi.y, lo.y);
     split2(v[4], v[5], hi.z, lo.z); split2(v[6], v[7], hi.w, lo.w);
-    *(uint4*)(xlo + (size_t)pix * IG_REC_BYTES + g * 16) = lo;
+    *(uint4*)(xlo + (size_t)pix * REC + g * 16) = lo;
   } else {
     hi.x = pack_bf16x2(v[0], v[1]); hi.y = pack_bf16x2(v[2], v[3]);
     hi.z = pack_bf16x2(v[4], v[5]); hi.w = pack_bf16x2(v[6], v[7]);
   }
-  *(uint4*)(xhi + (size_t)pix * IG_REC_BYTES + g * 16) = hi;
+  *(uint4*)(xhi + (size_t)pix * REC + g * 16) = hi;
 }
 
 // wave-uniform channel -> plane pointer / lazy-BatchNorm affine of a two-source input.  Selects on
@@ -45,8 +47,8 @@ __device__ __forceinline__ void src_affine(const pcuda_src& x, int c, float& sc,
 //    (cdna_hip_programming.md, "Three .s-level traps" (c));
 //  * the lazy-BatchNorm scale/shift are read in uniform control flow (scalar loads), one fma per value.
 // Phase 1 issues all 32*PF loads of the chunk, phase 2 applies the affine, splits and writes LDS.
-template <bool X3, int PF>
-__device__ __forceinline__ void stage_x_chunk_mlp(unsigned char* __restrict__ xhi, unsigned char* __restrict__ xlo,
+template <bool X3, int PF, int REC = IG_REC_BYTES>
+__device__ __forceinline__ void stage_x_chunk_mlp(unsigned char* xhi, unsigned char* xlo,
                                                   const pcuda_src& x, int n, int cin, int chunk, int in_h, int in_w,
                                                   int in_shift, int in_row, int oy0, int ox0, int th, int tw,
                                                   int ngroups, int nwrite, int tid0) {
@@ -85,8 +87,8 @@ __device__ __forceinline__ void stage_x_chunk_mlp(unsigned char* __restrict__ xh
 #pragma unroll
       for (int s = 0; s < PF; ++s)
         if (tid + s * 256 < npix) {
-          *(uint4*)(xhi + (size_t)(tid + s * 256) * IG_REC_BYTES + g * 16) = make_uint4(0, 0, 0, 0);
-          if (X3) *(uint4*)(xlo + (size_t)(tid + s * 256) * IG_REC_BYTES + g * 16) = make_uint4(0, 0, 0, 0);
+          *(uint4*)(xhi + (size_t)(tid + s * 256) * REC + g * 16) = make_uint4(0, 0, 0, 0);
+          if (X3) *(uint4*)(xlo + (size_t)(tid + s * 256) * REC + g * 16) = make_uint4(0, 0, 0, 0);
         }
     }
     if (g < ngroups) {
@@ -104,27 +106,27 @@ __device__ __forceinline__ void stage_x_chunk_mlp(unsigned char* __restrict__ xh
       }
 #pragma unroll
       for (int s = 0; s < PF; ++s)
-        if (tid + s * 256 < npix) stage_write<X3>(xhi, xlo, v[s][g], tid + s * 256, g);
+        if (tid + s * 256 < npix) stage_write<X3, REC>(xhi, xlo, v[s][g], tid + s * 256, g);
     }
   }
 }
 
-template <bool X3, int MAXPF = 3>
-__device__ __forceinline__ void stage_x_chunk(unsigned char* __restrict__ xhi, unsigned char* __restrict__ xlo,
+template <bool X3, int MAXPF = 3, int REC = IG_REC_BYTES>
+__device__ __forceinline__ void stage_x_chunk(unsigned char* xhi, unsigned char* xlo,
                                               const pcuda_src& x, int n, int cin, int chunk, int in_h, int in_w,
                                               int in_shift, int in_row, int oy0, int ox0, int th, int tw,
                                               int ngroups, int nwrite, int tid) {
   const int npix = th * tw;
   if (MAXPF == 1) {   // register-tight callers (wgrad: 80+ accumulator registers): 32 loads in flight per lane
     for (int pix0 = 0; pix0 < npix; pix0 += 256)
-      stage_x_chunk_mlp<X3, 1>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, nwrite, tid + pix0);
+      stage_x_chunk_mlp<X3, 1, REC>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, nwrite, tid + pix0);
     return;
   }
-  if (npix <= 256) { stage_x_chunk_mlp<X3, 1>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, nwrite, tid); return; }
-  if (npix <= 512) { stage_x_chunk_mlp<X3, 2>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, nwrite, tid); return; }
-  if (npix <= 768) { stage_x_chunk_mlp<X3, 3>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, nwrite, tid); return; }
+  if (npix <= 256) { stage_x_chunk_mlp<X3, 1, REC>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, nwrite, tid); return; }
+  if (npix <= 512) { stage_x_chunk_mlp<X3, 2, REC>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, nwrite, tid); return; }
+  if (npix <= 768) { stage_x_chunk_mlp<X3, 3, REC>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, nwrite, tid); return; }
   for (int pix0 = 0; pix0 < npix; pix0 += 512)   // big tiles: 512 pixels at a time
-    stage_x_chunk_mlp<X3, 2>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, nwrite, tid + pix0);
+    stage_x_chunk_mlp<X3, 2, REC>(xhi, xlo, x, n, cin, chunk, in_h, in_w, in_shift, in_row, oy0, ox0, th, tw, ngroups, nwrite, tid + pix0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -189,9 +191,9 @@ __device__ __forceinline__ void xfast_issue(XFast<PF>& pre, const pcuda_src& x, 
 }
 
 // commit: lazy-BatchNorm affine (if the source has one), bf16 hi/lo split, LDS write
-template <bool X3, int PF, int NT = 256>
-__device__ __forceinline__ void xfast_commit(XFast<PF>& pre, unsigned char* __restrict__ xhi,
-                                             unsigned char* __restrict__ xlo, const pcuda_src& x, int cin, int chunk,
+template <bool X3, int PF, int NT = 256, int REC = IG_REC_BYTES>
+__device__ __forceinline__ void xfast_commit(XFast<PF>& pre, unsigned char* xhi,
+                                             unsigned char* xlo, const pcuda_src& x, int cin, int chunk,
                                              int npix, int ngroups, int nwrite, int tid) {
   const int c0 = chunk * 32;
   const bool first = c0 < x.c1;
@@ -205,8 +207,8 @@ __device__ __forceinline__ void xfast_commit(XFast<PF>& pre, unsigned char* __re
 #pragma unroll
       for (int s = 0; s < PF; ++s)
         if (tid + s * NT < npix) {
-          *(uint4*)(xhi + (size_t)(tid + s * NT) * IG_REC_BYTES + g * 16) = make_uint4(0, 0, 0, 0);
-          if (X3) *(uint4*)(xlo + (size_t)(tid + s * NT) * IG_REC_BYTES + g * 16) = make_uint4(0, 0, 0, 0);
+          *(uint4*)(xhi + (size_t)(tid + s * NT) * REC + g * 16) = make_uint4(0, 0, 0, 0);
+          if (X3) *(uint4*)(xlo + (size_t)(tid + s * NT) * REC + g * 16) = make_uint4(0, 0, 0, 0);
         }
     }
     if (g < ngroups) {
@@ -238,7 +240,7 @@ __device__ __forceinline__ void xfast_commit(XFast<PF>& pre, unsigned char* __re
           float (&v)[32] = pre.v[s];
           const float vv[8] = {v[g * 8 + 0], v[g * 8 + 1], v[g * 8 + 2], v[g * 8 + 3],
                                v[g * 8 + 4], v[g * 8 + 5], v[g * 8 + 6], v[g * 8 + 7]};
-          stage_write<X3>(xhi, xlo, vv, tid + s * NT, g);
+          stage_write<X3, REC>(xhi, xlo, vv, tid + s * NT, g);
         }
     }
   }
@@ -291,8 +293,8 @@ __device__ __forceinline__ void xq_issue(XFast<PF>& pre, const pcuda_src& x, int
   }
 }
 
-template <bool X3, int PF, int NT = 256>
-__device__ __forceinline__ void xq_commit(XFast<PF>& pre, unsigned char* __restrict__ xhi, unsigned char* __restrict__ xlo,
+template <bool X3, int PF, int NT = 256, int REC = IG_REC_BYTES>
+__device__ __forceinline__ void xq_commit(XFast<PF>& pre, unsigned char* xhi, unsigned char* xlo,
                                           const pcuda_src& x, int cin, int chunk, int ox0, int th, int tw, int nwrite,
                                           int tid) {
   // wave -> channel group (wv & 3); with 8 waves the two waves of a group split the (row, quad) items
@@ -341,7 +343,7 @@ __device__ __forceinline__ void xq_commit(XFast<PF>& pre, unsigned char* __restr
       if ((item < nitems) & ((unsigned)ix < (unsigned)tw)) {
         const float vv[8] = {pre.v[s][e], pre.v[s][4 + e], pre.v[s][8 + e], pre.v[s][12 + e],
                              pre.v[s][16 + e], pre.v[s][20 + e], pre.v[s][24 + e], pre.v[s][28 + e]};
-        stage_write<X3>(xhi, xlo, vv, iy * tw + ix, w);
+        stage_write<X3, REC>(xhi, xlo, vv, iy * tw + ix, w);
       }
     }
   }

@@ -38,7 +38,7 @@ bool aligned16(const void* p, long long sn, long long sc) { return (((uintptr_t)
 struct C1Params {
   const float* x; long long x_sn;
   float* y; long long y_sn, y_sc;
-  const uint16_t* wpack; long long w_lo_off;   // [co-tile][1 chunk][9 taps][CO_TILE][IG_REC]; lo plane or 0
+  const uint16_t* wpack; int rec;              // [co-tile][1 chunk][9 taps][CO_TILE][rec]; rec = 72: lo plane at +32 (bf16x3)
   int co_tile;
   const float* bias;
   float slope;
@@ -55,9 +55,9 @@ __global__ __launch_bounds__(256) void c1_fwd_kernel(const C1Params p) {
     const int co = i / 12, k = i - co * 12;
     float v = 0.f;
     if (k < 9) {
-      const long long idx = (((long long)(co / p.co_tile) * 9 + k) * p.co_tile + co % p.co_tile) * IG_REC;
+      const long long idx = (((long long)(co / p.co_tile) * 9 + k) * p.co_tile + co % p.co_tile) * p.rec;
       v = bf16_bits_to_float(p.wpack[idx]);
-      if (p.w_lo_off) v += bf16_bits_to_float(p.wpack[p.w_lo_off + idx]);
+      if (p.rec > IG_REC) v += bf16_bits_to_float(p.wpack[idx + 32]);
     } else if (k == 9) {
       v = p.bias ? p.bias[co] : 0.f;
     }
@@ -199,7 +199,7 @@ __global__ void c1_wgrad_reduce_kernel(const float* partial, int nblocks, int co
 struct PwParams {
   pcuda_src x;            // forward: input (lazy BatchNorm affine applied on load); dgrad: dz
   pcuda_dst y;            // forward: output; dgrad: dx
-  const uint16_t* wpack; long long w_lo_off;
+  const uint16_t* wpack; int rec;   // rec = 72: lo plane at +32 inside the record (bf16x3), 40: bf16 mode
   int row_tile;           // CO_TILE of the packed layout's row dimension
   const float* bias;
   float slope;
@@ -214,7 +214,7 @@ __device__ __forceinline__ float* pw_dst_plane(const pcuda_dst& y, int n, int c)
   return c < y.c1 ? y.p1 + (long long)n * y.sn1 + (long long)c * y.sc1 : y.p2 + (long long)n * y.sn2 + (long long)(c - y.c1) * y.sc2;
 }
 
-// forward packed layout: rows = cout (one 32-row tile), reduction = cin: w[co][ci] at ((ci/32) * 32 + co) * IG_REC + ci%32
+// forward packed layout: rows = cout (one 32-row tile), reduction = cin: w[co][ci] at ((ci/32) * 32 + co) * rec + ci%32
 template <int CO>
 __global__ __launch_bounds__(256) void pw_fwd_kernel(const PwParams p) {
   __shared__ float sw[64 * CO], ssc[64], ssh[64], sb[CO];
@@ -223,9 +223,9 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const PwParams p) {
     const int ci = i / CO, co = i - ci * CO;
     float v = 0.f;
     if (co < p.cout) {
-      const long long idx = ((long long)(ci >> 5) * p.row_tile + co) * IG_REC + (ci & 31);
+      const long long idx = ((long long)(ci >> 5) * p.row_tile + co) * p.rec + (ci & 31);
       v = bf16_bits_to_float(p.wpack[idx]);
-      if (p.w_lo_off) v += bf16_bits_to_float(p.wpack[p.w_lo_off + idx]);
+      if (p.rec > IG_REC) v += bf16_bits_to_float(p.wpack[idx + 32]);
     }
     sw[i] = v;
   }
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const PwParams p) {
   }
 }
 
-// dgrad packed layout: rows = cin (tiles of row_tile), reduction = cout: w[co][ci] at ((ci/row_tile) * row_tile + ci%row_tile) * IG_REC + co
+// dgrad packed layout: rows = cin (tiles of row_tile), reduction = cout: w[co][ci] at ((ci/row_tile) * row_tile + ci%row_tile) * rec + co
 template <int CO>
 __global__ __launch_bounds__(256) void pw_dgrad_kernel(const PwParams p) {
   __shared__ float sw[64 * CO];
@@ -281,9 +281,9 @@ __global__ __launch_bounds__(256) void pw_dgrad_kernel(const PwParams p) {
     const int ci = i / CO, co = i - ci * CO;
     float v = 0.f;
     if (co < p.cout) {
-      const long long idx = (long long)ci * IG_REC + co;
+      const long long idx = (long long)ci * p.rec + co;
       v = bf16_bits_to_float(p.wpack[idx]);
-      if (p.w_lo_off) v += bf16_bits_to_float(p.wpack[p.w_lo_off + idx]);
+      if (p.rec > IG_REC) v += bf16_bits_to_float(p.wpack[idx + 32]);
     }
     sw[i] = v;
   }
@@ -348,7 +348,7 @@ int direct_forward(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const
     C1Params p;
     p.x = x->p1; p.x_sn = x->sn1;
     p.y = y->p1; p.y_sn = y->sn1; p.y_sc = y->sc1;
-    p.wpack = (const uint16_t*)packed_w; p.w_lo_off = prec == PCUDA_PREC_BF16X3 ? w_lo_off : 0;
+    p.wpack = (const uint16_t*)packed_w; p.rec = ig_rec_bytes(prec == PCUDA_PREC_BF16X3) / 2;
     p.co_tile = 32 * ig_co_blks(g->cout);
     p.bias = bias; p.slope = slope; p.stats = bn_partials;
     p.n = g->n; p.h = g->in_h; p.w = g->in_w; p.cout = g->cout;
@@ -369,7 +369,7 @@ int direct_forward(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const
       return 0;
     PwParams p;
     p.x = *x; p.y = *y;
-    p.wpack = (const uint16_t*)packed_w; p.w_lo_off = prec == PCUDA_PREC_BF16X3 ? w_lo_off : 0;
+    p.wpack = (const uint16_t*)packed_w; p.rec = ig_rec_bytes(prec == PCUDA_PREC_BF16X3) / 2;
     p.row_tile = 32 * ig_co_blks(g->cout);
     p.bias = bias; p.slope = slope; p.accumulate = 0;
     p.n = g->n; p.hw = g->in_h * g->in_w; p.cin = g->cin; p.cout = g->cout;
@@ -399,7 +399,7 @@ int direct_dgrad(const pcuda_conv_geom* g, int prec, const pcuda_src* dy, const 
   p.wpack = (const uint16_t*)packed_w_dgrad;
   // dgrad layout of a 1x1 stride-1 layer: one parity class, one tap; rows = cin in tiles of 32 / 64, reduction = cout <= 8
   const int rt = 32 * ig_co_blks(g->cin);
-  p.w_lo_off = prec == PCUDA_PREC_BF16X3 ? (long long)cdiv(g->cin, rt) * rt * IG_REC : 0;
+  p.rec = ig_rec_bytes(prec == PCUDA_PREC_BF16X3) / 2;
   p.row_tile = rt;
   p.bias = nullptr; p.slope = 1.f; p.accumulate = accumulate;
   p.n = g->n; p.hw = g->in_h * g->in_w; p.cin = g->cin; p.cout = g->cout;

@@ -5,6 +5,17 @@
 #define IG_MAX_TAPS 36
 #define IG_REC 40          // bf16 per LDS record: 32 channels + 8 pad (80 B: conflict-free b128 reads)
 #define IG_REC_BYTES 80
+// Forward / dgrad kernels in bf16x3 mode keep BOTH planes of a pixel (or weight row) in ONE 144-byte record:
+// hi 64 B | lo 64 B | 16 pad.  36-dword stride: ds_read_b128 over consecutive records is still conflict-free, and the
+// haloed input tile plus a tap of weights take 10 % less LDS than two padded 80-byte planes -- which is what lets a
+// 64-row tile hold three taps per weight group (three groups per stage instead of five) next to a second workgroup.
+// The packed weight image in global memory has the same record (the LDS copy stays a linear 16-byte copy).
+template <bool X3>
+struct IgRec {
+  static constexpr int BYTES = X3 ? 144 : 80;
+};
+#define IG_LO_OFF 64
+static inline int ig_rec_bytes(bool x3) { return x3 ? 144 : 80; }
 
 // One launch of the generic kernel computes, for every logical output pixel (oy,ox) and row r:
 //   D[r][oy,ox] = sum_{tap t, channel c} Wp[t][r][c] * X[c][oy*in_step + dy[t]][ox*in_step + dx[t]]
@@ -71,7 +82,7 @@ struct WgradParams {
 struct PackParams {
   const float* w;
   uint16_t* out;
-  long long lo_off;        // 0 -> no lo plane (bf16 mode)
+  int rec;                 // bf16 elements per record: 40 (bf16 mode) or 72 (bf16x3: hi | lo | pad)
   int rows, red;           // rows (M) and reduction (K) extents
   long long s_row, s_red;  // element strides in w for row / reduction index (tap stride is 1)
   int ntaps;

@@ -19,24 +19,24 @@
 // weight repack: fp32 [rows][red][taps] (any strides) -> bf16 [co_tile][chunk][tap][CO_TILE][40]
 // ------------------------------------------------------------------------------------------
 __global__ void pack_kernel(const PackParams p) {
-  const long long total = (long long)p.n_co_tiles * p.nchunks * p.ntaps * p.co_tile * IG_REC;
+  const long long total = (long long)p.n_co_tiles * p.nchunks * p.ntaps * p.co_tile * p.rec;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
-    int col = (int)(idx % IG_REC);
-    long long rest = idx / IG_REC;
+    // record = 40 bf16 (bf16 mode: 32 values + 8 pad) or 72 (bf16x3: 32 hi | 32 lo | 8 pad)
+    int col = (int)(idx % p.rec);
+    long long rest = idx / p.rec;
     int row = (int)(rest % p.co_tile); rest /= p.co_tile;
     int t = (int)(rest % p.ntaps); rest /= p.ntaps;
     int ch = (int)(rest % p.nchunks);
     int cot = (int)(rest / p.nchunks);
-    int r = cot * p.co_tile + row, c = ch * 32 + col;
+    const bool is_lo = p.rec > IG_REC && col >= 32;
+    const int cc = is_lo ? col - 32 : col;
+    int r = cot * p.co_tile + row, c = ch * 32 + cc;
     float v = 0.f;
-    if (col < 32 && r < p.rows && c < p.red) v = p.w[r * p.s_row + c * p.s_red + p.tap_src[t]];
+    if (cc < 32 && r < p.rows && c < p.red) v = p.w[r * p.s_row + c * p.s_red + p.tap_src[t]];
     __bf16 hi = (__bf16)v;
+    if (is_lo) hi = (__bf16)(v - (float)hi);
     p.out[idx] = __builtin_bit_cast(uint16_t, hi);
-    if (p.lo_off) {
-      __bf16 lo = (__bf16)(v - (float)hi);
-      p.out[p.lo_off + idx] = __builtin_bit_cast(uint16_t, lo);
-    }
   }
 }
 
@@ -49,24 +49,24 @@ struct PackJobs {
 };
 __global__ void pack_multi_kernel(const PackJobs jobs) {
   const PackParams& p = jobs.p[blockIdx.y];
-  const long long total = (long long)p.n_co_tiles * p.nchunks * p.ntaps * p.co_tile * IG_REC;
+  const long long total = (long long)p.n_co_tiles * p.nchunks * p.ntaps * p.co_tile * p.rec;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
-    int col = (int)(idx % IG_REC);
-    long long rest = idx / IG_REC;
+    // record = 40 bf16 (bf16 mode: 32 values + 8 pad) or 72 (bf16x3: 32 hi | 32 lo | 8 pad)
+    int col = (int)(idx % p.rec);
+    long long rest = idx / p.rec;
     int row = (int)(rest % p.co_tile); rest /= p.co_tile;
     int t = (int)(rest % p.ntaps); rest /= p.ntaps;
     int ch = (int)(rest % p.nchunks);
     int cot = (int)(rest / p.nchunks);
-    int r = cot * p.co_tile + row, c = ch * 32 + col;
+    const bool is_lo = p.rec > IG_REC && col >= 32;
+    const int cc = is_lo ? col - 32 : col;
+    int r = cot * p.co_tile + row, c = ch * 32 + cc;
     float v = 0.f;
-    if (col < 32 && r < p.rows && c < p.red) v = p.w[r * p.s_row + c * p.s_red + p.tap_src[t]];
+    if (cc < 32 && r < p.rows && c < p.red) v = p.w[r * p.s_row + c * p.s_red + p.tap_src[t]];
     __bf16 hi = (__bf16)v;
+    if (is_lo) hi = (__bf16)(v - (float)hi);
     p.out[idx] = __builtin_bit_cast(uint16_t, hi);
-    if (p.lo_off) {
-      __bf16 lo = (__bf16)(v - (float)hi);
-      p.out[p.lo_off + idx] = __builtin_bit_cast(uint16_t, lo);
-    }
   }
 }
 
@@ -99,10 +99,10 @@ int ig_plan_mode() {
   return mode;
 }
 
-size_t packed_elems(int rows, int red, int ntaps) {   // bf16 elements of ONE plane (hi)
+size_t packed_elems(int rows, int red, int ntaps, int prec) {   // bf16 elements of one packed layout (both planes)
   const int co_tile = 32 * ig_co_blks(rows);
   const int n_co_tiles = cdiv(rows, co_tile), nchunks = cdiv(red, 32);
-  return (size_t)n_co_tiles * nchunks * ntaps * co_tile * IG_REC;
+  return (size_t)n_co_tiles * nchunks * ntaps * co_tile * (ig_rec_bytes(prec == PCUDA_PREC_BF16X3) / 2);
 }
 
 size_t fill_pack(PackParams& p, const float* w, uint16_t* out, int prec, int rows, int red, long long s_row,
@@ -114,8 +114,8 @@ size_t fill_pack(PackParams& p, const float* w, uint16_t* out, int prec, int row
   p.co_tile = 32 * ig_co_blks(rows);
   p.n_co_tiles = cdiv(rows, p.co_tile);
   p.nchunks = cdiv(red, 32);
-  const size_t plane = packed_elems(rows, red, taps.n);
-  p.lo_off = prec == PCUDA_PREC_BF16X3 ? (long long)plane : 0;
+  const size_t plane = packed_elems(rows, red, taps.n, prec);
+  p.rec = ig_rec_bytes(prec == PCUDA_PREC_BF16X3) / 2;
   return plane;
 }
 
@@ -134,25 +134,26 @@ int launch_pack(const float* w, uint16_t* out, int prec, int rows, int red, long
 // as many taps resident as one 256*WV-vector copy pass holds.
 int plan_lds(bool x3, int co_tile, int x_cap, int ntaps, int mode, int* tg_out, size_t* lds_out) {
   const bool fat = mode != 0;
-  const size_t mul = x3 ? 2 : 1;
-  const size_t xb = (size_t)x_cap * IG_REC_BYTES * mul;
-  const size_t wtap = (size_t)co_tile * IG_REC_BYTES * mul;
+  const size_t rec = ig_rec_bytes(x3), vecs = rec / 16;
+  const size_t xb = (size_t)x_cap * rec;
+  const size_t wtap = (size_t)co_tile * rec;
   const size_t epi = 4 * (size_t)co_tile * 2 * sizeof(float);
   const size_t tab = 512;   // per-tap offset table + the epilogue's bias slice, behind the weight slabs
   if (ntaps < 1) ntaps = 1;
-  // one copy pass per group: 3 / 5 slots x 256 lanes, or 6 slots x 512 lanes
-  const int cap = (mode == 2 ? 6 * 512 : (mode == 1 ? 5 * 256 : (co_tile == 32 ? 4 : 3) * 256)) / (co_tile * 5);
+  // one copy pass per group: the kernels' register slots (16-byte vectors per lane) x lanes; a bf16x3 record is 9
+  // vectors (both planes), a bf16 record 5
+  const int slots = mode == 2 ? (x3 ? 11 : 6) * 512 : (x3 ? (co_tile == 32 ? 8 : 7) : (co_tile == 32 ? 4 : 3)) * 256;
+  const int cap = slots / (int)(co_tile * vecs);
   // budgets: 3, 2, 1 workgroups per CU (160 KiB LDS)
   const size_t budgets[3] = {54528, 81920, 163840};
   for (int b = fat ? 2 : 0; b < 3; ++b) {
     if (xb + tab >= budgets[b]) continue;
-    const int nbuf = mode == 1 ? 2 : 1;   // mode 1: two alternating weight buffers
-    int fit = (int)((budgets[b] - xb - tab) / (nbuf * wtap));
+    int fit = (int)((budgets[b] - xb - tab) / wtap);
     if (fit > cap) fit = cap;
     const int need = b == 0 ? (ntaps < 3 ? ntaps : 3) : 1;
     if (fit < need) continue;
     const int tg = fit > ntaps ? ntaps : fit;
-    size_t total = xb + (size_t)nbuf * tg * wtap + tab;
+    size_t total = xb + (size_t)tg * wtap + tab;
     if (total < epi) total = epi;
     *tg_out = tg; *lds_out = total;
     return 0;
@@ -290,13 +291,13 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
     pl.te = (pipe && !pl.w8 && !note &&
              te_dst_ok(&p.y, p.cout, p.out_w, p.lw, pl.tw, p.ox_mul, p.ox_off)) ? 1 : 0;
     if (pl.te) {
-      const size_t mul = x3 ? 2 : 1, wtap = (size_t)co_tile * IG_REC_BYTES * mul;
+      const size_t rec = ig_rec_bytes(x3), wtap = (size_t)co_tile * rec;
       const size_t need = (size_t)16384 * pl.npb + (size_t)co_tile * 32;
-      const size_t have = (size_t)pl.x_cap * IG_REC_BYTES * mul + (size_t)pl.tg * wtap;
+      const size_t have = (size_t)pl.x_cap * rec + (size_t)pl.tg * wtap;
       if (have < need) {
-        const int add = (int)((need - have + IG_REC_BYTES * mul - 1) / (IG_REC_BYTES * mul));
+        const int add = (int)((need - have + rec - 1) / rec);
         pl.x_cap += add;
-        pl.lds += (size_t)add * IG_REC_BYTES * mul;
+        pl.lds += (size_t)add * rec;
       }
     }
   }
@@ -308,7 +309,7 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 extern "C" size_t pcuda_conv2d_packed_fwd_bytes(const pcuda_conv_geom* g, int prec) {
   if (!geom_ok(g)) return 0;
-  return packed_elems(g->cout, g->cin, g->k * g->k) * 2 * (prec == PCUDA_PREC_BF16X3 ? 2 : 1);
+  return packed_elems(g->cout, g->cin, g->k * g->k, prec) * 2;
 }
 
 extern "C" size_t pcuda_conv2d_packed_dgrad_bytes(const pcuda_conv_geom* g, int prec) {
@@ -317,7 +318,7 @@ extern "C" size_t pcuda_conv2d_packed_dgrad_bytes(const pcuda_conv_geom* g, int 
   for (int ry = 0; ry < g->stride; ++ry)
     for (int rx = 0; rx < g->stride; ++rx) {
       TapSet t = dgrad_taps(g, ry, rx);
-      tot += packed_elems(g->cin, g->cout, t.n) * 2 * (prec == PCUDA_PREC_BF16X3 ? 2 : 1);
+      tot += packed_elems(g->cin, g->cout, t.n, prec) * 2;
     }
   return tot;
 }
@@ -340,7 +341,7 @@ extern "C" int pcuda_conv2d_pack_dgrad(const pcuda_conv_geom* g, int prec, const
       TapSet t = dgrad_taps(g, ry, rx);
       int rc = launch_pack(w, out, prec, g->cin, g->cout, kk, (long long)g->cin * kk, t, (hipStream_t)s);
       if (rc) return rc;
-      out += packed_elems(g->cin, g->cout, t.n) * (prec == PCUDA_PREC_BF16X3 ? 2 : 1);
+      out += packed_elems(g->cin, g->cout, t.n, prec);
     }
   return PCUDA_OK;
 }
@@ -366,7 +367,7 @@ extern "C" int pcuda_conv2d_pack_all(const pcuda_conv_geom* g, int prec, const f
         if (t.n == 0) continue;
         const size_t plane = fill_pack(jobs.p[jobs.n++], w, out, prec, g->cin, g->cout, kk, (long long)g->cin * kk, t);
         if (plane > maxplane) maxplane = plane;
-        out += plane * (prec == PCUDA_PREC_BF16X3 ? 2 : 1);
+        out += plane;
       }
   }
   const int blocks = (int)((maxplane + 255) / 256 > 2048 ? 2048 : (maxplane + 255) / 256);
@@ -393,7 +394,7 @@ extern "C" int pcuda_conv2d_forward(const pcuda_conv_geom* g, int prec, const pc
   if (prec != PCUDA_PREC_BF16X3 && prec != PCUDA_PREC_BF16) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_forward: bad precision");
   {
     int rc;
-    if (direct_forward(g, prec, x, packed_w, (long long)packed_elems(g->cout, g->cin, g->k * g->k), bias, slope, y,
+    if (direct_forward(g, prec, x, packed_w, 0, bias, slope, y,
                        bn_partials, (hipStream_t)s, &rc))
       return rc;
   }
@@ -406,7 +407,7 @@ extern "C" int pcuda_conv2d_forward(const pcuda_conv_geom* g, int prec, const pc
   p.oy_mul = p.ox_mul = 1; p.oy_off = p.ox_off = 0;
   p.in_step = g->stride;
   p.wpack = (const uint16_t*)packed_w;
-  p.w_lo_off = (long long)packed_elems(g->cout, g->cin, g->k * g->k);
+  p.w_lo_off = 0;   // (both planes live in one record)
   p.bias = bias; p.slope = slope; p.accumulate = 0; p.stats = bn_partials;
   p.n = g->n;
   TapSet t = fwd_taps(g);
@@ -427,7 +428,7 @@ extern "C" int pcuda_conv2d_dgrad(const pcuda_conv_geom* g, int prec, const pcud
   for (int ry = 0; ry < st; ++ry)
     for (int rx = 0; rx < st; ++rx) {
       TapSet t = dgrad_taps(g, ry, rx);
-      const size_t plane = packed_elems(g->cin, g->cout, t.n);
+      const size_t plane = packed_elems(g->cin, g->cout, t.n, prec);
       const int lh = (g->in_h - ry + st - 1) / st, lw = (g->in_w - rx + st - 1) / st;
       if (lh > 0 && lw > 0) {
         IgemmParams p;
@@ -438,13 +439,13 @@ extern "C" int pcuda_conv2d_dgrad(const pcuda_conv_geom* g, int prec, const pcud
         p.lh = lh; p.lw = lw;
         p.oy_mul = p.ox_mul = st; p.oy_off = ry; p.ox_off = rx;
         p.in_step = 1;
-        p.wpack = wp; p.w_lo_off = (long long)plane;
+        p.wpack = wp; p.w_lo_off = 0;
         p.bias = nullptr; p.slope = 1.f; p.accumulate = accumulate; p.stats = nullptr;
         p.n = g->n;
         int rc = launch_igemm(p, prec, t, (hipStream_t)s);
         if (rc) return rc;
       }
-      wp += plane * (prec == PCUDA_PREC_BF16X3 ? 2 : 1);
+      wp += plane;
     }
   return PCUDA_OK;
 }

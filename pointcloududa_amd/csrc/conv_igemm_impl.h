@@ -37,10 +37,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p, const i
   }
   const int npix = th * tw;
 
+  constexpr int REC = IgRec<X3>::BYTES, RECV = REC / 16;
   unsigned char* Xhi = smem;
-  unsigned char* Xlo = smem + (size_t)x_cap * IG_REC_BYTES;
-  unsigned char* Whi = smem + (size_t)(X3 ? 2 : 1) * x_cap * IG_REC_BYTES;
-  unsigned char* Wlo = Whi + (size_t)p.tg * CO_TILE * IG_REC_BYTES;
+  unsigned char* Xlo = Xhi + IG_LO_OFF;
+  unsigned char* Whi = smem + (size_t)x_cap * REC;
+  unsigned char* Wlo = Whi + IG_LO_OFF;
 
   // per-lane pixel of each MFMA column block
   int pty[NPB], ptx[NPB], bbase[NPB];
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p, const i
     const int pl = min(plr, TPIX - 1);          // idle slots of a non-power-of-two tile read a valid pixel
     pty[pb] = IG_TY(pl, p.tmagic);
     ptx[pb] = pl - pty[pb] * TW;
-    bbase[pb] = ((pty[pb] * p.in_step) * tw + ptx[pb] * p.in_step) * IG_REC_BYTES + h * 16;
+    bbase[pb] = ((pty[pb] * p.in_step) * tw + ptx[pb] * p.in_step) * REC + h * 16;
   }
 
   f32x16 acc[CO_BLKS][NPB];
@@ -68,21 +69,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p, const i
     const int nks = cvalid > 16 ? 2 : 1;
     __syncthreads();   // every wave is done reading the previous chunk's X / W
     if (!(p.dbg & 1))
-      stage_x_chunk<X3>(Xhi, Xlo, p.x, n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row, oy0, ox0, th, tw,
+      stage_x_chunk<X3, 3, REC>(Xhi, Xlo, p.x, n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row, oy0, ox0, th, tw,
                         (cvalid + 7) >> 3, nks * 2, tid);
-    if (CLAMP && tid < 5) {   // the all-zero record that out-of-image taps read
-      *(uint4*)(Xhi + (size_t)npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
-      if (X3) *(uint4*)(Xlo + (size_t)npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
-    }
+    if (CLAMP && tid < RECV)   // the all-zero record that out-of-image taps read
+      *(uint4*)(Xhi + (size_t)npix * REC + tid * 16) = make_uint4(0, 0, 0, 0);
     for (int t0 = 0; t0 < p.ntaps; t0 += p.tg) {
       if (t0 > 0) __syncthreads();
       const int tgc = min(p.tg, p.ntaps - t0);
       {
-        const long long slab = (long long)CO_TILE * IG_REC;   // bf16 elements per tap
+        const long long slab = (long long)CO_TILE * (REC / 2);   // bf16 elements per tap
         const uint16_t* src = p.wpack + (((long long)cot * p.nchunks + chunk) * p.ntaps + t0) * slab;
-        const int nvec = tgc * CO_TILE * 5;                  // 16-B vectors
+        const int nvec = tgc * CO_TILE * RECV;               // 16-B vectors
         if (!(p.dbg & 8)) {
-          wcopy<X3, 2>(Whi, Wlo, (const uint4*)src, (const uint4*)(src + p.w_lo_off), nvec, 0, tid);
+          wcopy<false, 4>(Whi, nullptr, (const uint4*)src, nullptr, nvec, 0, tid);
         }
       }
       __syncthreads();
@@ -96,22 +95,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p, const i
             const int gx = (x0 + ptx[pb]) * p.in_step + p.dx[t];
             const bool ok = ((unsigned)gy < (unsigned)p.in_h) & ((unsigned)gx < (unsigned)p.in_w);
             const int idx = ok ? (gy - oy0) * tw + (gx - ox0) : npix;
-            baddr[pb] = idx * IG_REC_BYTES + h * 16;
+            baddr[pb] = idx * REC + h * 16;
           }
         } else {
-          const int toff = ((p.dy[t] - p.dy_min) * tw + (p.dx[t] - p.dx_min)) * IG_REC_BYTES;
+          const int toff = ((p.dy[t] - p.dy_min) * tw + (p.dx[t] - p.dx_min)) * REC;
 #pragma unroll
           for (int pb = 0; pb < NPB; ++pb) baddr[pb] = bbase[pb] + toff;
         }
-        const int abase = (tl * CO_TILE + r) * IG_REC_BYTES + h * 16;
+        const int abase = (tl * CO_TILE + r) * REC + h * 16;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           if (ks < nks) {
             bf16x8 ah[CO_BLKS], al[CO_BLKS], bh[NPB], bl[NPB];
 #pragma unroll
             for (int cb = 0; cb < CO_BLKS; ++cb) {
-              ah[cb] = lds_frag(Whi + abase + cb * 32 * IG_REC_BYTES + ks * 32);
-              if (X3) al[cb] = lds_frag(Wlo + abase + cb * 32 * IG_REC_BYTES + ks * 32);
+              ah[cb] = lds_frag(Whi + abase + cb * 32 * REC + ks * 32);
+              if (X3) al[cb] = lds_frag(Wlo + abase + cb * 32 * REC + ks * 32);
             }
 #pragma unroll
             for (int pb = 0; pb < NPB; ++pb) {
@@ -313,11 +312,14 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
   const int gx = ((int)gridDim.x - xcd + nx - 1) / nx;            // workgroups in this group
   const int lo = (int)((long long)total * xcd / nx), hi = (int)((long long)total * (xcd + 1) / nx);
 
+  constexpr int REC = IgRec<X3>::BYTES, RECV = REC / 16;
+  // weight-copy register slots per lane (16-B vectors): a bf16x3 record carries both planes
+  constexpr int WS = X3 ? 2 * WV + (CO_BLKS == 2 ? 1 : 0) : WV;
   unsigned char* Xhi = smem;
-  unsigned char* Xlo = smem + (size_t)x_cap * IG_REC_BYTES;
-  unsigned char* Whi = smem + (size_t)(X3 ? 2 : 1) * x_cap * IG_REC_BYTES;
-  unsigned char* Wlo = Whi + (size_t)p.tg * CO_TILE * IG_REC_BYTES;
-  int* taptab = (int*)(Whi + (size_t)(X3 ? 2 : 1) * (DB ? 2 : 1) * p.tg * CO_TILE * IG_REC_BYTES);   // [ntaps], behind the weight slabs
+  unsigned char* Xlo = Xhi + IG_LO_OFF;
+  unsigned char* Whi = smem + (size_t)x_cap * REC;
+  unsigned char* Wlo = Whi + IG_LO_OFF;
+  int* taptab = (int*)(Whi + (size_t)(DB ? 2 : 1) * p.tg * CO_TILE * REC);   // [ntaps], behind the weight slabs
   float* sbias = (float*)(taptab + 64);   // [CO_TILE] bias of the tile being finished (host adds 512 B in all)
   float* sred = (float*)smem;   // [4 waves][CO_TILE][2], reused between a tile's last MFMA and the next commit
 
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
   for (int t = 0; t < p.ntaps; ++t) {   // uniform index: a per-lane index would copy the tables to scratch
     const int dy = p.dy[t], dx = p.dx[t];
     if (tid == 0)
-      taptab[t] = CLAMP ? ((dy & 0xffff) | (dx << 16)) : ((dy - p.dy_min) * p.iw_t + (dx - p.dx_min)) * IG_REC_BYTES;
+      taptab[t] = CLAMP ? ((dy & 0xffff) | (dx << 16)) : ((dy - p.dy_min) * p.iw_t + (dx - p.dx_min)) * REC;
   }
 
   int pty[NPB], ptx[NPB];
@@ -360,35 +362,32 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
     DBG_CLK(7)
     __syncthreads();   // every wave is done with the previous stage's X / W / reduction scratch
     DBG_CLK(0)
-    if (XQ) xq_commit<X3, PF>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.ox0, g.th, g.tw, nks * 2, tid);
-    else xfast_commit<X3, PF>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.npix, (cvalid + 7) >> 3, nks * 2, tid);
+    if (XQ) xq_commit<X3, PF, 256, REC>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.ox0, g.th, g.tw, nks * 2, tid);
+    else xfast_commit<X3, PF, 256, REC>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.npix, (cvalid + 7) >> 3, nks * 2, tid);
     DBG_CLK(1)
-    if (CLAMP && tid < 5) {
-      *(uint4*)(Xhi + (size_t)g.npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
-      if (X3) *(uint4*)(Xlo + (size_t)g.npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
-    }
+    if (CLAMP && tid < RECV) *(uint4*)(Xhi + (size_t)g.npix * REC + tid * 16) = make_uint4(0, 0, 0, 0);
     // bias of this tile's rows (consumed by the epilogue after the last chunk): fetched here, in front of the
     // stage's other loads, so its wait never drains them
     float bias_r = 0.f;
     if (chunk == p.nchunks - 1 && p.bias && tid < CO_TILE) bias_r = p.bias[min(g.cot * CO_TILE + tid, p.cout - 1)];
     // first weight group: its loads go out BEFORE the next stage's input prefetch (vmcnt retires in order:
     // behind the prefetch they would not be usable until all of it has landed)
-    const long long slab = (long long)CO_TILE * IG_REC;
+    const long long slab = (long long)CO_TILE * (REC / 2);
     const uint16_t* wsrc = p.wpack + ((long long)g.cot * p.nchunks + chunk) * p.ntaps * slab;
-    WPass<X3, WV> wp0;
-    const int nvec0 = min(p.tg, p.ntaps) * CO_TILE * 5;
-    wcopy_issue<X3, WV>(wp0, (const uint4*)wsrc, (const uint4*)(wsrc + p.w_lo_off), nvec0, 0, tid);
+    WPass<false, WS> wp0;
+    const int nvec0 = min(p.tg, p.ntaps) * CO_TILE * RECV;
+    wcopy_issue<false, WS>(wp0, (const uint4*)wsrc, nullptr, nvec0, 0, tid);
     // second weight group (more taps than one LDS slab holds): requested here too, IN FRONT of the input prefetch, and
     // parked in registers until the first group's MFMAs are done.  Requested behind the prefetch (vmcnt retires in
     // order) its wait was a wait for the whole next input tile to arrive from HBM, in the middle of every stage.
     // Unconditional (a single-group plan re-reads one vector of group 0): a branch around loads would turn the
     // counted waits below into vmcnt(0).
-    WPass<X3, WV> wp1;
-    const bool two = !DB && CO_BLKS == 1 && p.ntaps > p.tg;   // (64-row tiles: five groups, and no registers to spare)
-    const int nvec1 = two ? min(p.tg, p.ntaps - p.tg) * CO_TILE * 5 : 1;
+    WPass<false, WS> wp1;
+    const bool two = !DB && CO_BLKS == 1 && p.ntaps > p.tg;   // (64-row tiles: no registers to spare)
+    const int nvec1 = two ? min(p.tg, p.ntaps - p.tg) * CO_TILE * RECV : 1;
     if (!DB && CO_BLKS == 1) {
       const uint16_t* src1 = wsrc + (two ? (long long)p.tg * slab : 0);
-      wcopy_issue<X3, WV>(wp1, (const uint4*)src1, (const uint4*)(src1 + p.w_lo_off), nvec1, 0, tid);
+      wcopy_issue<false, WS>(wp1, (const uint4*)src1, nullptr, nvec1, 0, tid);
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -419,25 +418,25 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
     int bbase[NPB];
 #pragma unroll
     for (int pb = 0; pb < NPB; ++pb)
-      bbase[pb] = ((pty[pb] * p.in_step) * g.tw + ptx[pb] * p.in_step) * IG_REC_BYTES + h * 16;
+      bbase[pb] = ((pty[pb] * p.in_step) * g.tw + ptx[pb] * p.in_step) * REC + h * 16;
 
     // weight groups of p.tg taps (<= 256*WV vectors per plane: one copy pass)
-    wcopy_commit<X3, WV>(wp0, Whi, Wlo, nvec0, 0, tid);
+    wcopy_commit<false, WS>(wp0, Whi, nullptr, nvec0, 0, tid);
     DBG_CLK(3)
     __syncthreads();
     DBG_CLK(4)
-    const size_t wbuf_bytes = (size_t)(X3 ? 2 : 1) * p.tg * CO_TILE * IG_REC_BYTES;
+    const size_t wbuf_bytes = (size_t)p.tg * CO_TILE * REC;
     for (int t0 = 0, gi = 0; t0 < p.ntaps; t0 += p.tg, ++gi) {
       const int tgc = min(p.tg, p.ntaps - t0);
       const bool more = t0 + p.tg < p.ntaps;
-      const int nvecn = min(p.tg, p.ntaps - (t0 + p.tg)) * CO_TILE * 5;
+      const int nvecn = min(p.tg, p.ntaps - (t0 + p.tg)) * CO_TILE * RECV;
       if (!DB && t0 > 0) {
         __syncthreads();
         if (CO_BLKS == 1 && gi == 1) {   // the group parked in registers since the top of the stage
-          wcopy_commit<X3, WV>(wp1, Whi, Wlo, nvec1, 0, tid);
+          wcopy_commit<false, WS>(wp1, Whi, nullptr, nvec1, 0, tid);
         } else {         // third and later groups: loaded behind the X prefetch, latency exposed
           const uint16_t* src = wsrc + (long long)t0 * slab;
-          wcopy<X3, WV>(Whi, Wlo, (const uint4*)src, (const uint4*)(src + p.w_lo_off), tgc * CO_TILE * 5, 0, tid);
+          wcopy<false, WS>(Whi, nullptr, (const uint4*)src, nullptr, tgc * CO_TILE * RECV, 0, tid);
         }
         DBG_CLK(3)
         __syncthreads();
@@ -446,7 +445,7 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
       if (DB) {
         if (more) {
           const uint16_t* src = wsrc + (long long)(t0 + p.tg) * slab;
-          wcopy_issue<X3, WV>(wp0, (const uint4*)src, (const uint4*)(src + p.w_lo_off), nvecn, 0, tid);
+          wcopy_issue<false, WS>(wp0, (const uint4*)src, nullptr, nvecn, 0, tid);
         } else {
           issue_next();
         }
@@ -471,21 +470,21 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
             const int gxx = (g.x0 + ptx[pb]) * p.in_step + dx;
             const bool ok = ((unsigned)gy < (unsigned)p.in_h) & ((unsigned)gxx < (unsigned)p.in_w);
             const int idx = ok ? (gy - g.oy0) * g.tw + (gxx - g.ox0) : g.npix;
-            baddr[pb] = idx * IG_REC_BYTES + h * 16;
+            baddr[pb] = idx * REC + h * 16;
           }
         } else {
 #pragma unroll
           for (int pb = 0; pb < NPB; ++pb) baddr[pb] = bbase[pb] + tcur;
         }
-        const int abase = (tl * CO_TILE + r) * IG_REC_BYTES + h * 16;
+        const int abase = (tl * CO_TILE + r) * REC + h * 16;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           if (ks < nks) {
             bf16x8 ah[CO_BLKS], al[CO_BLKS], bh[NPB], bl[NPB];
 #pragma unroll
             for (int cb = 0; cb < CO_BLKS; ++cb) {
-              ah[cb] = lds_frag(Wh + abase + cb * 32 * IG_REC_BYTES + ks * 32);
-              if (X3) al[cb] = lds_frag(Wl + abase + cb * 32 * IG_REC_BYTES + ks * 32);
+              ah[cb] = lds_frag(Wh + abase + cb * 32 * REC + ks * 32);
+              if (X3) al[cb] = lds_frag(Wl + abase + cb * 32 * REC + ks * 32);
             }
 #pragma unroll
             for (int pb = 0; pb < NPB; ++pb) {
@@ -507,7 +506,7 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
       }
       DBG_CLK_ACC(5)
       if (DB && more) {
-        wcopy_commit<X3, WV>(wp0, Whi + ((gi + 1) & 1) * wbuf_bytes, Wlo + ((gi + 1) & 1) * wbuf_bytes, nvecn, 0, tid);
+        wcopy_commit<false, WS>(wp0, Whi + ((gi + 1) & 1) * wbuf_bytes, nullptr, nvecn, 0, tid);
         DBG_CLK(3)
         __syncthreads();
         DBG_CLK(4)
@@ -719,7 +718,8 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
 // Wave roles: NPBT = 32-pixel blocks per tile (8: 256-pixel tiles, every wave owns one pixel block and
 // all CO_BLKS row blocks; 4: 128-pixel tiles with CO_BLKS = 2, waves 0-3 take row block 0, 4-7 block 1).
 // ------------------------------------------------------------------------------------------
-#define IG8_WV 6   // weight-copy slots per lane and plane: 6 * 512 vectors >= 9 taps x 64 rows x 5
+#define IG8_WV 6    // weight-copy slots per lane (bf16 mode, 80-B records): 6 * 512 vectors >= 9 taps x 64 rows x 5
+#define IG8_WV3 11  // bf16x3 (144-B records): 11 * 512 vectors >= 9 taps x 64 rows x 9
 template <bool X3, int CO_BLKS, bool CLAMP, int NPBT, int PF, bool XQ, bool STATS>
 __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, const int x_cap, const int total) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -737,18 +737,20 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
   const int gx = ((int)gridDim.x - xcd + nx - 1) / nx;
   const int lo = (int)((long long)total * xcd / nx), hi = (int)((long long)total * (xcd + 1) / nx);
 
+  constexpr int REC = IgRec<X3>::BYTES, RECV = REC / 16;
+  constexpr int WS = X3 ? IG8_WV3 : WV;
   unsigned char* Xhi = smem;
-  unsigned char* Xlo = smem + (size_t)x_cap * IG_REC_BYTES;
-  unsigned char* Whi = smem + (size_t)(X3 ? 2 : 1) * x_cap * IG_REC_BYTES;
-  unsigned char* Wlo = Whi + (size_t)p.tg * CO_TILE * IG_REC_BYTES;
-  int* taptab = (int*)(Whi + (size_t)(X3 ? 2 : 1) * p.tg * CO_TILE * IG_REC_BYTES);
+  unsigned char* Xlo = Xhi + IG_LO_OFF;
+  unsigned char* Whi = smem + (size_t)x_cap * REC;
+  unsigned char* Wlo = Whi + IG_LO_OFF;
+  int* taptab = (int*)(Whi + (size_t)p.tg * CO_TILE * REC);
   float* sbias = (float*)(taptab + 64);
   float* sred = (float*)smem;   // [8 waves][CO_TILE][2]
 
   for (int t = 0; t < p.ntaps; ++t) {
     const int dy = p.dy[t], dx = p.dx[t];
     if (tid == 0)
-      taptab[t] = CLAMP ? ((dy & 0xffff) | (dx << 16)) : ((dy - p.dy_min) * p.iw_t + (dx - p.dx_min)) * IG_REC_BYTES;
+      taptab[t] = CLAMP ? ((dy & 0xffff) | (dx << 16)) : ((dy - p.dy_min) * p.iw_t + (dx - p.dx_min)) * REC;
   }
 
   const int plr = pbw * 32 + r;
@@ -778,23 +780,20 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
     __syncthreads();   // every wave is done with the previous stage's X / W / reduction scratch
     float bias_r = 0.f;
     if (chunk == p.nchunks - 1 && p.bias && tid < CO_TILE) bias_r = p.bias[min(g.cot * CO_TILE + tid, p.cout - 1)];
-    if (XQ) xq_commit<X3, PF, NT>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.ox0, g.th, g.tw, nks * 2, tid);
-    else xfast_commit<X3, PF, NT>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.npix, (cvalid + 7) >> 3, nks * 2, tid);
-    if (CLAMP && tid < 5) {
-      *(uint4*)(Xhi + (size_t)g.npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
-      if (X3) *(uint4*)(Xlo + (size_t)g.npix * IG_REC_BYTES + tid * 16) = make_uint4(0, 0, 0, 0);
-    }
+    if (XQ) xq_commit<X3, PF, NT, REC>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.ox0, g.th, g.tw, nks * 2, tid);
+    else xfast_commit<X3, PF, NT, REC>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.npix, (cvalid + 7) >> 3, nks * 2, tid);
+    if (CLAMP && tid < RECV) *(uint4*)(Xhi + (size_t)g.npix * REC + tid * 16) = make_uint4(0, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     // the stage's (first) weight group, with nothing else in the load queue: one L2 round trip.  (Requested
     // before the X commit its 48 registers were spilled to scratch one load at a time.)
-    const long long slab = (long long)CO_TILE * IG_REC;
+    const long long slab = (long long)CO_TILE * (REC / 2);
     const uint16_t* wsrc = p.wpack + ((long long)g.cot * p.nchunks + chunk) * p.ntaps * slab;
-    const int nvec0 = min(p.tg, p.ntaps) * CO_TILE * 5;
+    const int nvec0 = min(p.tg, p.ntaps) * CO_TILE * RECV;
     {
-      WPass<X3, WV> wp0;
-      wcopy_issue<X3, WV, NT>(wp0, (const uint4*)wsrc, (const uint4*)(wsrc + p.w_lo_off), nvec0, 0, tid);
+      WPass<false, WS> wp0;
+      wcopy_issue<false, WS, NT>(wp0, (const uint4*)wsrc, nullptr, nvec0, 0, tid);
       __builtin_amdgcn_sched_barrier(0);
-      wcopy_commit<X3, WV, NT>(wp0, Whi, Wlo, nvec0, 0, tid);
+      wcopy_commit<false, WS, NT>(wp0, Whi, nullptr, nvec0, 0, tid);
       __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -812,7 +811,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
     }
-    const int bbase = ((pty * p.in_step) * g.tw + ptx * p.in_step) * IG_REC_BYTES + h * 16;
+    const int bbase = ((pty * p.in_step) * g.tw + ptx * p.in_step) * REC + h * 16;
     __syncthreads();
 
     for (int t0 = 0; t0 < p.ntaps; t0 += p.tg) {
@@ -820,7 +819,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
       if (t0 > 0) {   // more taps than fit (4x4 / 6x6 kernels): later groups load behind the prefetch
         __syncthreads();
         const uint16_t* src = wsrc + (long long)t0 * slab;
-        wcopy<X3, WV, NT>(Whi, Wlo, (const uint4*)src, (const uint4*)(src + p.w_lo_off), tgc * CO_TILE * 5, 0, tid);
+        wcopy<false, WS, NT>(Whi, nullptr, (const uint4*)src, nullptr, tgc * CO_TILE * RECV, 0, tid);
         __syncthreads();
       }
       int tv = taptab[t0];
@@ -834,20 +833,20 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
           const int gxx = (g.x0 + ptx) * p.in_step + dx;
           const bool ok = ((unsigned)gy < (unsigned)p.in_h) & ((unsigned)gxx < (unsigned)p.in_w);
           const int idx = ok ? (gy - g.oy0) * g.tw + (gxx - g.ox0) : g.npix;
-          baddr = idx * IG_REC_BYTES + h * 16;
+          baddr = idx * REC + h * 16;
         } else {
           baddr = bbase + tcur;
         }
-        const int abase = (tl * CO_TILE + cb0 * 32 + r) * IG_REC_BYTES + h * 16;
+        const int abase = (tl * CO_TILE + cb0 * 32 + r) * REC + h * 16;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           if (ks < nks) {
             bf16x8 ah[CBW], al[CBW];
 #pragma unroll
             for (int cb = 0; cb < CBW; ++cb) {
-              ah[cb] = lds_frag(Whi + abase + cb * 32 * IG_REC_BYTES + ks * 32);
+              ah[cb] = lds_frag(Whi + abase + cb * 32 * REC + ks * 32);
               al[cb] = ah[cb];
-              if (X3) al[cb] = lds_frag(Wlo + abase + cb * 32 * IG_REC_BYTES + ks * 32);
+              if (X3) al[cb] = lds_frag(Wlo + abase + cb * 32 * REC + ks * 32);
             }
             const bf16x8 bh = lds_frag(Xhi + baddr + ks * 32);
             bf16x8 bl = bh;
