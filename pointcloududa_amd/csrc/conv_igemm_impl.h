@@ -296,10 +296,6 @@ template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ, bo
 __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const IgemmParams p, const int x_cap, const int total) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CO_TILE = 32 * CO_BLKS;
-  // DB (one workgroup per CU): weight groups alternate between two LDS buffers -- group i+1 is requested
-  // before group i's MFMAs and written behind them -- and the next stage's input is requested in front of
-  // the LAST group's MFMAs, so that no weight load ever queues behind the HBM-latency prefetch.
-  constexpr bool DB = WV > 4;
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int TW = p.tw, TPIX = p.tw * p.th;
@@ -319,7 +315,7 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
   unsigned char* Xlo = Xhi + IG_LO_OFF;
   unsigned char* Whi = smem + (size_t)x_cap * REC;
   unsigned char* Wlo = Whi + IG_LO_OFF;
-  int* taptab = (int*)(Whi + (size_t)(DB ? 2 : 1) * p.tg * CO_TILE * REC);   // [ntaps], behind the weight slabs
+  int* taptab = (int*)(Whi + (size_t)p.tg * CO_TILE * REC);   // [ntaps], behind the weight slab
   float* sbias = (float*)(taptab + 64);   // [CO_TILE] bias of the tile being finished (host adds 512 B in all)
   float* sred = (float*)smem;   // [4 waves][CO_TILE][2], reused between a tile's last MFMA and the next commit
 
@@ -370,24 +366,41 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
     // stage's other loads, so its wait never drains them
     float bias_r = 0.f;
     if (chunk == p.nchunks - 1 && p.bias && tid < CO_TILE) bias_r = p.bias[min(g.cot * CO_TILE + tid, p.cout - 1)];
+    // (pinned behind the commit: hoisted above it into one memory clause, the two parked weight groups were live next
+    // to the 64 prefetch registers and the kernel spilled)
+    __builtin_amdgcn_sched_barrier(0);
     // first weight group: its loads go out BEFORE the next stage's input prefetch (vmcnt retires in order:
     // behind the prefetch they would not be usable until all of it has landed)
     const long long slab = (long long)CO_TILE * (REC / 2);
     const uint16_t* wsrc = p.wpack + ((long long)g.cot * p.nchunks + chunk) * p.ntaps * slab;
+    // (an opaque zero in the lane index of the weight copies: their per-lane vector indices and LDS addresses are
+    // loop-invariant, were hoisted out of the stage loop -- three groups' worth -- and spilled; every reload sat in
+    // front of a load or an LDS write with an s_waitcnt vmcnt(0) that drained the prefetch)
+    const int tidw = tid + opaque_zero();
     WPass<false, WS> wp0;
     const int nvec0 = min(p.tg, p.ntaps) * CO_TILE * RECV;
-    wcopy_issue<false, WS>(wp0, (const uint4*)wsrc, nullptr, nvec0, 0, tid);
+    wcopy_issue<false, WS>(wp0, (const uint4*)wsrc, nullptr, nvec0, 0, tidw);
     // second weight group (more taps than one LDS slab holds): requested here too, IN FRONT of the input prefetch, and
     // parked in registers until the first group's MFMAs are done.  Requested behind the prefetch (vmcnt retires in
     // order) its wait was a wait for the whole next input tile to arrive from HBM, in the middle of every stage.
     // Unconditional (a single-group plan re-reads one vector of group 0): a branch around loads would turn the
     // counted waits below into vmcnt(0).
+    // Weight groups (more taps than one LDS slab holds) are requested IN FRONT of the next stage's input prefetch and
+    // parked in registers until the slab is free: requested behind the prefetch (vmcnt retires in order) a group's wait
+    // was a wait for the whole next input tile to arrive from HBM, in the middle of every stage.
+    //  * 32-row tiles (two groups: 7 + 2 taps of a 3x3 layer): both groups go out here, the prefetch follows;
+    //  * 64-row tiles (three groups of 3 taps; no registers for two parked groups next to the 64 prefetch registers):
+    //    groups 0 and 1 go out here, group 2 and THEN the prefetch right after group 0's MFMAs, when group 0's
+    //    registers are free again -- the prefetch is still in flight for two thirds of the stage.
+    // The loads are unconditional (a plan with fewer groups re-reads one vector): a branch around loads would turn the
+    // counted waits below into vmcnt(0).  Groups past the third are copied in place (latency exposed; 16-tap layers).
+    constexpr bool DEFER = CO_BLKS == 2;
+    const int ngrp = (p.ntaps + p.tg - 1) / p.tg;
     WPass<false, WS> wp1;
-    const bool two = !DB && CO_BLKS == 1 && p.ntaps > p.tg;   // (64-row tiles: no registers to spare)
-    const int nvec1 = two ? min(p.tg, p.ntaps - p.tg) * CO_TILE * RECV : 1;
-    if (!DB && CO_BLKS == 1) {
-      const uint16_t* src1 = wsrc + (two ? (long long)p.tg * slab : 0);
-      wcopy_issue<false, WS>(wp1, (const uint4*)src1, nullptr, nvec1, 0, tid);
+    const int nvec1 = ngrp > 1 ? min(p.tg, p.ntaps - p.tg) * CO_TILE * RECV : 1;
+    {
+      const uint16_t* src1 = wsrc + (ngrp > 1 ? (long long)p.tg * slab : 0);
+      wcopy_issue<false, WS>(wp1, (const uint4*)src1, nullptr, nvec1, 0, tidw);
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -404,7 +417,7 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
       else xfast_issue<PF>(pre, p.x, ng.n, p.cin, nhave ? nchunk : 0, p.in_h, p.in_w, p.in_shift, p.in_row, ng.oy0,
                            ng.ox0, ng.tw, nhave ? ng.npix : 0, 4, tid);
     };
-    if (!DB) issue_next();
+    if (!DEFER) issue_next();
     DBG_CLK(2)
 
     if (chunk == 0) {
@@ -420,43 +433,12 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
     for (int pb = 0; pb < NPB; ++pb)
       bbase[pb] = ((pty[pb] * p.in_step) * g.tw + ptx[pb] * p.in_step) * REC + h * 16;
 
-    // weight groups of p.tg taps (<= 256*WV vectors per plane: one copy pass)
-    wcopy_commit<false, WS>(wp0, Whi, nullptr, nvec0, 0, tid);
-    DBG_CLK(3)
-    __syncthreads();
-    DBG_CLK(4)
-    const size_t wbuf_bytes = (size_t)p.tg * CO_TILE * REC;
-    for (int t0 = 0, gi = 0; t0 < p.ntaps; t0 += p.tg, ++gi) {
-      const int tgc = min(p.tg, p.ntaps - t0);
-      const bool more = t0 + p.tg < p.ntaps;
-      const int nvecn = min(p.tg, p.ntaps - (t0 + p.tg)) * CO_TILE * RECV;
-      if (!DB && t0 > 0) {
-        __syncthreads();
-        if (CO_BLKS == 1 && gi == 1) {   // the group parked in registers since the top of the stage
-          wcopy_commit<false, WS>(wp1, Whi, nullptr, nvec1, 0, tid);
-        } else {         // third and later groups: loaded behind the X prefetch, latency exposed
-          const uint16_t* src = wsrc + (long long)t0 * slab;
-          wcopy<false, WS>(Whi, nullptr, (const uint4*)src, nullptr, tgc * CO_TILE * RECV, 0, tid);
-        }
-        DBG_CLK(3)
-        __syncthreads();
-        DBG_CLK(4)
-      }
-      if (DB) {
-        if (more) {
-          const uint16_t* src = wsrc + (long long)(t0 + p.tg) * slab;
-          wcopy_issue<false, WS>(wp0, (const uint4*)src, nullptr, nvecn, 0, tid);
-        } else {
-          issue_next();
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      const unsigned char* Wh = Whi + (DB ? (gi & 1) * wbuf_bytes : 0);
-      const unsigned char* Wl = Wlo + (DB ? (gi & 1) * wbuf_bytes : 0);
-      // (Operand prefetch across k-steps was tried twice and reverted: two full fragment sets spilled 41-109 registers
-      // next to the 64 prefetch registers; a rotating form -- weights one step ahead in a second set, each pixel block's
-      // input fragments re-read under the other block's MFMAs -- fit, and measured 4 % SLOWER on the 3x3 layers: with two
-      // waves per SIMD the partner wave already covers the LDS round trip, and the schedule fences cost more.)
+    // MFMA phase of one weight group (taps t0 .. t0 + tgc - 1, resident in the slab).
+    // (Operand prefetch across k-steps was tried twice and reverted: two full fragment sets spilled 41-109 registers
+    // next to the 64 prefetch registers; a rotating form -- weights one step ahead in a second set, each pixel block's
+    // input fragments re-read under the other block's MFMAs -- fit, and measured 4 % SLOWER on the 3x3 layers: with two
+    // waves per SIMD the partner wave already covers the LDS round trip, and the schedule fences cost more.)
+    auto mfma_group = [&](int t0, int tgc) {
       int tv = taptab[t0];
       for (int tl = 0; tl < tgc; ++tl) {
         const int tcur = tv;
@@ -483,8 +465,8 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
             bf16x8 ah[CO_BLKS], al[CO_BLKS], bh[NPB], bl[NPB];
 #pragma unroll
             for (int cb = 0; cb < CO_BLKS; ++cb) {
-              ah[cb] = lds_frag(Wh + abase + cb * 32 * REC + ks * 32);
-              if (X3) al[cb] = lds_frag(Wl + abase + cb * 32 * REC + ks * 32);
+              ah[cb] = lds_frag(Whi + abase + cb * 32 * REC + ks * 32);
+              if (X3) al[cb] = lds_frag(Wlo + abase + cb * 32 * REC + ks * 32);
             }
 #pragma unroll
             for (int pb = 0; pb < NPB; ++pb) {
@@ -504,13 +486,47 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
           }
         }
       }
+    };
+
+    wcopy_commit<false, WS>(wp0, Whi, nullptr, nvec0, 0, tidw);
+    DBG_CLK(3)
+    __syncthreads();
+    DBG_CLK(4)
+    mfma_group(0, min(p.tg, p.ntaps));
+    DBG_CLK_ACC(5)
+    const int nvec2 = ngrp > 2 ? min(p.tg, p.ntaps - 2 * p.tg) * CO_TILE * RECV : 1;
+    if (ngrp > 1) {   // uniform
+      __syncthreads();
+      wcopy_commit<false, WS>(wp1, Whi, nullptr, nvec1, 0, tidw);   // parked since the top of the stage
+      if (DEFER) {
+        __builtin_amdgcn_sched_barrier(0);   // (group 2's loads stay behind group 1's LDS writes: its registers are free then)
+        const uint16_t* src2 = wsrc + (ngrp > 2 ? 2ll * p.tg * slab : 0);
+        wcopy_issue<false, WS>(wp0, (const uint4*)src2, nullptr, nvec2, 0, tidw);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_next();
+      }
+      DBG_CLK(3)
+      __syncthreads();
+      DBG_CLK(4)
+      mfma_group(p.tg, min(p.tg, p.ntaps - p.tg));
       DBG_CLK_ACC(5)
-      if (DB && more) {
-        wcopy_commit<false, WS>(wp0, Whi + ((gi + 1) & 1) * wbuf_bytes, nullptr, nvecn, 0, tid);
+      for (int t0 = 2 * p.tg, gi = 2; t0 < p.ntaps; t0 += p.tg, ++gi) {
+        const int tgc = min(p.tg, p.ntaps - t0);
+        __syncthreads();
+        if (DEFER && gi == 2) {
+          wcopy_commit<false, WS>(wp0, Whi, nullptr, nvec2, 0, tidw);   // requested in front of the prefetch
+        } else {
+          const uint16_t* src = wsrc + (long long)t0 * slab;
+          wcopy<false, WS>(Whi, nullptr, (const uint4*)src, nullptr, tgc * CO_TILE * RECV, 0, tidw);
+        }
         DBG_CLK(3)
         __syncthreads();
         DBG_CLK(4)
+        mfma_group(t0, tgc);
+        DBG_CLK_ACC(5)
       }
+    } else if (DEFER) {
+      issue_next();   // single group: the prefetch goes out behind the stage's MFMAs
     }
 
     DBG_CLK(6)
