@@ -801,7 +801,9 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
     if (CLAMP && tid < RECV) *(uint4*)(Xhi + (size_t)g.npix * REC + tid * 16) = make_uint4(0, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     // the stage's (first) weight group, with nothing else in the load queue: one L2 round trip.  (Requested
-    // before the X commit its 48 registers were spilled to scratch one load at a time.)
+    // before the X commit its 48 registers were spilled to scratch one load at a time.  Parking the second group in
+    // registers in front of the prefetch, as igemm_pipe_kernel does, measured neutral to 9 % slower here: the 16-tap
+    // layers' groups are 44 registers each, and the one-group 3x3 layers only pay for the extra loads.)
     const long long slab = (long long)CO_TILE * (REC / 2);
     const uint16_t* wsrc = p.wpack + ((long long)g.cot * p.nchunks + chunk) * p.ntaps * slab;
     const int nvec0 = min(p.tg, p.ntaps) * CO_TILE * RECV;
