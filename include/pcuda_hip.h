@@ -97,8 +97,9 @@ typedef struct pcuda_dst {
 /* packed-weight sizes (bytes) for a given geometry / precision */
 size_t pcuda_conv2d_packed_fwd_bytes(const pcuda_conv_geom* g, int prec);
 size_t pcuda_conv2d_packed_dgrad_bytes(const pcuda_conv_geom* g, int prec);
-/* repack fp32 OIHW weights into the MFMA-fragment layout ([co-tile][ci-chunk][tap][row][32+8]
- * bf16 hi (+lo)); call once per optimiser step */
+/* repack fp32 OIHW weights into the MFMA-fragment layout [co-tile][ci-chunk][tap][row][record]; record =
+ * 32 hi | 32 lo | 8 pad bf16 (144 bytes) in PCUDA_PREC_BF16X3, 32 values + 8 pad (80 bytes) in PCUDA_PREC_BF16.
+ * Opaque to the caller (sizes from the two queries above); call once per optimiser step */
 int pcuda_conv2d_pack_fwd(const pcuda_conv_geom* g, int prec, const float* w, void* packed, pcuda_stream_t s);
 int pcuda_conv2d_pack_dgrad(const pcuda_conv_geom* g, int prec, const float* w, void* packed, pcuda_stream_t s);
 /* both repacks in ONE launch (forward layout + every dgrad parity class); packed_dgrad may be NULL */

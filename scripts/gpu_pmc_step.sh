@@ -3,10 +3,10 @@
 # no trace domains; summary -> gpurun_out/<TAG>_pmc_traffic.csv (copy to profiles/)
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-TAG=${TAG:-r01}
+TAG=${TAG:-r02}
 rm -rf gpurun_out/pmc; mkdir -p gpurun_out/pmc
 for c in FETCH_SIZE WRITE_SIZE; do
-  PCUDA_DSTREAMS=0 timeout ${PMC_TIMEOUT:-500} rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc/$c -o $TAG -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/pmc_${c}_$TAG.log 2>&1
+  PCUDA_DSTREAMS=0 timeout ${PMC_TIMEOUT:-500} rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc/$c -o $TAG -- python3 bench.py --steps 2 --warmup 1 --settle 2 --no-cpu-baseline --no-roofline > gpurun_out/pmc_${c}_$TAG.log 2>&1
   echo "$c pass rc=$?"; tail -1 gpurun_out/pmc_${c}_$TAG.log | cut -c1-120
 done
 python3 - <<'PY'
