@@ -1,0 +1,255 @@
+// Direct (vector-ALU) kernels for the discriminators' first layer: cin <= 8 class / entropy maps -> 64 channels,
+// 4x4, stride 2, pad 2 (GAN.py:97).  On the MFMA kernels 4 or 5 of a 32-deep chunk's channels carry data: its data
+// gradient ran at 17 TFLOP/s in four stride-parity launches, its weight gradient at 20 TFLOP/s (0.45 ms).  Here both
+// are fp32 FMA loops; dispatched inside pcuda_conv2d_dgrad / pcuda_conv2d_wgrad like the kernels of conv_direct.hip
+// (same ABI, same packed weights: w = hi + lo; PCUDA_NODIRECT=1 switches them off).  Fixed reduction order.
+#include <stdlib.h>
+
+#include "conv_host.h"
+#include "conv_igemm.h"
+
+namespace {
+
+__device__ __forceinline__ float bf16_bits_to_float(uint16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
+
+bool direct_enabled() {
+  static int off = -1;
+  if (off < 0) { const char* e = getenv("PCUDA_NODIRECT"); off = (e && atoi(e)) ? 1 : 0; }
+  return off == 0;
+}
+bool aligned16(const void* p, long long sn, long long sc) { return (((uintptr_t)p) & 15) == 0 && (sn & 3) == 0 && (sc & 3) == 0; }
+
+struct D1Params {
+  const float* dz; long long dz_sn, dz_sc;    // [n][cout][oh][ow]
+  const float* x; long long x_sn, x_sc;       // wgrad: [n][cin][h][w]
+  float* dx; long long dx_sn, dx_sc;          // dgrad: [n][cin][h][w]
+  const uint16_t* wpack; int rec;             // dgrad: packed parity-class layouts (below)
+  float* partial;                             // wgrad: [blocks][cout * cin * 16]
+  int accumulate;
+  int n, h, w, oh, ow, cin, cout;
+  long long cls_stride;                       // dgrad: bf16 elements between the four parity-class images
+};
+
+// data gradient.  A 2x2 block of input pixels (2Y + py, 2X + px) sees the same four gradient pixels (Y + a, X + b),
+// a, b in {0, 1}, through the taps ky = py + 2(1 - a), kx = px + 2(1 - b).  A thread owns 4 consecutive X (two rows of
+// 8 input pixels) for ALL input channels: per output channel 10 gradient values, CIN * 64 FMAs.
+// Packed dgrad weights (conv_igemm.hip, pcuda_conv2d_pack_dgrad): one image per parity class (ry, rx), rows = cin (one
+// 32-row tile), reduction = cout in 32-deep chunks, taps = the class's (ky, kx) with ky = ry, kx = rx (mod 2), ky
+// ascending then kx ascending: element (co, ci, t) at (((co / 32) * 4 + t) * 32 + ci) * rec + co % 32.
+template <int CIN>
+__global__ __launch_bounds__(256) void d1_dgrad_kernel(const D1Params p) {
+  __shared__ float sw[64 * CIN * 16];   // [co][ci][ky][kx]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < p.cout * CIN * 16; i += 256) {
+    const int kx = i & 3, ky = (i >> 2) & 3, ci = (i >> 4) % CIN, co = i / (16 * CIN);
+    const int ry = ky & 1, rx = kx & 1, t = (ky >> 1) * 2 + (kx >> 1);
+    const long long idx = (long long)(ry * 2 + rx) * p.cls_stride +
+                          ((((long long)(co >> 5)) * 4 + t) * 32 + ci) * p.rec + (co & 31);
+    float v = bf16_bits_to_float(p.wpack[idx]);
+    if (p.rec > IG_REC) v += bf16_bits_to_float(p.wpack[idx + 32]);
+    sw[i] = v;
+  }
+  __syncthreads();
+  const int n = blockIdx.y;
+  const int xg = p.w >> 3;                              // groups of 4 X (8 input pixels) per row
+  const int item = blockIdx.x * 256 + tid;
+  if (item >= xg * (p.h >> 1)) return;
+  const int Y = item / xg, X0 = 4 * (item - Y * xg);
+  float acc[CIN][2][8];
+#pragma unroll
+  for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[ci][r][e] = 0.f;
+  const float* zp = p.dz + (long long)n * p.dz_sn + (long long)Y * p.ow + X0;
+  for (int co = 0; co < p.cout; ++co) {
+    float z[2][5];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 5; ++b) z[a][b] = zp[(long long)co * p.dz_sc + a * p.ow + b];
+    const float* wc = sw + co * CIN * 16;
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+      for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int px = 0; px < 2; ++px)
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              const float wv = wc[(ci * 4 + py + 2 * (1 - a)) * 4 + px + 2 * (1 - b)];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[ci][py][2 * j + px] = fmaf(wv, z[a][j + b], acc[ci][py][2 * j + px]);
+            }
+  }
+#pragma unroll
+  for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      float* d = p.dx + (long long)n * p.dx_sn + (long long)ci * p.dx_sc + (long long)(2 * Y + r) * p.w + 2 * X0;
+      f32x4 o0 = {acc[ci][r][0], acc[ci][r][1], acc[ci][r][2], acc[ci][r][3]};
+      f32x4 o1 = {acc[ci][r][4], acc[ci][r][5], acc[ci][r][6], acc[ci][r][7]};
+      if (p.accumulate) {
+        const f32x4 q0 = *(const f32x4*)d, q1 = *(const f32x4*)(d + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o0[e] += q0[e]; o1[e] += q1[e]; }
+      }
+      *(f32x4*)d = o0;
+      *(f32x4*)(d + 4) = o1;
+    }
+}
+
+// weight gradient.  256 threads own the cout * cin * 16 <= 64 * 4 * 16 sums: thread -> (4 output channels, one
+// (ci, ky), the four kx).  A persistent workgroup walks (image, output row) items: the row of dz (all channels) and
+// the four input rows it meets are staged in LDS (zero halo), then 4 output pixels per iteration = 64 FMAs against
+// seven 16-byte LDS reads.  Block partials + fixed-order reduce.
+#define D1_ZP 132    // dz row pitch in LDS (up to 129 + pad to 16 B)
+#define D1_XP 272    // x row pitch: 2 zero columns left, up to 256 + 2 right, read 12 wide per 4 output pixels
+template <int CIN>
+__global__ __launch_bounds__(256) void d1_wgrad_kernel(const D1Params p, const int items) {
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  float* sz = smem_f;                       // [64][D1_ZP]
+  float* sx = smem_f + 64 * D1_ZP;          // [CIN][4 rows][D1_XP]
+  const int tid = threadIdx.x;
+  const int cg = tid >> 4, jg = tid & 15;   // 4 output channels; (ci, ky)
+  const int ci = jg >> 2, ky = jg & 3;
+  const bool live = ci < CIN;
+  float acc[4][4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[c][k] = 0.f;
+  const int ow4 = (p.ow + 3) >> 2;
+  for (int it = blockIdx.x; it < items; it += gridDim.x) {
+    const int n = it / p.oh, oy = it - n * p.oh;
+    __syncthreads();
+    for (int i = tid; i < 64 * D1_ZP; i += 256) {
+      const int co = i / D1_ZP, c = i - co * D1_ZP;
+      sz[i] = (c < p.ow && co < p.cout) ? p.dz[(long long)n * p.dz_sn + (long long)co * p.dz_sc + (long long)oy * p.ow + c] : 0.f;
+    }
+    for (int i = tid; i < CIN * 4 * D1_XP; i += 256) {
+      const int c = i % D1_XP, r = (i / D1_XP) & 3, cc = i / (4 * D1_XP);
+      const int yy = 2 * oy + r - 2, xx = c - 2;
+      const bool ok = (unsigned)yy < (unsigned)p.h && (unsigned)xx < (unsigned)p.w;
+      sx[i] = ok ? p.x[(long long)n * p.x_sn + (long long)cc * p.x_sc + (long long)yy * p.w + xx] : 0.f;
+    }
+    __syncthreads();
+    if (live) {
+      const float* xr = sx + (ci * 4 + ky) * D1_XP;
+      for (int q = 0; q < ow4; ++q) {
+        // output pixels ox = 4q .. 4q+3 meet input columns 2ox + kx - 2 (+2 halo) = 8q + 2j + kx, j < 4
+        const f32x4 x0 = *(const f32x4*)(xr + 8 * q), x1 = *(const f32x4*)(xr + 8 * q + 4), x2 = *(const f32x4*)(xr + 8 * q + 8);
+        const float xv[12] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3], x2[0], x2[1], x2[2], x2[3]};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 z = *(const f32x4*)(sz + (cg * 4 + c) * D1_ZP + 4 * q);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) acc[c][kx] = fmaf(z[j], xv[2 * j + kx], acc[c][kx]);
+        }
+      }
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) {
+        const int co = cg * 4 + c;
+        if (co < p.cout) p.partial[(long long)blockIdx.x * (p.cout * CIN * 16) + ((co * CIN + ci) * 4 + ky) * 4 + kx] = acc[c][kx];
+      }
+  }
+}
+
+__global__ void d1_wgrad_reduce_kernel(const float* partial, int nblocks, int numel, float* dw, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= numel) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += (double)partial[(long long)b * numel + i];   // fixed order
+  dw[i] = (accumulate ? dw[i] : 0.f) + (float)s;
+}
+
+bool d1_geom(const pcuda_conv_geom* g) {
+  return g->k == 4 && g->stride == 2 && g->pad == 2 && g->dil == 1 && !g->in_up && g->cin <= 5 && g->cout <= 64 &&
+         (g->cout & 3) == 0 && (g->in_w & 7) == 0 && (g->in_h & 1) == 0 && g->in_w <= 256 && g->out_w <= 129;
+}
+const int D1_WG_BLOCKS = 768;   // persistent grid of the weight gradient (3 workgroups per CU: ~50 KB of LDS each)
+
+}  // namespace
+
+int direct_d1_dgrad(const pcuda_conv_geom* g, int prec, const pcuda_src* dy, const void* packed_w_dgrad, const pcuda_dst* dx,
+                    int accumulate, size_t cls_elems, hipStream_t s, int* rc) {
+  *rc = PCUDA_OK;
+  if (!direct_enabled() || !d1_geom(g) || dy->scale1 || dy->c1 < g->cout || dx->c1 < g->cin) return 0;
+  if (!aligned16(dx->p1, dx->sn1, dx->sc1)) return 0;
+  D1Params p;
+  memset(&p, 0, sizeof(p));
+  p.dz = dy->p1; p.dz_sn = dy->sn1; p.dz_sc = dy->sc1;
+  p.dx = dx->p1; p.dx_sn = dx->sn1; p.dx_sc = dx->sc1;
+  p.wpack = (const uint16_t*)packed_w_dgrad; p.rec = ig_rec_bytes(prec == PCUDA_PREC_BF16X3) / 2;
+  p.cls_stride = (long long)cls_elems;
+  p.accumulate = accumulate;
+  p.n = g->n; p.h = g->in_h; p.w = g->in_w; p.oh = g->out_h; p.ow = g->out_w; p.cin = g->cin; p.cout = g->cout;
+  const double flops = 2.0 * g->n * (double)g->out_h * g->out_w * g->cout * (double)g->cin * 16;
+  char tag[96];
+  snprintf(tag, sizeof(tag), "direct d1 dgrad n%d cin%d cout%d %dx%d", g->n, g->cin, g->cout, g->in_h, g->in_w);
+  ProfScope prof(PCUDA_FAM_CONV_FWD, flops, s, tag);
+  const dim3 grid(cdiv((long long)(g->in_w / 8) * (g->in_h / 2), 256), g->n);
+  switch (g->cin) {
+    case 1: hipLaunchKernelGGL(d1_dgrad_kernel<1>, grid, dim3(256), 0, s, p); break;
+    case 2: hipLaunchKernelGGL(d1_dgrad_kernel<2>, grid, dim3(256), 0, s, p); break;
+    case 3: hipLaunchKernelGGL(d1_dgrad_kernel<3>, grid, dim3(256), 0, s, p); break;
+    case 4: hipLaunchKernelGGL(d1_dgrad_kernel<4>, grid, dim3(256), 0, s, p); break;
+    default: hipLaunchKernelGGL(d1_dgrad_kernel<5>, grid, dim3(256), 0, s, p); break;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { pcuda_set_error("d1_dgrad_kernel: %s", hipGetErrorString(e)); *rc = PCUDA_E_LAUNCH; }
+  return 1;
+}
+
+size_t direct_d1_wgrad_workspace(const pcuda_conv_geom* g) {
+  if (!d1_geom(g) || g->cin > 4) return 0;
+  return (size_t)D1_WG_BLOCKS * g->cout * g->cin * 16 * sizeof(float) + 256;
+}
+
+int direct_d1_wgrad(const pcuda_conv_geom* g, const pcuda_src* x, const float* dz, long long dz_sn, long long dz_sc, float* dw,
+                    float* db, int accumulate, void* workspace, hipStream_t s, int* rc) {
+  *rc = PCUDA_OK;
+  if (!direct_enabled() || !d1_geom(g) || g->cin > 4 || x->scale1 || x->c1 < g->cin || db) return 0;
+  D1Params p;
+  memset(&p, 0, sizeof(p));
+  p.dz = dz; p.dz_sn = dz_sn; p.dz_sc = dz_sc;
+  p.x = x->p1; p.x_sn = x->sn1; p.x_sc = x->sc1;
+  p.partial = (float*)workspace;
+  p.n = g->n; p.h = g->in_h; p.w = g->in_w; p.oh = g->out_h; p.ow = g->out_w; p.cin = g->cin; p.cout = g->cout;
+  const int items = g->n * g->out_h;
+  const int blocks = items < D1_WG_BLOCKS ? items : D1_WG_BLOCKS;
+  const size_t lds = (size_t)(64 * D1_ZP + g->cin * 4 * D1_XP) * sizeof(float);
+  const double flops = 2.0 * g->n * (double)g->out_h * g->out_w * g->cout * (double)g->cin * 16;
+  char tag[96];
+  snprintf(tag, sizeof(tag), "direct d1 wgrad n%d cin%d cout%d %dx%d", g->n, g->cin, g->cout, g->in_h, g->in_w);
+  ProfScope prof(PCUDA_FAM_CONV_WGRAD, flops, s, tag);
+  const int numel = g->cout * g->cin * 16;
+#define D1_WG_LAUNCH(C_)                                                                                              \
+  {                                                                                                                   \
+    static bool set_ = false;                                                                                         \
+    if (!set_) { (void)hipFuncSetAttribute((const void*)d1_wgrad_kernel<C_>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); set_ = true; } \
+    hipLaunchKernelGGL(d1_wgrad_kernel<C_>, dim3(blocks), dim3(256), lds, s, p, items);                               \
+  }
+  switch (g->cin) {
+    case 1: D1_WG_LAUNCH(1) break;
+    case 2: D1_WG_LAUNCH(2) break;
+    case 3: D1_WG_LAUNCH(3) break;
+    default: D1_WG_LAUNCH(4) break;
+  }
+#undef D1_WG_LAUNCH
+  hipLaunchKernelGGL(d1_wgrad_reduce_kernel, dim3(cdiv(numel, 256)), dim3(256), 0, s, (const float*)workspace, blocks, numel,
+                     dw, accumulate);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { pcuda_set_error("d1_wgrad_kernel: %s", hipGetErrorString(e)); *rc = PCUDA_E_LAUNCH; }
+  return 1;
+}

@@ -145,3 +145,8 @@ int direct_dgrad(const pcuda_conv_geom* g, int prec, const pcuda_src* dy, const 
 size_t direct_wgrad_workspace(const pcuda_conv_geom* g);
 int direct_wgrad(const pcuda_conv_geom* g, const pcuda_src* x, const float* dz, long long dz_sn, long long dz_sc, float* dw,
                  float* db, int accumulate, void* workspace, hipStream_t s, int* rc);
+int direct_d1_dgrad(const pcuda_conv_geom* g, int prec, const pcuda_src* dy, const void* packed_w_dgrad, const pcuda_dst* dx,
+                    int accumulate, size_t cls_elems, hipStream_t s, int* rc);
+size_t direct_d1_wgrad_workspace(const pcuda_conv_geom* g);
+int direct_d1_wgrad(const pcuda_conv_geom* g, const pcuda_src* x, const float* dz, long long dz_sn, long long dz_sc, float* dw,
+                    float* db, int accumulate, void* workspace, hipStream_t s, int* rc);

@@ -191,7 +191,8 @@ int plan_igemm_mode(int rows, int lh, int lw, int in_h, int in_w, int in_step, c
         // the eight-wave kernel needs 8 or 16 MFMA tiles per stage and an input tile of <= 2 slots per lane
         int mode = mode_env;
         if (mode == 2) {
-          const int ihc = pl.ih_t < in_h ? pl.ih_t : in_h;
+          // (only a clamped tile is clipped to the image; an unclamped one stages every halo row, image or padding)
+          const int ihc = (pl.clamp && pl.ih_t > in_h) ? in_h : pl.ih_t;
           const bool fits = pl.x_cap <= 1024 && ihc * ((pl.iw_t + 6) / 4) <= 256;
           if (!fits || (npb == 1 && co_tile == 32)) mode = 0;
         }
@@ -273,7 +274,7 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
   {   // quad staging: rows of 4k pixels, no upsampling fold, (rows x quads) of a tile in <= 3 x 64 lanes
     static int noxq = -1;
     if (noxq < 0) { const char* e = getenv("PCUDA_NOXQ"); noxq = e ? atoi(e) : 0; }
-    const int ih = pl.ih_t < p.in_h ? pl.ih_t : p.in_h;
+    const int ih = (pl.clamp && pl.ih_t > p.in_h) ? p.in_h : pl.ih_t;   // rows the kernel stages (unclamped: all of the halo)
     const int pfq = (ih * ((pl.iw_t + 6) / 4) + 63) / 64;
     p.xq = (!noxq && (p.in_w & 3) == 0 && p.in_shift == 0 && pfq <= 3) ? 1 : 0;
     if (p.xq) pf = pfq;
@@ -422,6 +423,8 @@ extern "C" int pcuda_conv2d_dgrad(const pcuda_conv_geom* g, int prec, const pcud
   {
     int rc;
     if (direct_dgrad(g, prec, dy, packed_w_dgrad, dx, accumulate, (hipStream_t)s, &rc)) return rc;
+    if (direct_d1_dgrad(g, prec, dy, packed_w_dgrad, dx, accumulate, packed_elems(g->cin, g->cout, 4, prec), (hipStream_t)s, &rc))
+      return rc;
   }
   const uint16_t* wp = (const uint16_t*)packed_w_dgrad;
   const int st = g->stride;

@@ -109,7 +109,9 @@ extern "C" size_t pcuda_conv2d_wgrad_workspace_size(const pcuda_conv_geom* g) {
   if (!geom_ok(g)) return 0;
   WgradPlan w = plan_wgrad(g);
   const size_t need = ((size_t)w.ksplit * g->cout * g->cin * g->k * g->k + (size_t)w.ksplit * g->cout) * sizeof(float) + 256;
-  const size_t dneed = direct_wgrad_workspace(g);
+  size_t dneed = direct_wgrad_workspace(g);
+  const size_t d1need = direct_d1_wgrad_workspace(g);
+  if (d1need > dneed) dneed = d1need;
   return need > dneed ? need : dneed;
 }
 
@@ -131,6 +133,7 @@ extern "C" int pcuda_conv2d_wgrad(const pcuda_conv_geom* g, int prec, const pcud
   {
     int rc;
     if (direct_wgrad(g, x, dy, dy_sn, dy_sc, dw, db, accumulate, workspace, s, &rc)) return rc;
+    if (direct_d1_wgrad(g, x, dy, dy_sn, dy_sc, dw, db, accumulate, workspace, s, &rc)) return rc;
   }
   const bool x3 = prec == PCUDA_PREC_BF16X3;
   WgradPlan w = plan_wgrad(g);

@@ -555,6 +555,19 @@ extern "C" int pcuda_lrelu_bwd(const float* dy, long long dy_sn, long long dy_sc
                                pcuda_stream_t s) {
   if (!dims_ok(n, c, hw) || !dy || !a || !dz) PCUDA_FAIL(PCUDA_E_BADARG, "lrelu_bwd: bad arguments");
   ProfScope prof(PCUDA_FAM_POINTWISE, (dy2 ? 16.0 : 12.0) * n * c * (double)hw, (hipStream_t)s);
+  // dense tensors are ONE run of n*c*hw elements for this element-wise op: the discriminators' odd planes (129x129,
+  // 65x65 ...) fail the per-plane float4 test, and the scalar form ran at a quarter of the vector rate
+  auto dense = [&](const void* q, long long sn_, long long sc_) {
+    return q == nullptr || ((((uintptr_t)q) & 15) == 0 && sc_ == hw && sn_ == (long long)c * hw);
+  };
+  const long long total = (long long)n * c * hw;
+  if ((hw & 3) && (total & 3) == 0 && dense(dy, dy_sn, dy_sc) && dense(dy2, dy2_sn, dy2_sc) && dense(a, a_sn, a_sc) &&
+      dense(dz, dz_sn, dz_sc)) {
+    hipLaunchKernelGGL(lrelu_bwd_kernel<4>, plane_grid(1, 1, total), dim3(256), 0, (hipStream_t)s, dy, total, total, dy2,
+                       total, total, a, total, total, slope, dz, total, total, total);
+    PCUDA_CHECK_LAUNCH("lrelu_bwd_kernel");
+    return PCUDA_OK;
+  }
   if (vec_ok(dy, dy_sn, dy_sc, hw) && vec_ok(dy2, dy2_sn, dy2_sc, hw) && vec_ok(a, a_sn, a_sc, hw) &&
       vec_ok(dz, dz_sn, dz_sc, hw))
     hipLaunchKernelGGL(lrelu_bwd_kernel<4>, plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, dy, dy_sn, dy_sc, dy2,

@@ -77,3 +77,31 @@ def test_classifier_forward_and_dgrad(dev, shape):
     op.dgrad(gz.to(dev), w.to(dev), h, w_, dx=d1, dx2=d2, accumulate=False)
     got = d1 if d2 is None else torch.cat([d1, d2], 1)
     assert rel_err(got, xin.grad) < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 64, 64, 64), (3, 5, 64, 32, 48), (2, 4, 32, 256, 256), (2, 1, 64, 16, 24)])
+def test_discriminator_first_layer_dgrad_and_wgrad(dev, shape):
+    """cin <= 5 -> 64 channels, 4x4, stride 2, pad 2 (GAN.py:97): data gradient (with and without accumulation) and
+    weight gradient (cin <= 4) on the direct kernels, against torch."""
+    from pointcloududa_amd import kernels as K
+    n, cin, cout, h, w_ = shape
+    rng = np.random.default_rng(cin * 1000 + h)
+    x = torch.from_numpy(rng.normal(0, 1, (n, cin, h, w_)).astype(np.float32)).requires_grad_(True)
+    w = torch.from_numpy(rng.normal(0, 0.05, (cout, cin, 4, 4)).astype(np.float32)).requires_grad_(True)
+    z = F.conv2d(x, w, None, stride=2, padding=2)
+    gz = torch.from_numpy(rng.normal(0, 1, z.shape).astype(np.float32))
+    z.backward(gz)
+    op = K.ConvOp(cin, cout, 4, stride=2, pad=2)
+    wd, gzd = w.detach().to(dev), gz.to(dev)
+    y, _, _ = op.forward(x.detach().to(dev), wd, None, 1.0, h, w_)
+    assert rel_err(y, z) < 1e-4
+    dx = op.dgrad(gzd, wd, h, w_)
+    assert rel_err(dx, x.grad) < 1e-4
+    base = torch.full((n, cin, h, w_), 0.5, device=dev)
+    op.dgrad(gzd, wd, h, w_, dx=base, accumulate=True)
+    assert rel_err(base - 0.5, x.grad) < 1e-4
+    dw = torch.full((cout, cin, 4, 4), 3.0, device=dev)
+    op.wgrad(x.detach().to(dev), gzd, dw, None, h, w_, accumulate=False)
+    assert rel_err(dw, w.grad) < 1e-4
+    op.wgrad(x.detach().to(dev), gzd, dw, None, h, w_, accumulate=True)
+    assert rel_err(dw, 2 * w.grad) < 1e-4

@@ -31,6 +31,8 @@ CASES = [
     (2, 128, 1, 9, 9, 4, 2, 2, 1, False, False, 1.0),       # discriminator conv5
     (2, 64, 32, 17, 17, 3, 2, 1, 1, False, False, 0.2),     # ext discriminator 3x3 s2 p1
     (2, 64, 32, 32, 32, 3, 1, 1, 1, True, True, 1.0),       # decoder: nearest x2 folded into the conv
+    (2, 4, 64, 16, 24, 4, 2, 2, 1, False, False, 0.2),      # stride-2 halo tile taller than the image, rows of 4k pixels
+    (2, 8, 32, 12, 16, 3, 1, 1, 1, False, True, 0.01),      # 3x3 on a map shorter than one tile
     (3, 3, 64, 1, 300, 1, 1, 0, 1, False, True, 1.0),       # PointNet conv1d(k=1): H = 1
     (3, 128, 1024, 1, 300, 1, 1, 0, 1, False, True, 1.0),
 ]

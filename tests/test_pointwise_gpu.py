@@ -75,6 +75,13 @@ def test_maxpool_upsample_add(dev):
     a = _rand(rng, 2, 5, 16, 16)
     gy = _rand(rng, 2, 5, 16, 16)
     assert rel_err(K.lrelu_bwd(gy.to(dev), a.to(dev), 0.2), torch.where(a > 0, gy, 0.2 * gy)) < 1e-6
+    # odd planes (the discriminators' 129x129 / 65x65 / 33x33 maps): dense tensors go through the flat float4 path,
+    # a total that is no multiple of 4 through the scalar one, a second gradient source through either
+    for shp in ((4, 3, 33, 33), (4, 8, 17, 17), (1, 3, 9, 9)):
+        a2, g2, g3 = _rand(rng, *shp), _rand(rng, *shp), _rand(rng, *shp)
+        assert rel_err(K.lrelu_bwd(g2.to(dev), a2.to(dev), 0.2), torch.where(a2 > 0, g2, 0.2 * g2)) < 1e-6
+        assert rel_err(K.lrelu_bwd(g2.to(dev), a2.to(dev), 0.2, dy2=g3.to(dev)),
+                       torch.where(a2 > 0, g2 + g3, 0.2 * (g2 + g3))) < 1e-6
     db = torch.zeros(5, device=dev)
     K.channel_sum(gy.to(dev), db, accumulate=False)
     assert rel_err(db, gy.sum((0, 2, 3))) < 1e-5
