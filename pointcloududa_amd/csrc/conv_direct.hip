@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void c1_fwd_kernel(const C1Params p) {
 struct C1WgParams {
   const float* x; long long x_sn;
   const float* dz; long long dz_sn, dz_sc;
-  float* partial;                               // [n * blocks_per_image][cout][10]
+  float* partial;                               // [blocks][cout * 9] tap sums, then [blocks][cout] bias sums
+  long long nblocks;
   int n, h, w, cout;
 };
 
@@ -148,10 +149,20 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(const C1WgParams p) {
     in[r][5] = (rok && x + 4 < p.w) ? rr : 0.f;
   }
   const float* zp = p.dz + (long long)n * p.dz_sn + (long long)y0 * p.w + x;
-  for (int co = 0; co < p.cout; ++co) {
+  // output channels are split over blockIdx.z (twice the workgroups: 512 of them left the chip at two per CU)
+  const int co_lo = (int)((long long)p.cout * blockIdx.z / gridDim.z), co_hi = (int)((long long)p.cout * (blockIdx.z + 1) / gridDim.z);
+  // (the next channel's four rows are requested before this channel's FMAs and reductions: loaded at the top of each
+  // iteration, the loop ran at one memory round trip per channel)
+  f32x4 zn[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) zn[r] = *(const f32x4*)(zp + (long long)co_lo * p.dz_sc + (long long)r * p.w);
+  for (int co = co_lo; co < co_hi; ++co) {
     f32x4 z[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) z[r] = *(const f32x4*)(zp + (long long)co * p.dz_sc + (long long)r * p.w);
+    for (int r = 0; r < 4; ++r) z[r] = zn[r];
+    const int con = min(co + 1, co_hi - 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zn[r] = *(const f32x4*)(zp + (long long)con * p.dz_sc + (long long)r * p.w);
     float part[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) part[k] = 0.f;
@@ -173,23 +184,11 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(const C1WgParams p) {
   }
   __syncthreads();
   const long long blk = (long long)n * gridDim.x + blockIdx.x;
-  for (int i = tid; i < p.cout * 10; i += 256) {
+  for (int i = co_lo * 10 + tid; i < co_hi * 10; i += 256) {
     const float s = ((sred[0][i] + sred[1][i]) + sred[2][i]) + sred[3][i];   // fixed order
-    p.partial[blk * p.cout * 10 + i] = s;
-  }
-}
-
-__global__ void c1_wgrad_reduce_kernel(const float* partial, int nblocks, int cout, float* dw, float* db, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= cout * 10) return;
-  double s = 0.0;
-  for (int b = 0; b < nblocks; ++b) s += (double)partial[(long long)b * cout * 10 + i];   // fixed order
-  const int co = i / 10, k = i - co * 10;
-  if (k < 9) {
-    float* d = dw + co * 9 + k;
-    *d = (accumulate ? *d : 0.f) + (float)s;
-  } else if (db) {
-    db[co] = (accumulate ? db[co] : 0.f) + (float)s;
+    const int co = i / 10, k = i - co * 10;
+    if (k < 9) p.partial[blk * p.cout * 9 + co * 9 + k] = s;
+    else p.partial[p.nblocks * p.cout * 9 + blk * p.cout + co] = s;
   }
 }
 
@@ -437,10 +436,12 @@ int direct_wgrad(const pcuda_conv_geom* g, const pcuda_src* x, const float* dz, 
   char tag[96];
   snprintf(tag, sizeof(tag), "direct c1 wgrad n%d cout%d %dx%d", g->n, g->cout, g->in_h, g->in_w);
   ProfScope prof(PCUDA_FAM_CONV_WGRAD, flops, s, tag);
-  hipLaunchKernelGGL(c1_wgrad_kernel, dim3(bpi, g->n), dim3(256), 0, s, p);
-  hipLaunchKernelGGL(c1_wgrad_reduce_kernel, dim3(cdiv(g->cout * 10, 64)), dim3(64), 0, s, (const float*)workspace, bpi * g->n,
-                     g->cout, dw, db, accumulate);
+  p.nblocks = (long long)bpi * g->n;
+  hipLaunchKernelGGL(c1_wgrad_kernel, dim3(bpi, g->n, g->cout >= 8 ? 2 : 1), dim3(256), 0, s, p);
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { pcuda_set_error("c1_wgrad_kernel: %s", hipGetErrorString(e)); *rc = PCUDA_E_LAUNCH; }
+  if (e != hipSuccess) { pcuda_set_error("c1_wgrad_kernel: %s", hipGetErrorString(e)); *rc = PCUDA_E_LAUNCH; return 1; }
+  // block partials through the split-K reduce of the MFMA weight-gradient kernels (16 waves per 64 outputs, fixed order)
+  const float* pw = (const float*)workspace;
+  *rc = launch_wgrad_reduce(pw, (long long)g->cout * 9, (int)p.nblocks, dw, accumulate, pw + p.nblocks * g->cout * 9, g->cout, db, s);
   return 1;
 }

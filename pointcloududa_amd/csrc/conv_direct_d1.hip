@@ -63,12 +63,24 @@ __global__ __launch_bounds__(256) void d1_dgrad_kernel(const D1Params p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[ci][r][e] = 0.f;
   const float* zp = p.dz + (long long)n * p.dz_sn + (long long)Y * p.ow + X0;
+  // (the next channel's ten gradient values are requested before this channel's FMAs: with the loads at the top of each
+  // iteration the loop ran at one memory round trip per channel)
+  float zn[2][5];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 5; ++b) zn[a][b] = zp[a * p.ow + b];
   for (int co = 0; co < p.cout; ++co) {
     float z[2][5];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 5; ++b) z[a][b] = zp[(long long)co * p.dz_sc + a * p.ow + b];
+      for (int b = 0; b < 5; ++b) z[a][b] = zn[a][b];
+    const int con = min(co + 1, p.cout - 1);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 5; ++b) zn[a][b] = zp[(long long)con * p.dz_sc + a * p.ow + b];
     const float* wc = sw + co * CIN * 16;
 #pragma unroll
     for (int ci = 0; ci < CIN; ++ci)
@@ -107,7 +119,8 @@ __global__ __launch_bounds__(256) void d1_dgrad_kernel(const D1Params p) {
 // the four input rows it meets are staged in LDS (zero halo), then 4 output pixels per iteration = 64 FMAs against
 // seven 16-byte LDS reads.  Block partials + fixed-order reduce.
 #define D1_ZP 132    // dz row pitch in LDS (up to 129 + pad to 16 B)
-#define D1_XP 272    // x row pitch: 2 zero columns left, up to 256 + 2 right, read 12 wide per 4 output pixels
+#define D1_XP 276    // x row pitch: 2 zero columns left, up to 256 + 2 right, read 12 wide per 4 output pixels; 276 = 20 (mod 64):
+                     // the 16 (channel, ky) rows a wave reads together start on different banks (272 put four on each)
 template <int CIN>
 __global__ __launch_bounds__(256) void d1_wgrad_kernel(const D1Params p, const int items) {
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -123,20 +136,62 @@ __global__ __launch_bounds__(256) void d1_wgrad_kernel(const D1Params p, const i
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[c][k] = 0.f;
   const int ow4 = (p.ow + 3) >> 2;
-  for (int it = blockIdx.x; it < items; it += gridDim.x) {
+  // Staging, coalesced and one item ahead: wave w loads rows co = w, w + 4, ... of dz (three 64-lane dword loads per
+  // row) and the four input rows of channel w (one 16-byte load per lane and row); the loads of item i + 1 are in
+  // flight during item i's FMAs.  (A plain strided copy loop issued one load per iteration and waited for it: the
+  // kernel ran at a memory round trip per 256 elements.)
+  const int lane = tid & 63, wv = tid >> 6;
+  float rz[16][3];
+  f32x4 rx[4];
+  auto issue = [&](int it) {
     const int n = it / p.oh, oy = it - n * p.oh;
-    __syncthreads();
-    for (int i = tid; i < 64 * D1_ZP; i += 256) {
-      const int co = i / D1_ZP, c = i - co * D1_ZP;
-      sz[i] = (c < p.ow && co < p.cout) ? p.dz[(long long)n * p.dz_sn + (long long)co * p.dz_sc + (long long)oy * p.ow + c] : 0.f;
+    const float* zb = p.dz + (long long)n * p.dz_sn + (long long)oy * p.ow;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int co = min(wv + 4 * k, p.cout - 1);
+#pragma unroll
+      for (int u = 0; u < 3; ++u) rz[k][u] = zb[(long long)co * p.dz_sc + min(lane + 64 * u, p.ow - 1)];
     }
-    for (int i = tid; i < CIN * 4 * D1_XP; i += 256) {
-      const int c = i % D1_XP, r = (i / D1_XP) & 3, cc = i / (4 * D1_XP);
-      const int yy = 2 * oy + r - 2, xx = c - 2;
-      const bool ok = (unsigned)yy < (unsigned)p.h && (unsigned)xx < (unsigned)p.w;
-      sx[i] = ok ? p.x[(long long)n * p.x_sn + (long long)cc * p.x_sc + (long long)yy * p.w + xx] : 0.f;
+    const float* xb = p.x + (long long)n * p.x_sn + (long long)min(wv, CIN - 1) * p.x_sc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int yy = min(max(2 * oy + r - 2, 0), p.h - 1);
+      rx[r] = *(const f32x4*)(xb + (long long)yy * p.w + min(4 * lane, p.w - 4));
     }
+  };
+  auto commit = [&](int it) {
+    const int n = it / p.oh, oy = it - n * p.oh;
+    (void)n;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int co = wv + 4 * k;
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int c = lane + 64 * u;
+        if (c < D1_ZP) sz[co * D1_ZP + c] = (c < p.ow && co < p.cout) ? rz[k][u] : 0.f;
+      }
+    }
+    if (wv < CIN) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int yy = 2 * oy + r - 2;
+        const bool ok = (unsigned)yy < (unsigned)p.h && 4 * lane < p.w;
+        float* d = sx + (wv * 4 + r) * D1_XP + 2 + 4 * lane;      // (column c of the row holds input column c - 2)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = ok ? rx[r][e] : 0.f;
+        if (lane < 2) sx[(wv * 4 + r) * D1_XP + lane] = 0.f;                                  // left halo
+        if (lane < D1_XP - 2 - 256) sx[(wv * 4 + r) * D1_XP + 2 + 256 + lane] = 0.f;          // right halo / pad
+      }
+    }
+  };
+  int it = blockIdx.x;
+  if (it < items) issue(it);
+  for (; it < items; it += gridDim.x) {
+    __syncthreads();   // the previous item's FMAs are done with the tiles
+    commit(it);
     __syncthreads();
+    const int nit = it + gridDim.x;
+    if (nit < items) issue(nit);
     if (live) {
       const float* xr = sx + (ci * 4 + ky) * D1_XP;
       for (int q = 0; q < ow4; ++q) {
@@ -163,14 +218,6 @@ __global__ __launch_bounds__(256) void d1_wgrad_kernel(const D1Params p, const i
         if (co < p.cout) p.partial[(long long)blockIdx.x * (p.cout * CIN * 16) + ((co * CIN + ci) * 4 + ky) * 4 + kx] = acc[c][kx];
       }
   }
-}
-
-__global__ void d1_wgrad_reduce_kernel(const float* partial, int nblocks, int numel, float* dw, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= numel) return;
-  double s = 0.0;
-  for (int b = 0; b < nblocks; ++b) s += (double)partial[(long long)b * numel + i];   // fixed order
-  dw[i] = (accumulate ? dw[i] : 0.f) + (float)s;
 }
 
 bool d1_geom(const pcuda_conv_geom* g) {
@@ -220,6 +267,7 @@ int direct_d1_wgrad(const pcuda_conv_geom* g, const pcuda_src* x, const float* d
                     float* db, int accumulate, void* workspace, hipStream_t s, int* rc) {
   *rc = PCUDA_OK;
   if (!direct_enabled() || !d1_geom(g) || g->cin > 4 || x->scale1 || x->c1 < g->cin || db) return 0;
+  if (!aligned16(x->p1, x->sn1, x->sc1)) return 0;
   D1Params p;
   memset(&p, 0, sizeof(p));
   p.dz = dz; p.dz_sn = dz_sn; p.dz_sc = dz_sc;
@@ -247,9 +295,10 @@ int direct_d1_wgrad(const pcuda_conv_geom* g, const pcuda_src* x, const float* d
     default: D1_WG_LAUNCH(4) break;
   }
 #undef D1_WG_LAUNCH
-  hipLaunchKernelGGL(d1_wgrad_reduce_kernel, dim3(cdiv(numel, 256)), dim3(256), 0, s, (const float*)workspace, blocks, numel,
-                     dw, accumulate);
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { pcuda_set_error("d1_wgrad_kernel: %s", hipGetErrorString(e)); *rc = PCUDA_E_LAUNCH; }
+  if (e != hipSuccess) { pcuda_set_error("d1_wgrad_kernel: %s", hipGetErrorString(e)); *rc = PCUDA_E_LAUNCH; return 1; }
+  // (the block partials go through the split-K reduce of the MFMA weight-gradient kernels: 16 waves per 64 outputs; a
+  // serial loop over the 768 blocks per output ran longer than the FMA kernel itself)
+  *rc = launch_wgrad_reduce((const float*)workspace, numel, blocks, dw, accumulate, nullptr, 0, nullptr, s);
   return 1;
 }

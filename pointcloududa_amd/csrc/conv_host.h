@@ -150,3 +150,5 @@ int direct_d1_dgrad(const pcuda_conv_geom* g, int prec, const pcuda_src* dy, con
 size_t direct_d1_wgrad_workspace(const pcuda_conv_geom* g);
 int direct_d1_wgrad(const pcuda_conv_geom* g, const pcuda_src* x, const float* dz, long long dz_sn, long long dz_sc, float* dw,
                     float* db, int accumulate, void* workspace, hipStream_t s, int* rc);
+int launch_wgrad_reduce(const float* partial, long long numel, int ksplit, float* dw, int accumulate, const float* db_partial,
+                        long long nb, float* db, hipStream_t s);

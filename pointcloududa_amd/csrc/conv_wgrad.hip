@@ -48,6 +48,19 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
   }
 }
 
+// the split-K reduce for other translation units (the direct kernels' block partials): partial = [ksplit][numel],
+// dw[i] (+)= sum over k in a fixed order; db_partial = [ksplit][nb] or NULL
+int launch_wgrad_reduce(const float* partial, long long numel, int ksplit, float* dw, int accumulate, const float* db_partial,
+                        long long nb, float* db, hipStream_t s) {
+  int nkg = 1;
+  while (nkg < 16 && nkg * 2 <= ksplit) nkg <<= 1;
+  const unsigned nblk = (unsigned)cdiv(numel, 64) + (db ? (unsigned)cdiv(nb, 64) : 0u);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk), dim3(64 * nkg), 0, s, partial, numel, ksplit, dw, accumulate, 1,
+                     db_partial, db ? nb : 0, db);
+  PCUDA_CHECK_LAUNCH("wgrad_reduce_kernel");
+  return PCUDA_OK;
+}
+
 namespace {
 
 struct WgradPlan {
