@@ -105,7 +105,11 @@ WgradPlan plan_wgrad(const pcuda_conv_geom* g) {
   w.iw_t = (TW - 1) * g->stride + span + 1;
   const long long ntiles = (long long)g->n * w.tiles_x * w.tiles_y;
   const int base = w.n_co_tiles * w.n_chunks * w.tap_groups;
-  long long ks = 1024 / base;
+  // blocks in flight: 32-row blocks (160 VGPRs, 50 KB of LDS) are resident three per CU, 64-row blocks two per CU --
+  // 768 / 1024 blocks are one / two balanced rounds (1024 32-row blocks were one full round plus a third of one)
+  static int tgt32 = -1;
+  if (tgt32 < 0) { const char* e = getenv("PCUDA_WG_BLOCKS32"); tgt32 = e ? atoi(e) : 768; }
+  long long ks = (w.co_blks == 1 ? tgt32 : 1024) / base;
   if (ks < 1) ks = 1;
   if (ks > ntiles) ks = ntiles;
   // keep the partial slabs (written once, re-read once by the reduce kernel) below ~64 MB (measured:
