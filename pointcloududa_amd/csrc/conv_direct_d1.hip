@@ -302,3 +302,127 @@ int direct_d1_wgrad(const pcuda_conv_geom* g, const pcuda_src* x, const float* d
   *rc = launch_wgrad_reduce((const float*)workspace, numel, blocks, dw, accumulate, nullptr, 0, nullptr, s);
   return 1;
 }
+
+// ------------------------------------------------------------------------------------------
+// The discriminators' LAST layer: cin (256 / 512) -> 1 channel, 4x4, stride 2, pad 2, on a 17x17 (or smaller) map
+// (GAN.py:101).  One output row of a 32-row MFMA tile carried data: 0.4-0.7 TFLOP/s, 120 us per launch.  Here: one
+// 1024-thread workgroup per image; 64-channel chunks of the input staged in LDS one chunk ahead (registers: 18 loads
+// per lane in flight), every thread one output pixel and a twelfth of a chunk's channels, fixed-order combine.
+// (With 16-channel chunks and 256 threads the kernel ran at one memory round trip per chunk: 135 us.)
+// Packed forward weights: rows = cout = 1 (row 0 of a 32-row tile), element (ci, t) at ((ci / 32) * 16 + t) * 32 * rec + ci % 32.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+#define D5_CH 64
+#define D5_NT 1024
+#define D5_MAXPIX 292     // in_h * in_w of the staged planes (17 x 17 = 289)
+struct D5Params {
+  const float* x; long long x_sn, x_sc;
+  float* y; long long y_sn;
+  const uint16_t* wpack; int rec;
+  const float* bias;
+  float slope;
+  int h, w, oh, ow, cin;
+};
+
+__global__ __launch_bounds__(D5_NT) void d5_fwd_kernel(const D5Params p) {
+  extern __shared__ __attribute__((aligned(16))) float d5_smem[];
+  float* sx = d5_smem;                          // [D5_CH][D5_MAXPIX]
+  float* swt = d5_smem + D5_CH * D5_MAXPIX;     // [D5_CH][16]
+  float* spart = swt + D5_CH * 16;              // [D5_NT]
+  const int tid = threadIdx.x, n = blockIdx.x;
+  const int hw = p.h * p.w, op = p.oh * p.ow;
+  const int ng = D5_NT / op;                        // channel groups (threads per output pixel)
+  const int o = tid % op, gsel = tid / op;
+  const bool live = gsel < ng;
+  const int oy = o / p.ow, ox = o - oy * p.ow;
+  int off[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int iy = 2 * oy + (t >> 2) - 2, ix = 2 * ox + (t & 3) - 2;
+    off[t] = ((unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.w) ? iy * p.w + ix : -1;
+  }
+  const int per = (D5_CH * hw + D5_NT - 1) / D5_NT;   // staged elements per thread and chunk (<= 19)
+  float rx[19], rw;
+  auto issue = [&](int c0) {
+    const float* xb = p.x + (long long)n * p.x_sn + (long long)c0 * p.x_sc;
+#pragma unroll
+    for (int u = 0; u < 19; ++u) {
+      const int i = tid + D5_NT * u;
+      const int c = min(i / hw, D5_CH - 1), q = i - (i / hw) * hw;
+      const int cc = min(c, p.cin - 1 - c0);                     // (a ragged last chunk re-reads a valid plane; its weights are 0)
+      rx[u] = (u < per) ? xb[(long long)cc * p.x_sc + min(q, hw - 1)] : 0.f;
+    }
+    {
+      const int c = tid >> 4, t = tid & 15, ci = min(c0 + c, p.cin - 1);
+      const long long idx = (((long long)(ci >> 5)) * 16 + t) * 32 * p.rec + (ci & 31);
+      rw = bf16_bits_to_float(p.wpack[idx]);
+      if (p.rec > IG_REC) rw += bf16_bits_to_float(p.wpack[idx + 32]);
+      if (c0 + c >= p.cin) rw = 0.f;
+    }
+  };
+  float acc = 0.f;
+  issue(0);
+  for (int c0 = 0; c0 < p.cin; c0 += D5_CH) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 19; ++u) {
+      const int i = tid + D5_NT * u;
+      if (u < per && i < D5_CH * hw) sx[(i / hw) * D5_MAXPIX + (i - (i / hw) * hw)] = rx[u];
+    }
+    swt[tid] = rw;
+    __syncthreads();
+    if (c0 + D5_CH < p.cin) issue(c0 + D5_CH);
+    if (live) {
+      for (int c = gsel; c < D5_CH; c += ng) {
+        const float* xc = sx + c * D5_MAXPIX;
+        const float* wc = swt + c * 16;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const float xv = off[t] >= 0 ? xc[off[t]] : 0.f;
+          acc = fmaf(wc[t], xv, acc);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  spart[tid] = live ? acc : 0.f;
+  __syncthreads();
+  if (tid < op) {
+    float s = 0.f;
+    for (int k = 0; k < ng; ++k) s += spart[k * op + tid];   // fixed order
+    s += p.bias ? p.bias[0] : 0.f;
+    s = s > 0.f ? s : s * p.slope;
+    p.y[(long long)n * p.y_sn + tid] = s;
+  }
+}
+
+bool d5_geom(const pcuda_conv_geom* g) {
+  return g->cout == 1 && g->k == 4 && g->stride == 2 && g->pad == 2 && g->dil == 1 && !g->in_up &&
+         g->in_h * g->in_w <= D5_MAXPIX && g->out_h * g->out_w <= 128;
+}
+
+}  // namespace
+
+int direct_d5_forward(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const void* packed_w, const float* bias,
+                      float slope, const pcuda_dst* y, float* bn_partials, hipStream_t s, int* rc) {
+  *rc = PCUDA_OK;
+  if (!direct_enabled() || !d5_geom(g) || bn_partials || x->scale1 || x->c1 < g->cin) return 0;
+  D5Params p;
+  p.x = x->p1; p.x_sn = x->sn1; p.x_sc = x->sc1;
+  p.y = y->p1; p.y_sn = y->sn1;
+  p.wpack = (const uint16_t*)packed_w; p.rec = ig_rec_bytes(prec == PCUDA_PREC_BF16X3) / 2;
+  p.bias = bias; p.slope = slope;
+  p.h = g->in_h; p.w = g->in_w; p.oh = g->out_h; p.ow = g->out_w; p.cin = g->cin;
+  const double flops = 2.0 * g->n * (double)g->out_h * g->out_w * (double)g->cin * 16;
+  char tag[96];
+  snprintf(tag, sizeof(tag), "direct d5 fwd n%d cin%d %dx%d", g->n, g->cin, g->in_h, g->in_w);
+  ProfScope prof(PCUDA_FAM_CONV_FWD, flops, s, tag);
+  const size_t lds = (size_t)(D5_CH * D5_MAXPIX + D5_CH * 16 + D5_NT) * sizeof(float);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)d5_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL(d5_fwd_kernel, dim3(g->n), dim3(D5_NT), lds, s, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { pcuda_set_error("d5_fwd_kernel: %s", hipGetErrorString(e)); *rc = PCUDA_E_LAUNCH; }
+  return 1;
+}

@@ -152,3 +152,5 @@ int direct_d1_wgrad(const pcuda_conv_geom* g, const pcuda_src* x, const float* d
                     float* db, int accumulate, void* workspace, hipStream_t s, int* rc);
 int launch_wgrad_reduce(const float* partial, long long numel, int ksplit, float* dw, int accumulate, const float* db_partial,
                         long long nb, float* db, hipStream_t s);
+int direct_d5_forward(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const void* packed_w, const float* bias,
+                      float slope, const pcuda_dst* y, float* bn_partials, hipStream_t s, int* rc);

@@ -105,3 +105,26 @@ def test_discriminator_first_layer_dgrad_and_wgrad(dev, shape):
     assert rel_err(dw, w.grad) < 1e-4
     op.wgrad(x.detach().to(dev), gzd, dw, None, h, w_, accumulate=True)
     assert rel_err(dw, 2 * w.grad) < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(4, 512, 17, 17), (3, 256, 9, 9), (2, 72, 17, 13)])
+def test_discriminator_last_layer_forward(dev, shape):
+    """cin -> 1 channel, 4x4, stride 2, pad 2 on a small map (GAN.py:101): the direct forward kernel against torch
+    (ragged last 16-channel chunk included); its gradients stay on the MFMA kernels and are checked there."""
+    from pointcloududa_amd import kernels as K
+    n, cin, h, w_ = shape
+    rng = np.random.default_rng(cin + h)
+    x = torch.from_numpy(rng.normal(0, 1, (n, cin, h, w_)).astype(np.float32)).requires_grad_(True)
+    w = torch.from_numpy(rng.normal(0, 0.05, (1, cin, 4, 4)).astype(np.float32)).requires_grad_(True)
+    z = F.conv2d(x, w, None, stride=2, padding=2)
+    gz = torch.from_numpy(rng.normal(0, 1, z.shape).astype(np.float32))
+    z.backward(gz)
+    op = K.ConvOp(cin, 1, 4, stride=2, pad=2)
+    y, _, _ = op.forward(x.detach().to(dev), w.detach().to(dev), None, 1.0, h, w_)
+    assert rel_err(y, z) < 1e-4
+    y2, _, _ = op.forward(x.detach().to(dev), w.detach().to(dev), None, 0.2, h, w_)
+    assert rel_err(y2, F.leaky_relu(z, 0.2)) < 1e-4
+    assert rel_err(op.dgrad(gz.to(dev), w.detach().to(dev), h, w_), x.grad) < 1e-4
+    dw = torch.zeros((1, cin, 4, 4), device=dev)
+    op.wgrad(x.detach().to(dev), gz.to(dev), dw, None, h, w_, accumulate=False)
+    assert rel_err(dw, w.grad) < 1e-4
