@@ -120,6 +120,15 @@ int pcuda_conv2d_forward(const pcuda_conv_geom* g, int prec, const pcuda_src* x,
  * When g->in_up is set, dx is the gradient of the UPSAMPLED (logical) input. */
 int pcuda_conv2d_dgrad(const pcuda_conv_geom* g, int prec, const pcuda_src* dy, const void* packed_w_dgrad,
                        const pcuda_dst* dx, int accumulate, pcuda_stream_t s);
+/* The same data gradient with the BatchNorm-backward reduce of the layer in front of this convolution fused into its
+ * epilogue (unet.py:23-30: conv -> LeakyReLU -> BN -> conv; the second convolution's dx IS the first BatchNorm's incoming
+ * gradient): red_partials[tile][cin][2] = (sum g, sum g * (a - mean) * invstd) over the tile's stored gradient g, the
+ * input of pcuda_bn_bwd_finalize with ntiles = pcuda_conv2d_dgrad_tiles().  Stride-1 layers whose rows are multiples of
+ * 4 pixels; returns PCUDA_E_UNSUPPORTED otherwise (run pcuda_conv2d_dgrad + pcuda_bn_bwd_reduce instead). */
+int pcuda_conv2d_dgrad_tiles(const pcuda_conv_geom* g, int prec);
+int pcuda_conv2d_dgrad_bnred(const pcuda_conv_geom* g, int prec, const pcuda_src* dy, const void* packed_w_dgrad,
+                             const pcuda_dst* dx, int accumulate, const float* a, long long a_sn, long long a_sc,
+                             const float* mean, const float* invstd, float* red_partials, pcuda_stream_t s);
 /* dw (+)= sum over batch and space of dy (x) x ; db (+)= sum dy (db may be NULL).
  * workspace: pcuda_conv2d_wgrad_workspace_size() bytes. */
 size_t pcuda_conv2d_wgrad_workspace_size(const pcuda_conv_geom* g);

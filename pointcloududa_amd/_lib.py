@@ -50,6 +50,9 @@ _PROTOS = {
     "pcuda_conv2d_fwd_tiles": (i32, [C.POINTER(ConvGeom), i32]),
     "pcuda_conv2d_forward": (i32, [C.POINTER(ConvGeom), i32, C.POINTER(Src), vp, vp, f32, C.POINTER(Dst), vp, vp]),
     "pcuda_conv2d_dgrad": (i32, [C.POINTER(ConvGeom), i32, C.POINTER(Src), vp, C.POINTER(Dst), i32, vp]),
+    "pcuda_conv2d_dgrad_tiles": (i32, [C.POINTER(ConvGeom), i32]),
+    "pcuda_conv2d_dgrad_bnred": (i32, [C.POINTER(ConvGeom), i32, C.POINTER(Src), vp, C.POINTER(Dst), i32, vp, i64, i64, vp,
+                                       vp, vp, vp]),
     "pcuda_conv2d_wgrad_workspace_size": (sz, [C.POINTER(ConvGeom)]),
     "pcuda_conv2d_wgrad": (i32, [C.POINTER(ConvGeom), i32, C.POINTER(Src), vp, i64, i64, vp, vp, i32, vp, sz, vp]),
     "pcuda_bn_finalize": (i32, [vp, i32, i32, i64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp]),
@@ -102,6 +105,9 @@ _PROTOS = {
 
 EXPORTED_SYMBOLS = tuple(_PROTOS.keys())
 _lib = None
+
+
+PCUDA_E_UNSUPPORTED = -2      # include/pcuda_hip.h
 
 
 def lib():

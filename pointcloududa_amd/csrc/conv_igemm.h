@@ -44,6 +44,10 @@ struct IgemmParams {
   float slope;
   int accumulate;
   float* stats;            // [tile][cout][2] partial (sum, sumsq) of the stored values, or NULL
+  // BatchNorm-backward reduce fused into a dgrad launch (transposed epilogue only): with red_a set, `stats` receives
+  // per tile and row (sum of the stored gradient g, sum of g * (a - mean) * invstd) -- what bn_bwd_reduce computes
+  const float* red_a; long long red_sn, red_sc;
+  const float* red_mean; const float* red_invstd;
   int tw, th, tmagic;      // output tile TW x TH (TW*TH <= 128*NPB slots, any TW <= 256); tmagic = 65536/TW + 1
   int tiles_x, tiles_y, n;
   int n_co_tiles;

@@ -138,7 +138,7 @@ int plan_lds(bool x3, int co_tile, int x_cap, int ntaps, int mode, int* tg_out, 
   const size_t xb = (size_t)x_cap * rec;
   const size_t wtap = (size_t)co_tile * rec;
   const size_t epi = 4 * (size_t)co_tile * 2 * sizeof(float);
-  const size_t tab = 512;   // per-tap offset table + the epilogue's bias slice, behind the weight slabs
+  const size_t tab = 1024;  // per-tap offset table + the epilogue's bias / mean / invstd slices, behind the weight slabs
   if (ntaps < 1) ntaps = 1;
   // one copy pass per group: the kernels' register slots (16-byte vectors per lane) x lanes; a bf16x3 record is 9
   // vectors (both planes), a bf16 record 5
@@ -302,6 +302,8 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
       }
     }
   }
+  if (p.red_a && !(pipe && pl.te))
+    PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv2d_dgrad_bnred: this geometry does not run on the transposed-epilogue kernel");
   return x3 ? igemm_dispatch_x3(p, pl, co_blks, pf, pipe, s) : igemm_dispatch_bf16(p, pl, co_blks, pf, pipe, s);
 }
 
@@ -461,4 +463,44 @@ extern "C" int pcuda_debug_read_clocks(unsigned long long* out8) {
   if (hipMemcpy(out8, g_dbg_clk_host, sizeof(z), hipMemcpyDeviceToHost) != hipSuccess) return -1;
   if (hipMemcpy(g_dbg_clk_host, z, sizeof(z), hipMemcpyHostToDevice) != hipSuccess) return -1;
   return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// dgrad with the BatchNorm-backward reduce of the layer in FRONT of this convolution fused into its epilogue
+// (unet.py:23-30: conv -> LeakyReLU -> BN -> conv: the second convolution's data gradient IS the first BatchNorm's
+// incoming gradient, and nothing else adds to it).  Stride-1 layers on the transposed-epilogue kernel only;
+// PCUDA_E_UNSUPPORTED otherwise (the caller then runs pcuda_conv2d_dgrad + pcuda_bn_bwd_reduce).
+// ------------------------------------------------------------------------------------------
+extern "C" int pcuda_conv2d_dgrad_tiles(const pcuda_conv_geom* g, int prec) {
+  if (!geom_ok(g) || g->stride != 1) return 0;
+  TapSet t = dgrad_taps(g, 0, 0);
+  IgemmPlan pl;
+  if (plan_igemm(g->cin, g->cout, g->n, g->in_h, g->in_w, g->out_h, g->out_w, 1, t, prec == PCUDA_PREC_BF16X3, &pl) < 0) return 0;
+  return g->n * pl.tiles_x * pl.tiles_y;
+}
+
+extern "C" int pcuda_conv2d_dgrad_bnred(const pcuda_conv_geom* g, int prec, const pcuda_src* dy, const void* packed_w_dgrad,
+                                        const pcuda_dst* dx, int accumulate, const float* a, long long a_sn, long long a_sc,
+                                        const float* mean, const float* invstd, float* red_partials, pcuda_stream_t s) {
+  if (!geom_ok(g)) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_dgrad_bnred: inconsistent geometry");
+  if (!src_ok(dy, g->cout) || !dst_ok(dx, g->cin) || !packed_w_dgrad || !a || !mean || !invstd || !red_partials)
+    PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_dgrad_bnred: bad tensors");
+  if (prec != PCUDA_PREC_BF16X3 && prec != PCUDA_PREC_BF16) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_dgrad_bnred: bad precision");
+  if (g->stride != 1 || g->in_up || (((uintptr_t)a) & 15) || (a_sn & 3) || (a_sc & 3))
+    PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv2d_dgrad_bnred: stride-1 layers with 16-byte aligned activations only");
+  TapSet t = dgrad_taps(g, 0, 0);
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = *dy; p.cin = g->cout;
+  p.in_h = g->out_h; p.in_w = g->out_w; p.in_shift = 0; p.in_row = g->out_w;
+  p.y = *dx; p.cout = g->cin; p.out_w = g->in_w;
+  p.lh = g->in_h; p.lw = g->in_w;
+  p.oy_mul = p.ox_mul = 1; p.oy_off = p.ox_off = 0;
+  p.in_step = 1;
+  p.wpack = (const uint16_t*)packed_w_dgrad; p.w_lo_off = 0;
+  p.bias = nullptr; p.slope = 1.f; p.accumulate = accumulate;
+  p.stats = red_partials;
+  p.red_a = a; p.red_sn = a_sn; p.red_sc = a_sc; p.red_mean = mean; p.red_invstd = invstd;
+  p.n = g->n;
+  return launch_igemm(p, prec, t, (hipStream_t)s);
 }

@@ -292,7 +292,9 @@ __device__ __forceinline__ TileGeom tile_decode(const IgemmParams& p, int L) {
 // resident (512 VGPRs per lane: the whole group sits in registers between its loads and its LDS
 // write) -- a stage then has one weight round trip, issued in front of the X prefetch, and no barrier
 // inside its MFMA phase.
-template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ, bool STATS, bool TE>
+// STATS: 0 none, 1 BatchNorm partial sums of the stored values (forward), 2 BatchNorm-BACKWARD reduce partials of the
+// stored gradient against the saved activation (dgrad of a block's second convolution; transposed epilogue only)
+template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ, int STATS, bool TE>
 __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const IgemmParams p, const int x_cap, const int total) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CO_TILE = 32 * CO_BLKS;
@@ -316,7 +318,9 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
   unsigned char* Whi = smem + (size_t)x_cap * REC;
   unsigned char* Wlo = Whi + IG_LO_OFF;
   int* taptab = (int*)(Whi + (size_t)p.tg * CO_TILE * REC);   // [ntaps], behind the weight slab
-  float* sbias = (float*)(taptab + 64);   // [CO_TILE] bias of the tile being finished (host adds 512 B in all)
+  float* sbias = (float*)(taptab + 64);   // [CO_TILE] bias of the tile being finished
+  float* smean = sbias + 64;              // [CO_TILE] STATS == 2: mean / invstd of the rows' BatchNorm (host adds 1 KiB in all)
+  float* sinv = smean + 64;
   float* sred = (float*)smem;   // [4 waves][CO_TILE][2], reused between a tile's last MFMA and the next commit
 
   // per-tap LDS offset (or packed dy/dx in clamp mode), read back with one broadcast ds_read per tap:
@@ -366,6 +370,11 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
     // stage's other loads, so its wait never drains them
     float bias_r = 0.f;
     if (chunk == p.nchunks - 1 && p.bias && tid < CO_TILE) bias_r = p.bias[min(g.cot * CO_TILE + tid, p.cout - 1)];
+    float mean_r = 0.f, inv_r = 0.f;
+    if (STATS == 2 && chunk == p.nchunks - 1 && tid < CO_TILE) {
+      mean_r = p.red_mean[min(g.cot * CO_TILE + tid, p.cout - 1)];
+      inv_r = p.red_invstd[min(g.cot * CO_TILE + tid, p.cout - 1)];
+    }
     // (pinned behind the commit: hoisted above it into one memory clause, the two parked weight groups were live next
     // to the 64 prefetch registers and the kernel spilled)
     __builtin_amdgcn_sched_barrier(0);
@@ -536,7 +545,10 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
       // Bias comes through LDS (fetched at the top of the stage), stores go through buffer resources:
       // 32-bit offsets, rows past cout / pixels outside the output dropped by the range check.
       const int co0 = g.cot * CO_TILE;
-      if (tid < CO_TILE) sbias[tid] = bias_r;
+      if (tid < CO_TILE) {
+        sbias[tid] = bias_r;
+        if (STATS == 2) { smean[tid] = mean_r; sinv[tid] = inv_r; }
+      }
       __syncthreads();   // sbias visible; sred aliases the X tile: every wave's last fragment reads are done
       if constexpr (TE) {
         // Transposed epilogue (rows of 4k pixels, unit x stride): every wave turns its [32 rows][WPIX pixels]
@@ -586,6 +598,16 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
               dptr[k] = base + (size_t)((unsigned)cs * (first ? pl1 : pl2) + pixq);
               ok[k] = pokq & (cu + cs < p.cout);
             }
+            f32x4 av[HN];
+            if (STATS == 2) {   // the saved activation of the rows' BatchNorm, same element as the stored gradient
+              char* const ab = (char*)(p.red_a + (long long)g.n * p.red_sn);
+#pragma unroll
+              for (int k = 0; k < HN; ++k) {
+                av[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int cu = co0 + cb * 32 + (ib + k) * CPI + cs;
+                if (ok[k]) av[k] = *(const f32x4*)(ab + ((long long)cu * p.red_sc) * 4 + pixq);
+              }
+            }
             if (p.accumulate) {   // uniform: dgrad into a gradient that already holds another consumer's share
               f32x4 o[HN];
 #pragma unroll
@@ -617,7 +639,15 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
               if (ok[k]) *(f32x4*)dptr[k] = v[k];
               if (STATS) {
                 float s1 = (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
-                float s2 = (v[k][0] * v[k][0] + v[k][1] * v[k][1]) + (v[k][2] * v[k][2] + v[k][3] * v[k][3]);
+                float s2;
+                if (STATS == 2) {
+                  const int rr = cb * 32 + (ib + k) * CPI + cs;
+                  const float m = smean[rr], is = sinv[rr];
+                  s2 = (v[k][0] * ((av[k][0] - m) * is) + v[k][1] * ((av[k][1] - m) * is)) +
+                       (v[k][2] * ((av[k][2] - m) * is) + v[k][3] * ((av[k][3] - m) * is));
+                } else {
+                  s2 = (v[k][0] * v[k][0] + v[k][1] * v[k][1]) + (v[k][2] * v[k][2] + v[k][3] * v[k][3]);
+                }
                 s1 = ok[k] ? s1 : 0.f;
                 s2 = ok[k] ? s2 : 0.f;
                 s1 = row_sum<LPC>(s1);
@@ -1005,7 +1035,7 @@ static int launch_igemm_c(const IgemmParams& p, const IgemmPlan& pl, hipStream_t
                      : launch_igemm_t<X3, CO_BLKS, false, 1>(p, pl.x_cap, pl.lds, s);
 }
 
-template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ, bool STATS, bool TE>
+template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ, int STATS, bool TE>
 static int launch_pipe_s(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
   auto kern = igemm_pipe_kernel<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, STATS, TE>;
   static size_t lds_set = 0;
@@ -1036,10 +1066,14 @@ static int launch_pipe_s(const IgemmParams& p, const IgemmPlan& pl, hipStream_t 
 
 template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ>
 static int launch_pipe_t(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
-  if (pl.te) return p.stats ? launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, true, true>(p, pl, s)
-                            : launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, false, true>(p, pl, s);
-  return p.stats ? launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, true, false>(p, pl, s)
-                 : launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, false, false>(p, pl, s);
+  if (pl.te) {
+    if (p.stats && p.red_a) return launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, 2, true>(p, pl, s);
+    return p.stats ? launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, 1, true>(p, pl, s)
+                   : launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, 0, true>(p, pl, s);
+  }
+  if (p.red_a) PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "igemm: the fused BatchNorm-backward reduce needs the transposed epilogue");
+  return p.stats ? launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, 1, false>(p, pl, s)
+                 : launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, 0, false>(p, pl, s);
 }
 
 template <bool X3, int CO_BLKS, bool CLAMP, int NPB>

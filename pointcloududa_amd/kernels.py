@@ -97,6 +97,11 @@ def make_dst(a: torch.Tensor, b: Optional[torch.Tensor] = None) -> Dst:
 # ------------------------------------------------------------------------------------------
 # convolution
 # ------------------------------------------------------------------------------------------
+# PCUDA_BNRED=0: the BatchNorm-backward reduce of a block's first BatchNorm as its own kernel instead of riding in the
+# epilogue of the second convolution's dgrad (A/B switch)
+_fuse_bnred = os.environ.get("PCUDA_BNRED", "1") != "0"
+
+
 class ConvOp:
     """Geometry + packed-weight cache of one nn.Conv2d (square kernel, groups=1)."""
 
@@ -169,14 +174,33 @@ class ConvOp:
                                        C.byref(dst), _ptr(partials), _stream()), "conv2d_forward")
         return out, partials, nt
 
-    def dgrad(self, dy, w, in_h, in_w, dx=None, dx2=None, accumulate=False):
-        """dy: [n,cout,oh,ow].  dx (+dx2 split along channels) = gradient of the logical input."""
+    def dgrad(self, dy, w, in_h, in_w, dx=None, dx2=None, accumulate=False, bnred=None):
+        """dy: [n,cout,oh,ow].  dx (+dx2 split along channels) = gradient of the logical input.
+        ``bnred=(a, BNState)``: the BatchNorm-backward reduce of the layer in front of this convolution rides in the
+        epilogue; returns (dx, (partials, ntiles)) -- or (dx, None) where the geometry does not allow it."""
         n = dy.shape[0]
         g = self.geom(n, in_h, in_w)
         if dx is None:
             dx = torch.empty((n, self.cin, in_h, in_w), dtype=torch.float32, device=dy.device)
         pk = self._packed("dgrad", w, g)
         src, dst = make_src(dy), make_dst(dx, dx2)
+        if bnred is not None:
+            a, st = bnred
+            lib = L.lib()
+            nt = lib.pcuda_conv2d_dgrad_tiles(C.byref(g), _precision) if (_fuse_bnred and dx2 is None) else 0
+            if nt > 0:
+                _, _, _, asn, asc = _planes(a)
+                red = torch.empty((nt, self.cin, 2), dtype=torch.float32, device=dy.device)
+                rc = lib.pcuda_conv2d_dgrad_bnred(C.byref(g), _precision, C.byref(src), pk.data_ptr(), C.byref(dst),
+                                                  1 if accumulate else 0, a.data_ptr(), asn, asc, st.mean.data_ptr(),
+                                                  st.invstd.data_ptr(), red.data_ptr(), _stream())
+                if rc == 0:
+                    return dx, (red, nt)
+                if rc != L.PCUDA_E_UNSUPPORTED:
+                    check(rc, "conv2d_dgrad_bnred")
+            check(lib.pcuda_conv2d_dgrad(C.byref(g), _precision, C.byref(src), pk.data_ptr(), C.byref(dst),
+                                         1 if accumulate else 0, _stream()), "conv2d_dgrad")
+            return dx, None
         check(L.lib().pcuda_conv2d_dgrad(C.byref(g), _precision, C.byref(src), pk.data_ptr(), C.byref(dst),
                                          1 if accumulate else 0, _stream()), "conv2d_dgrad")
         return dx
@@ -235,7 +259,7 @@ def bn_apply(a: torch.Tensor, st: BNState, relu=False, out=None):
 
 
 def bn_backward(dy, a, st: BNState, gamma, dgamma, dbeta, dy2=None, post_relu=False, act_slope=1.0,
-                accumulate=True):
+                accumulate=True, red=None):
     """Backward of [a = lrelu(z, act_slope)] -> BN (post_relu=False) or a -> BN -> ReLU (post_relu=True).
     Returns dz (gradient w.r.t. the pre-activation conv output, or w.r.t. a when post_relu)."""
     n, c, hw, asn, asc = _planes(a)
@@ -245,16 +269,21 @@ def bn_backward(dy, a, st: BNState, gamma, dgamma, dbeta, dy2=None, post_relu=Fa
         _, _, _, d2sn, d2sc = _planes(dy2)
         d2p = dy2.data_ptr()
     lib = L.lib()
-    nt = C.c_int(0)
-    check(lib.pcuda_bn_bwd_reduce(None, 0, 0, None, 0, 0, None, 0, 0, None, None, None, None, 0, n, c, hw, None,
-                                  C.byref(nt), _stream()), "bn_bwd_reduce(query)")
-    red = torch.empty((nt.value, c, 2), dtype=torch.float32, device=a.device)
     pr = 1 if post_relu else 0
-    check(lib.pcuda_bn_bwd_reduce(dy.data_ptr(), dsn, dsc, d2p, d2sn, d2sc, a.data_ptr(), asn, asc,
-                                  st.mean.data_ptr(), st.invstd.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(),
-                                  pr, n, c, hw, red.data_ptr(), C.byref(nt), _stream()), "bn_bwd_reduce")
+    if red is not None:          # (partials, ntiles) from the producing dgrad's epilogue (ConvOp.dgrad(bnred=...))
+        assert dy2 is None and not post_relu
+        red, ntv = red
+    else:
+        nt = C.c_int(0)
+        check(lib.pcuda_bn_bwd_reduce(None, 0, 0, None, 0, 0, None, 0, 0, None, None, None, None, 0, n, c, hw, None,
+                                      C.byref(nt), _stream()), "bn_bwd_reduce(query)")
+        red = torch.empty((nt.value, c, 2), dtype=torch.float32, device=a.device)
+        check(lib.pcuda_bn_bwd_reduce(dy.data_ptr(), dsn, dsc, d2p, d2sn, d2sc, a.data_ptr(), asn, asc,
+                                      st.mean.data_ptr(), st.invstd.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(),
+                                      pr, n, c, hw, red.data_ptr(), C.byref(nt), _stream()), "bn_bwd_reduce")
+        ntv = nt.value
     coef = torch.empty((c, 3), dtype=torch.float32, device=a.device)
-    check(lib.pcuda_bn_bwd_finalize(red.data_ptr(), nt.value, c, n * hw, _ptr(gamma), st.invstd.data_ptr(),
+    check(lib.pcuda_bn_bwd_finalize(red.data_ptr(), ntv, c, n * hw, _ptr(gamma), st.invstd.data_ptr(),
                                     st.mean.data_ptr(), _ptr(dgamma), _ptr(dbeta), 1 if accumulate else 0,
                                     coef.data_ptr(), _stream()), "bn_bwd_finalize")
     dz = torch.empty(a.shape, dtype=torch.float32, device=a.device)

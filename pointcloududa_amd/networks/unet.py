@@ -94,9 +94,11 @@ class _SegEngine:
                             act_slope=SLOPE)
         if G(blk + ".3.weight") is not None:
             self.ops[blk + ".3"].wgrad(TA(a0, st0.scale, st0.shift), dz1, G(blk + ".3.weight"), G(blk + ".3.bias"), h, w)
-        d_y0 = self.ops[blk + ".3"].dgrad(dz1, P[blk + ".3.weight"], h, w)
+        # the second convolution's data gradient IS the first BatchNorm's incoming gradient: its reduce (sum g,
+        # sum g * a_hat) rides in the dgrad kernel's epilogue where the geometry allows
+        d_y0, red = self.ops[blk + ".3"].dgrad(dz1, P[blk + ".3.weight"], h, w, bnred=(a0, st0))
         dz0 = K.bn_backward(d_y0, a0, st0, P[blk + ".2.weight"], G(blk + ".2.weight"), G(blk + ".2.bias"),
-                            act_slope=SLOPE)
+                            act_slope=SLOPE, red=red)
         if G(blk + ".0.weight") is not None:
             self.ops[blk + ".0"].wgrad(x, dz0, G(blk + ".0.weight"), G(blk + ".0.bias"), h, w, x2=x2)
         if not need_dx:

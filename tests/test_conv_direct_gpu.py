@@ -128,3 +128,38 @@ def test_discriminator_last_layer_forward(dev, shape):
     dw = torch.zeros((1, cin, 4, 4), device=dev)
     op.wgrad(x.detach().to(dev), gz.to(dev), dw, None, h, w_, accumulate=False)
     assert rel_err(dw, w.grad) < 1e-4
+
+
+# (enough tiles for the two-workgroups-per-CU kernel that carries the transposed epilogue: > 320 tile x row-tile items)
+@pytest.mark.parametrize("shape", [(2, 32, 32, 256, 256, False), (6, 48, 64, 128, 128, True), (2, 16, 8, 64, 64, False)])
+def test_dgrad_with_fused_bn_backward_reduce(dev, shape):
+    """conv -> LeakyReLU -> BN -> conv (unet.py:23-30): the second convolution's data gradient with the first BatchNorm's
+    backward reduce in its epilogue: (sum g, sum g * (a - mean) * invstd) per channel against the sums over the reference
+    gradient (fp64), plain and accumulating into an existing gradient."""
+    from pointcloududa_amd import kernels as K
+    n, cin, cout, h, w_, acc = shape
+    rng = np.random.default_rng(cin + cout)
+    a = torch.from_numpy(rng.normal(0, 1, (n, cin, h, w_)).astype(np.float32))
+    w = torch.from_numpy(rng.normal(0, 0.05, (cout, cin, 3, 3)).astype(np.float32))
+    gz = torch.from_numpy(rng.normal(0, 1, (n, cout, h, w_)).astype(np.float32))
+    mean, invstd = a.mean((0, 2, 3)), 1.0 / torch.sqrt(a.var((0, 2, 3), unbiased=False) + 1e-5)
+    g_ref = F.conv_transpose2d(gz, w, padding=1).double()
+    base = torch.from_numpy(rng.normal(0, 1, (n, cin, h, w_)).astype(np.float32))
+    if acc:
+        g_ref = g_ref + base.double()
+    ahat = (a.double() - mean.double()[None, :, None, None]) * invstd.double()[None, :, None, None]
+    s1, s2 = g_ref.sum((0, 2, 3)), (g_ref * ahat).sum((0, 2, 3))
+    st = K.BNState()
+    st.mean, st.invstd = mean.to(dev), invstd.to(dev)
+    op = K.ConvOp(cin, cout, 3, pad=1)
+    dx = base.to(dev).clone() if acc else None
+    dx, red = op.dgrad(gz.to(dev), w.to(dev), h, w_, dx=dx, accumulate=acc, bnred=(a.to(dev), st))
+    assert rel_err(dx, g_ref.float()) < 1e-4
+    if h < 128:          # few tiles: the one-workgroup-per-CU kernel takes the layer and the caller reduces separately
+        assert red is None
+        return
+    assert red is not None, "this geometry runs on the transposed-epilogue kernel"
+    part, nt = red
+    got = part[:nt].double().sum(0).cpu()
+    assert rel_err(dx, g_ref.float()) < 1e-4
+    assert rel_err(got[:, 0], s1) < 1e-4 and rel_err(got[:, 1], s2) < 1e-4
