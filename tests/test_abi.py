@@ -40,7 +40,11 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     with pytest.raises(RuntimeError, match="adam_step"):
         check(lib.pcuda_adam_step(None, None, None, None, 0, 1e-3, 0.9, 0.99, 1e-8, 0.0, 1, 1.0, None), "adam_step")
     g2 = ConvGeom(2, 8, 8, 16, 16, 16, 16, 3, 1, 1, 1, 0)
-    assert lib.pcuda_conv2d_packed_fwd_bytes(ctypes.byref(g2), 0) == 2 * lib.pcuda_conv2d_packed_fwd_bytes(ctypes.byref(g2), 1) > 0
+    # records of the packed layout: 144 bytes (bf16x3: 32 hi | 32 lo | 8 pad bf16) against 80 (bf16: 32 values + 8 pad);
+    # one 32-row tile x one 32-channel chunk x 9 taps here
+    assert lib.pcuda_conv2d_packed_fwd_bytes(ctypes.byref(g2), 0) == 9 * 32 * 144
+    assert lib.pcuda_conv2d_packed_fwd_bytes(ctypes.byref(g2), 1) == 9 * 32 * 80
+    assert lib.pcuda_conv2d_dgrad_tiles(ctypes.byref(g2), 0) == lib.pcuda_conv2d_fwd_tiles(ctypes.byref(g2), 0)
     assert lib.pcuda_conv2d_wgrad_workspace_size(ctypes.byref(g2)) > 0
     assert lib.pcuda_conv2d_fwd_tiles(ctypes.byref(g2), 0) == 2
     assert lib.pcuda_seg_loss_workspace_size(2, 4, 256) > 0
