@@ -11,7 +11,7 @@ F=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1)
 [ -n "$F" ] && cp "$F" gpurun_out/${TAG}_kernel_stats.csv && head -12 "$F"
 # (HBM traffic counters: scripts/gpu_pmc.sh, on single layers -- a --pmc pass over the whole step serialises
 # thousands of dispatches and takes tens of minutes)
-PCUDA_PROF_DUMP=gpurun_out/${TAG}_layers.csv python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_prof.log 2>&1
+PCUDA_DSTREAMS=0 PCUDA_PROF_DUMP=gpurun_out/${TAG}_layers.csv python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_prof.log 2>&1
 python3 scripts/layer_table.py gpurun_out/${TAG}_layers.csv 60 > gpurun_out/${TAG}_layer_table.txt
 tail -3 gpurun_out/${TAG}_layer_table.txt
 python3 bench.py 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_line.json
