@@ -192,6 +192,13 @@ int pcuda_maxpool2_bwd(const float* dy, long long dy_sn, long long dy_sc, const 
 /* dx[h][w] (+)= sum of the 2x2 block of dy[2h][2w] (nearest-upsample backward) */
 int pcuda_upsample2_bwd(const float* dy, long long dy_sn, long long dy_sc, float* dx, long long dx_sn,
                         long long dx_sc, int accumulate, int n, int c, int h, int w, pcuda_stream_t s);
+/* ... with the BatchNorm-backward reduce of the layer that consumes dx fused in (the decoder's conv -> LeakyReLU -> BN
+ * blocks, unet.py:116-125, going back): red[ntiles][c][2] = (sum g, sum g * (a - mean) * invstd) per workgroup, the input of
+ * pcuda_bn_bwd_finalize; red == NULL only reports ntiles */
+int pcuda_upsample2_bwd_bnred(const float* dy, long long dy_sn, long long dy_sc, float* dx, long long dx_sn,
+                              long long dx_sc, int accumulate, const float* a, long long a_sn, long long a_sc,
+                              const float* mean, const float* invstd, float* red, int* ntiles, int n, int c, int h, int w,
+                              pcuda_stream_t s);
 /* bilinear resize, align_corners = True (nn.UpsamplingBilinear2d(size=(224, 224)) in OutputDiscriminator, GAN.py:57,78):
  * y dense [n][c][oh][ow]; ATen's arithmetic (src = dst * (in-1)/(out-1)).  bwd: dx = J^T dy, gather form (deterministic) */
 int pcuda_bilinear_fwd(const float* x, long long x_sn, long long x_sc, int n, int c, int h, int w, float* y, int oh,

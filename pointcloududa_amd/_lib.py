@@ -68,6 +68,8 @@ _PROTOS = {
     "pcuda_maxpool2_fwd": (i32, [vp, i64, i64, vp, vp, vp, i64, i64, vp, i32, i32, i32, i32, vp]),
     "pcuda_maxpool2_bwd": (i32, [vp, i64, i64, vp, i64, i64, vp, vp, i64, i64, i32, i32, i32, i32, i32, vp]),
     "pcuda_upsample2_bwd": (i32, [vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, i32, vp]),
+    "pcuda_upsample2_bwd_bnred": (i32, [vp, i64, i64, vp, i64, i64, i32, vp, i64, i64, vp, vp, vp, C.POINTER(i32), i32, i32,
+                                        i32, i32, vp]),
     "pcuda_bilinear_fwd": (i32, [vp, i64, i64, i32, i32, i32, i32, vp, i32, i32, vp]),
     "pcuda_bilinear_bwd": (i32, [vp, i32, i32, i32, i32, vp, i64, i64, i32, i32, vp]),
     "pcuda_unfold_taps": (i32, [vp, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp]),

@@ -204,6 +204,10 @@ struct PwParams {
   float slope;
   int accumulate;
   int n, hw, cin, cout;
+  // dgrad with the BatchNorm-backward reduce of the layer that consumes dx (see pcuda_conv2d_dgrad_bnred)
+  const float* red_a; long long red_sn, red_sc;
+  const float* red_mean; const float* red_invstd;
+  float* red;              // [n * blocks per image][cin][2]
 };
 
 __device__ __forceinline__ const float* pw_src_plane(const pcuda_src& x, int n, int c) {
@@ -272,10 +276,11 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const PwParams p) {
 }
 
 // dgrad packed layout: rows = cin (tiles of row_tile), reduction = cout: w[co][ci] at ((ci/row_tile) * row_tile + ci%row_tile) * rec + co
-template <int CO>
+template <int CO, bool RED>
 __global__ __launch_bounds__(256) void pw_dgrad_kernel(const PwParams p) {
   __shared__ float sw[64 * CO];
-  const int tid = threadIdx.x;
+  __shared__ float sred[4][64][2];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   for (int i = tid; i < p.cin * CO; i += 256) {
     const int ci = i / CO, co = i - ci * CO;
     float v = 0.f;
@@ -288,8 +293,10 @@ __global__ __launch_bounds__(256) void pw_dgrad_kernel(const PwParams p) {
   }
   __syncthreads();
   const int n = blockIdx.y, nq = p.hw >> 2;
-  const int q = blockIdx.x * 256 + tid;
-  if (q >= nq) return;
+  const int q0 = blockIdx.x * 256 + tid;
+  const bool valid = q0 < nq;
+  if (!RED && !valid) return;
+  const int q = min(q0, nq - 1);
   f32x4 z[CO];
 #pragma unroll
   for (int co = 0; co < CO; ++co) {
@@ -311,7 +318,24 @@ __global__ __launch_bounds__(256) void pw_dgrad_kernel(const PwParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] += old[e];
     }
-    *(f32x4*)d = o;
+    if (valid) *(f32x4*)d = o;
+    if (RED) {
+      const f32x4 av = *(const f32x4*)(p.red_a + (long long)n * p.red_sn + (long long)ci * p.red_sc + 4 * q);
+      const float m = p.red_mean[ci], is = p.red_invstd[ci];
+      float s1 = (o[0] + o[1]) + (o[2] + o[3]);
+      float s2 = (o[0] * ((av[0] - m) * is) + o[1] * ((av[1] - m) * is)) + (o[2] * ((av[2] - m) * is) + o[3] * ((av[3] - m) * is));
+      s1 = wave_sum_l63(valid ? s1 : 0.f);
+      s2 = wave_sum_l63(valid ? s2 : 0.f);
+      if (lane == 63) { sred[wv][ci][0] = s1; sred[wv][ci][1] = s2; }
+    }
+  }
+  if (RED) {
+    __syncthreads();
+    if (tid < p.cin) {
+      const long long tile = (long long)n * gridDim.x + blockIdx.x;
+      p.red[(tile * p.cin + tid) * 2 + 0] = ((sred[0][tid][0] + sred[1][tid][0]) + sred[2][tid][0]) + sred[3][tid][0];
+      p.red[(tile * p.cin + tid) * 2 + 1] = ((sred[0][tid][1] + sred[1][tid][1]) + sred[2][tid][1]) + sred[3][tid][1];
+    }
   }
 }
 
@@ -386,13 +410,21 @@ int direct_forward(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const
   return 0;
 }
 
+int direct_dgrad_tiles(const pcuda_conv_geom* g) {
+  if (!direct_enabled() || !pw_geom(g)) return 0;
+  return g->n * cdiv((long long)g->in_h * g->in_w / 4, 256);
+}
+
+// red != NULL: the BatchNorm-backward reduce of the layer that consumes dx rides along (a, mean, invstd of that layer)
 int direct_dgrad(const pcuda_conv_geom* g, int prec, const pcuda_src* dy, const void* packed_w_dgrad, const pcuda_dst* dx,
-                 int accumulate, hipStream_t s, int* rc) {
+                 int accumulate, hipStream_t s, int* rc, const float* red_a, long long red_sn, long long red_sc,
+                 const float* red_mean, const float* red_invstd, float* red) {
   *rc = PCUDA_OK;
   if (!direct_enabled() || !pw_geom(g) || dy->scale1 || dy->c1 < g->cout) return 0;
   const bool twoy = dx->c1 < g->cin;
   if (!aligned16(dy->p1, dy->sn1, dy->sc1) || !aligned16(dx->p1, dx->sn1, dx->sc1) || (twoy && !aligned16(dx->p2, dx->sn2, dx->sc2)))
     return 0;
+  if (red && !aligned16(red_a, red_sn, red_sc)) return 0;
   PwParams p;
   p.x = *dy; p.y = *dx;
   p.wpack = (const uint16_t*)packed_w_dgrad;
@@ -402,14 +434,21 @@ int direct_dgrad(const pcuda_conv_geom* g, int prec, const pcuda_src* dy, const 
   p.row_tile = rt;
   p.bias = nullptr; p.slope = 1.f; p.accumulate = accumulate;
   p.n = g->n; p.hw = g->in_h * g->in_w; p.cin = g->cin; p.cout = g->cout;
+  p.red_a = red_a; p.red_sn = red_sn; p.red_sc = red_sc; p.red_mean = red_mean; p.red_invstd = red_invstd; p.red = red;
   const double flops = 2.0 * g->n * (double)g->out_h * g->out_w * g->cout * (double)g->cin;
   char tag[96];
-  snprintf(tag, sizeof(tag), "direct 1x1 dgrad n%d cin%d cout%d %dx%d", g->n, g->cin, g->cout, g->in_h, g->in_w);
+  snprintf(tag, sizeof(tag), "direct 1x1 dgrad%s n%d cin%d cout%d %dx%d", red ? "+bnred" : "", g->n, g->cin, g->cout, g->in_h, g->in_w);
   ProfScope prof(PCUDA_FAM_CONV_FWD, flops, s, tag);
   const dim3 grid(cdiv(p.hw / 4, 256), g->n);
-  if (g->cout <= 4) hipLaunchKernelGGL(pw_dgrad_kernel<4>, grid, dim3(256), 0, s, p);
-  else if (g->cout <= 5) hipLaunchKernelGGL(pw_dgrad_kernel<5>, grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL(pw_dgrad_kernel<8>, grid, dim3(256), 0, s, p);
+#define PW_DG(CO_)                                                                         \
+  do {                                                                                     \
+    if (red) hipLaunchKernelGGL((pw_dgrad_kernel<CO_, true>), grid, dim3(256), 0, s, p);   \
+    else hipLaunchKernelGGL((pw_dgrad_kernel<CO_, false>), grid, dim3(256), 0, s, p);      \
+  } while (0)
+  if (g->cout <= 4) PW_DG(4);
+  else if (g->cout <= 5) PW_DG(5);
+  else PW_DG(8);
+#undef PW_DG
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { pcuda_set_error("pw_dgrad_kernel: %s", hipGetErrorString(e)); *rc = PCUDA_E_LAUNCH; }
   return 1;

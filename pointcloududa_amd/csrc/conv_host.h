@@ -140,8 +140,11 @@ static inline bool te_dst_ok(const pcuda_dst* y, int cout, int out_w, int lw, in
 int direct_fwd_tiles(const pcuda_conv_geom* g);
 int direct_forward(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const void* packed_w, long long w_lo_off,
                    const float* bias, float slope, const pcuda_dst* y, float* bn_partials, hipStream_t s, int* rc);
+int direct_dgrad_tiles(const pcuda_conv_geom* g);
 int direct_dgrad(const pcuda_conv_geom* g, int prec, const pcuda_src* dy, const void* packed_w_dgrad, const pcuda_dst* dx,
-                 int accumulate, hipStream_t s, int* rc);
+                 int accumulate, hipStream_t s, int* rc, const float* red_a = nullptr, long long red_sn = 0,
+                 long long red_sc = 0, const float* red_mean = nullptr, const float* red_invstd = nullptr,
+                 float* red = nullptr);
 size_t direct_wgrad_workspace(const pcuda_conv_geom* g);
 int direct_wgrad(const pcuda_conv_geom* g, const pcuda_src* x, const float* dz, long long dz_sn, long long dz_sc, float* dw,
                  float* db, int accumulate, void* workspace, hipStream_t s, int* rc);

@@ -473,6 +473,7 @@ extern "C" int pcuda_debug_read_clocks(unsigned long long* out8) {
 // ------------------------------------------------------------------------------------------
 extern "C" int pcuda_conv2d_dgrad_tiles(const pcuda_conv_geom* g, int prec) {
   if (!geom_ok(g) || g->stride != 1) return 0;
+  if (const int d = direct_dgrad_tiles(g)) return d;
   TapSet t = dgrad_taps(g, 0, 0);
   IgemmPlan pl;
   if (plan_igemm(g->cin, g->cout, g->n, g->in_h, g->in_w, g->out_h, g->out_w, 1, t, prec == PCUDA_PREC_BF16X3, &pl) < 0) return 0;
@@ -488,6 +489,12 @@ extern "C" int pcuda_conv2d_dgrad_bnred(const pcuda_conv_geom* g, int prec, cons
   if (prec != PCUDA_PREC_BF16X3 && prec != PCUDA_PREC_BF16) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_dgrad_bnred: bad precision");
   if (g->stride != 1 || g->in_up || (((uintptr_t)a) & 15) || (a_sn & 3) || (a_sc & 3))
     PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv2d_dgrad_bnred: stride-1 layers with 16-byte aligned activations only");
+  if (direct_dgrad_tiles(g)) {   // (the tile count the caller sized red_partials by is the direct kernel's)
+    int rc;
+    if (direct_dgrad(g, prec, dy, packed_w_dgrad, dx, accumulate, (hipStream_t)s, &rc, a, a_sn, a_sc, mean, invstd, red_partials))
+      return rc;
+    PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv2d_dgrad_bnred: 1x1 layer with tensors the direct kernel does not take");
+  }
   TapSet t = dgrad_taps(g, 0, 0);
   IgemmParams p;
   memset(&p, 0, sizeof(p));

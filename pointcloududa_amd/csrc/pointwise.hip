@@ -340,20 +340,45 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
   }
 }
 
+// RED: the BatchNorm-backward reduce of the layer that consumes dx rides along: per workgroup and channel
+// (sum g, sum g * (a - mean) * invstd) over the stored gradient g -- bn_bwd_reduce's partials, same tile indexing
+template <bool RED>
 __global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restrict__ dy, long long dy_sn,
                                                             long long dy_sc, float* __restrict__ dx, long long dx_sn,
-                                                            long long dx_sc, int accumulate, int h, int w) {
+                                                            long long dx_sc, int accumulate, int h, int w,
+                                                            const float* __restrict__ a, long long a_sn, long long a_sc,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, int c,
+                                                            float* __restrict__ red) {
+  __shared__ float sh[4];
   const int ch = blockIdx.y, n = blockIdx.z;
   const float* pd = dy + n * dy_sn + ch * dy_sc;
   float* px = dx + n * dx_sn + ch * dx_sc;
+  const float* pa = RED ? a + n * a_sn + ch * a_sc : nullptr;
+  const float m = RED ? mean[ch] : 0.f, is = RED ? invstd[ch] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
   const int total = h * w;
   for (int o = blockIdx.x * PCH + threadIdx.x; o < min(total, (int)(blockIdx.x + 1) * PCH); o += 256) {
     const int oy = o / w, ox = o - oy * w;
     const float* r0 = pd + (long long)(2 * oy) * (2 * w) + 2 * ox;
     const float2 t0 = *(const float2*)r0;
     const float2 t1 = *(const float2*)(r0 + 2 * w);
-    const float s = (t0.x + t0.y) + (t1.x + t1.y);
-    px[o] = accumulate ? px[o] + s : s;
+    float s = (t0.x + t0.y) + (t1.x + t1.y);
+    if (accumulate) s += px[o];
+    px[o] = s;
+    if (RED) {
+      s1 += s;
+      s2 += s * ((pa[o] - m) * is);
+    }
+  }
+  if (RED) {
+    s1 = block_sum(s1, sh);
+    s2 = block_sum(s2, sh);
+    if (threadIdx.x == 0) {
+      const long long tile = (long long)n * gridDim.x + blockIdx.x;
+      red[(tile * c + ch) * 2 + 0] = s1;
+      red[(tile * c + ch) * 2 + 1] = s2;
+    }
   }
 }
 
@@ -627,8 +652,27 @@ extern "C" int pcuda_upsample2_bwd(const float* dy, long long dy_sn, long long d
   if (!dims_ok(n, c, (long long)h * w) || !dy || !dx || ((dy_sn | dy_sc) & 1) || (((uintptr_t)dy) & 7))
     PCUDA_FAIL(PCUDA_E_BADARG, "upsample2_bwd: bad arguments");
   ProfScope prof(PCUDA_FAM_POINTWISE, 20.0 * n * c * (double)h * w, (hipStream_t)s);
-  hipLaunchKernelGGL(upsample2_bwd_kernel, plane_grid(n, c, (long long)h * w), dim3(256), 0, (hipStream_t)s, dy, dy_sn,
-                     dy_sc, dx, dx_sn, dx_sc, accumulate, h, w);
+  hipLaunchKernelGGL(upsample2_bwd_kernel<false>, plane_grid(n, c, (long long)h * w), dim3(256), 0, (hipStream_t)s, dy, dy_sn,
+                     dy_sc, dx, dx_sn, dx_sc, accumulate, h, w, nullptr, 0, 0, nullptr, nullptr, c, nullptr);
+  PCUDA_CHECK_LAUNCH("upsample2_bwd_kernel");
+  return PCUDA_OK;
+}
+
+/* the same with the BatchNorm-backward reduce of the layer that consumes dx fused in (unet.py:128-136: the decoder's
+ * up-convolution feeds conv -> LeakyReLU -> BN blocks; going back, the 2x2 fold's output IS that BatchNorm's incoming
+ * gradient): red[ntiles][c][2], ntiles as pcuda_bn_bwd_reduce reports them (query with red == NULL) */
+extern "C" int pcuda_upsample2_bwd_bnred(const float* dy, long long dy_sn, long long dy_sc, float* dx, long long dx_sn,
+                                         long long dx_sc, int accumulate, const float* a, long long a_sn, long long a_sc,
+                                         const float* mean, const float* invstd, float* red, int* ntiles, int n, int c,
+                                         int h, int w, pcuda_stream_t s) {
+  if (!dims_ok(n, c, (long long)h * w)) PCUDA_FAIL(PCUDA_E_BADARG, "upsample2_bwd_bnred: bad dims");
+  if (ntiles) *ntiles = n * cdiv((long long)h * w, PCH);
+  if (!red) return PCUDA_OK;
+  if (!dy || !dx || !a || !mean || !invstd || ((dy_sn | dy_sc) & 1) || (((uintptr_t)dy) & 7))
+    PCUDA_FAIL(PCUDA_E_BADARG, "upsample2_bwd_bnred: bad arguments");
+  ProfScope prof(PCUDA_FAM_POINTWISE, 24.0 * n * c * (double)h * w, (hipStream_t)s);
+  hipLaunchKernelGGL(upsample2_bwd_kernel<true>, plane_grid(n, c, (long long)h * w), dim3(256), 0, (hipStream_t)s, dy, dy_sn,
+                     dy_sc, dx, dx_sn, dx_sc, accumulate, h, w, a, a_sn, a_sc, mean, invstd, c, red);
   PCUDA_CHECK_LAUNCH("upsample2_bwd_kernel");
   return PCUDA_OK;
 }

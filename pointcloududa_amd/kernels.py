@@ -341,13 +341,27 @@ def maxpool2_bwd(dy, idx, h, w, dy2=None):
     return dx
 
 
-def upsample2_bwd(dy):
+def upsample2_bwd(dy, bnred=None):
+    """2x2 fold (backward of nearest x2).  ``bnred=(a, BNState)``: the BatchNorm-backward reduce of the layer that
+    consumes the result rides along; returns (dx, (partials, ntiles))."""
     n, c, _, dsn, dsc = _planes(dy)
     h, w = dy.shape[2] // 2, dy.shape[3] // 2
     dx = torch.empty((n, c, h, w), dtype=torch.float32, device=dy.device)
-    check(L.lib().pcuda_upsample2_bwd(dy.data_ptr(), dsn, dsc, dx.data_ptr(), dx.stride(0), dx.stride(1), 0, n, c, h,
-                                      w, _stream()), "upsample2_bwd")
-    return dx
+    lib = L.lib()
+    if bnred is not None and _fuse_bnred:
+        a, st = bnred
+        _, _, _, asn, asc = _planes(a)
+        nt = C.c_int(0)
+        check(lib.pcuda_upsample2_bwd_bnred(None, 0, 0, None, 0, 0, 0, None, 0, 0, None, None, None, C.byref(nt), n, c, h, w,
+                                            _stream()), "upsample2_bwd_bnred(query)")
+        red = torch.empty((nt.value, c, 2), dtype=torch.float32, device=dy.device)
+        check(lib.pcuda_upsample2_bwd_bnred(dy.data_ptr(), dsn, dsc, dx.data_ptr(), dx.stride(0), dx.stride(1), 0,
+                                            a.data_ptr(), asn, asc, st.mean.data_ptr(), st.invstd.data_ptr(),
+                                            red.data_ptr(), C.byref(nt), n, c, h, w, _stream()), "upsample2_bwd_bnred")
+        return dx, (red, nt.value)
+    check(lib.pcuda_upsample2_bwd(dy.data_ptr(), dsn, dsc, dx.data_ptr(), dx.stride(0), dx.stride(1), 0, n, c, h,
+                                  w, _stream()), "upsample2_bwd")
+    return (dx, None) if bnred is not None else dx
 
 
 def bilinear_fwd(x, oh, ow):

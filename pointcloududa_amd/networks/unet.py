@@ -88,10 +88,12 @@ class _SegEngine:
         S[blk] = (x, x2, a0, st0, a1, st1)
         return TA(a1, st1.scale, st1.shift)
 
-    def _dc_bwd(self, P, G, blk, dy, dy2, h, w, S, need_dx):
+    def _dc_bwd(self, P, G, blk, dy, dy2, h, w, S, need_dx, red=None):
+        """``red``: the second BatchNorm's backward-reduce partials where the kernel that produced ``dy`` already
+        computed them (decoder blocks: the classifier's dgrad, the 2x2 fold behind an up-convolution)"""
         x, x2, a0, st0, a1, st1 = S[blk]
         dz1 = K.bn_backward(dy, a1, st1, P[blk + ".5.weight"], G(blk + ".5.weight"), G(blk + ".5.bias"), dy2=dy2,
-                            act_slope=SLOPE)
+                            act_slope=SLOPE, red=red if dy2 is None else None)
         if G(blk + ".3.weight") is not None:
             self.ops[blk + ".3"].wgrad(TA(a0, st0.scale, st0.shift), dz1, G(blk + ".3.weight"), G(blk + ".3.bias"), h, w)
         # the second convolution's data gradient IS the first BatchNorm's incoming gradient: its reduce (sum g,
@@ -191,14 +193,21 @@ class _SegEngine:
             d_logits = d_logits.contiguous()
             if G("classifier.weight") is not None:
                 self.ops["classifier"].wgrad(S["cls_in"], d_logits, G("classifier.weight"), G("classifier.bias"), H, W)
-            d_cur = self.ops["classifier"].dgrad(d_logits, P["classifier.weight"], H, W)
+            # every decoder block's incoming gradient has ONE producer (the classifier's dgrad, then the 2x2 fold behind
+            # each up-convolution): that kernel also computes the block's second BatchNorm's backward-reduce partials
+            bn_of = lambda i: (S["decoder.decoder2_%d" % (i + 1)][4], S["decoder.decoder2_%d" % (i + 1)][5])
+            d_cur, red = self.ops["classifier"].dgrad(d_logits, P["classifier.weight"], H, W, bnred=bn_of(0))
             for i in range(nb):
                 oh, ow = H >> i, W >> i
-                d_skips[i], d_u = self._dc_bwd(P, G, "decoder.decoder2_%d" % (i + 1), d_cur, None, oh, ow, S, True)
+                d_skips[i], d_u = self._dc_bwd(P, G, "decoder.decoder2_%d" % (i + 1), d_cur, None, oh, ow, S, True, red=red)
                 up = "decoder.decoder1_%d.1" % (i + 1)
                 if G(up + ".weight") is not None:
                     self.ops[up].wgrad(S[up], d_u, G(up + ".weight"), G(up + ".bias"), oh, ow)
-                d_cur = K.upsample2_bwd(self.ops[up].dgrad(d_u, P[up + ".weight"], oh, ow))
+                d_up = self.ops[up].dgrad(d_u, P[up + ".weight"], oh, ow)
+                if i + 1 < nb:
+                    d_cur, red = K.upsample2_bwd(d_up, bnred=bn_of(i + 1))
+                else:
+                    d_cur, red = K.upsample2_bwd(d_up), None
             d_bsum = d_cur
         h, w = H >> nb, W >> nb
         if self.pointnet and d_verts is not None:

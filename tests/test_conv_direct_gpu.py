@@ -163,3 +163,39 @@ def test_dgrad_with_fused_bn_backward_reduce(dev, shape):
     got = part[:nt].double().sum(0).cpu()
     assert rel_err(dx, g_ref.float()) < 1e-4
     assert rel_err(got[:, 0], s1) < 1e-4 and rel_err(got[:, 1], s2) < 1e-4
+
+
+def test_decoder_reduce_fusions(dev):
+    """the two producers of a decoder block's incoming gradient carry its second BatchNorm's backward-reduce partials:
+    the 2x2 fold behind an up-convolution (pointwise kernel) and the 1x1 classifier's direct dgrad"""
+    from pointcloududa_amd import kernels as K
+    rng = np.random.default_rng(77)
+    n, c, h, w_ = 3, 6, 24, 40
+    gy = torch.from_numpy(rng.normal(0, 1, (n, c, 2 * h, 2 * w_)).astype(np.float32))
+    a = torch.from_numpy(rng.normal(0, 1, (n, c, h, w_)).astype(np.float32))
+    mean, invstd = a.mean((0, 2, 3)), 1.0 / torch.sqrt(a.var((0, 2, 3), unbiased=False) + 1e-5)
+    st = K.BNState()
+    st.mean, st.invstd = mean.to(dev), invstd.to(dev)
+    g_ref = F.avg_pool2d(gy.double(), 2) * 4
+    ahat = (a.double() - mean.double()[None, :, None, None]) * invstd.double()[None, :, None, None]
+    dx, red = K.upsample2_bwd(gy.to(dev), bnred=(a.to(dev), st))
+    part, nt = red
+    got = part[:nt].double().sum(0).cpu()
+    assert rel_err(dx, g_ref.float()) < 1e-6
+    assert rel_err(got[:, 0], g_ref.sum((0, 2, 3))) < 1e-5 and rel_err(got[:, 1], (g_ref * ahat).sum((0, 2, 3))) < 1e-5
+    # classifier: 32 -> 4, 1x1
+    n, cin, cout, h, w_ = 2, 32, 4, 48, 64
+    a = torch.from_numpy(rng.normal(0, 1, (n, cin, h, w_)).astype(np.float32))
+    w = torch.from_numpy(rng.normal(0, 0.1, (cout, cin, 1, 1)).astype(np.float32))
+    gz = torch.from_numpy(rng.normal(0, 1, (n, cout, h, w_)).astype(np.float32))
+    mean, invstd = a.mean((0, 2, 3)), 1.0 / torch.sqrt(a.var((0, 2, 3), unbiased=False) + 1e-5)
+    st.mean, st.invstd = mean.to(dev), invstd.to(dev)
+    g_ref = F.conv_transpose2d(gz, w).double()
+    ahat = (a.double() - mean.double()[None, :, None, None]) * invstd.double()[None, :, None, None]
+    op = K.ConvOp(cin, cout, 1)
+    dx, red = op.dgrad(gz.to(dev), w.to(dev), h, w_, bnred=(a.to(dev), st))
+    assert red is not None
+    part, nt = red
+    got = part[:nt].double().sum(0).cpu()
+    assert rel_err(dx, g_ref.float()) < 1e-4
+    assert rel_err(got[:, 0], g_ref.sum((0, 2, 3))) < 1e-4 and rel_err(got[:, 1], (g_ref * ahat).sum((0, 2, 3))) < 1e-4
