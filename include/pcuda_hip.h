@@ -105,6 +105,15 @@ int pcuda_conv2d_pack_dgrad(const pcuda_conv_geom* g, int prec, const float* w, 
 /* both repacks in ONE launch (forward layout + every dgrad parity class); packed_dgrad may be NULL */
 int pcuda_conv2d_pack_all(const pcuda_conv_geom* g, int prec, const float* w, void* packed_fwd, void* packed_dgrad,
                           pcuda_stream_t s);
+/* Batched repack (one launch for all layers of a network after an optimiser step): fill the job records of a layer
+ * (forward layout + every dgrad parity class; packed_dgrad may be NULL) into host memory -- returns the number of jobs
+ * written (<= 1 + stride^2) or <0; job_blocks[j] = workgroups job j needs.  Keep the concatenated records in DEVICE
+ * memory next to an int table first_block[j] (exclusive prefix sum of job_blocks over all jobs) and replay them with
+ * pcuda_conv2d_pack_table (total_blocks = the sum).  The records hold the raw pointers given here. */
+size_t pcuda_conv2d_pack_job_bytes(void);
+int pcuda_conv2d_pack_jobs_fill(const pcuda_conv_geom* g, int prec, const float* w, void* packed_fwd, void* packed_dgrad,
+                                void* host_jobs, int max_jobs, int* job_blocks);
+int pcuda_conv2d_pack_table(const void* dev_jobs, const int* dev_first_block, int njobs, int total_blocks, pcuda_stream_t s);
 
 /* y = lrelu(conv(x) + bias, slope)   (slope = 1 -> no activation; bias may be NULL)
  * bn_partials (optional): per-tile partial sums [ntiles][cout][2] (sum, sum of squares) of the

@@ -47,6 +47,9 @@ _PROTOS = {
     "pcuda_conv2d_pack_fwd": (i32, [C.POINTER(ConvGeom), i32, vp, vp, vp]),
     "pcuda_conv2d_pack_all": (i32, [C.POINTER(ConvGeom), i32, vp, vp, vp, vp]),
     "pcuda_conv2d_pack_dgrad": (i32, [C.POINTER(ConvGeom), i32, vp, vp, vp]),
+    "pcuda_conv2d_pack_job_bytes": (sz, []),
+    "pcuda_conv2d_pack_jobs_fill": (i32, [C.POINTER(ConvGeom), i32, vp, vp, vp, vp, i32, C.POINTER(i32)]),
+    "pcuda_conv2d_pack_table": (i32, [vp, vp, i32, i32, vp]),
     "pcuda_conv2d_fwd_tiles": (i32, [C.POINTER(ConvGeom), i32]),
     "pcuda_conv2d_forward": (i32, [C.POINTER(ConvGeom), i32, C.POINTER(Src), vp, vp, f32, C.POINTER(Dst), vp, vp]),
     "pcuda_conv2d_dgrad": (i32, [C.POINTER(ConvGeom), i32, C.POINTER(Src), vp, C.POINTER(Dst), i32, vp]),

@@ -24,10 +24,17 @@ __device__ __forceinline__ float wave_sum_l63(float v) {
   return v;
 }
 
-bool direct_enabled() {
-  static int off = -1;
-  if (off < 0) { const char* e = getenv("PCUDA_NODIRECT"); off = (e && atoi(e)) ? 1 : 0; }
-  return off == 0;
+// PCUDA_NODIRECT=1 switches every direct kernel off; PCUDA_DIRECT_MASK selects them one by one (A/B and bisection):
+// 1 first-layer forward, 2 first-layer wgrad, 4 classifier forward, 8 classifier dgrad, 16 / 32 discriminator first
+// layer dgrad / wgrad, 64 discriminator last layer forward
+bool direct_enabled(int bit) {
+  static int mask = -1;
+  if (mask < 0) {
+    const char* e = getenv("PCUDA_NODIRECT");
+    const char* m = getenv("PCUDA_DIRECT_MASK");
+    mask = (e && atoi(e)) ? 0 : (m ? atoi(m) : 0x7f);
+  }
+  return (mask & bit) != 0;
 }
 
 bool aligned16(const void* p, long long sn, long long sc) { return (((uintptr_t)p) & 15) == 0 && (sn & 3) == 0 && (sc & 3) == 0; }
@@ -352,16 +359,15 @@ bool pw_geom(const pcuda_conv_geom* g) {
 
 // ---- entry points used by conv_igemm.hip / conv_wgrad.hip (return 1 when the direct kernel took the launch) ----
 int direct_fwd_tiles(const pcuda_conv_geom* g) {
-  if (!direct_enabled() || !c1_geom(g)) return 0;
+  if (!direct_enabled(1) || !c1_geom(g)) return 0;
   return g->n * cdiv((long long)g->in_h * g->in_w / 4, 256);
 }
 
 int direct_forward(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const void* packed_w, long long w_lo_off,
                    const float* bias, float slope, const pcuda_dst* y, float* bn_partials, hipStream_t s, int* rc) {
   *rc = PCUDA_OK;
-  if (!direct_enabled()) return 0;
   const double flops = 2.0 * g->n * (double)g->out_h * g->out_w * g->cout * (double)g->cin * g->k * g->k;
-  if (c1_geom(g)) {
+  if (direct_enabled(1) && c1_geom(g)) {
     // (the BatchNorm partials are sized by pcuda_conv2d_fwd_tiles, which answers for this kernel whenever the
     // geometry qualifies: a tensor that fails the checks below must not fall back silently to another tile count)
     if (x->scale1 || y->c1 < g->cout || !aligned16(x->p1, x->sn1, 4) || !aligned16(y->p1, y->sn1, y->sc1)) {
@@ -385,7 +391,7 @@ int direct_forward(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const
     if (e != hipSuccess) { pcuda_set_error("c1_fwd_kernel: %s", hipGetErrorString(e)); *rc = PCUDA_E_LAUNCH; }
     return 1;
   }
-  if (pw_geom(g) && !bn_partials) {
+  if (direct_enabled(4) && pw_geom(g) && !bn_partials) {
     const bool two = x->c1 < g->cin, twoy = y->c1 < g->cout;
     if (!aligned16(x->p1, x->sn1, x->sc1) || (two && !aligned16(x->p2, x->sn2, x->sc2)) ||
         !aligned16(y->p1, y->sn1, y->sc1) || (twoy && !aligned16(y->p2, y->sn2, y->sc2)))
@@ -411,7 +417,7 @@ int direct_forward(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const
 }
 
 int direct_dgrad_tiles(const pcuda_conv_geom* g) {
-  if (!direct_enabled() || !pw_geom(g)) return 0;
+  if (!direct_enabled(8) || !pw_geom(g)) return 0;
   return g->n * cdiv((long long)g->in_h * g->in_w / 4, 256);
 }
 
@@ -420,7 +426,7 @@ int direct_dgrad(const pcuda_conv_geom* g, int prec, const pcuda_src* dy, const 
                  int accumulate, hipStream_t s, int* rc, const float* red_a, long long red_sn, long long red_sc,
                  const float* red_mean, const float* red_invstd, float* red) {
   *rc = PCUDA_OK;
-  if (!direct_enabled() || !pw_geom(g) || dy->scale1 || dy->c1 < g->cout) return 0;
+  if (!direct_enabled(8) || !pw_geom(g) || dy->scale1 || dy->c1 < g->cout) return 0;
   const bool twoy = dx->c1 < g->cin;
   if (!aligned16(dy->p1, dy->sn1, dy->sc1) || !aligned16(dx->p1, dx->sn1, dx->sc1) || (twoy && !aligned16(dx->p2, dx->sn2, dx->sc2)))
     return 0;
@@ -463,7 +469,7 @@ size_t direct_wgrad_workspace(const pcuda_conv_geom* g) {
 int direct_wgrad(const pcuda_conv_geom* g, const pcuda_src* x, const float* dz, long long dz_sn, long long dz_sc, float* dw,
                  float* db, int accumulate, void* workspace, hipStream_t s, int* rc) {
   *rc = PCUDA_OK;
-  if (!direct_enabled() || !c1_geom(g) || (g->in_h & 3) || x->scale1) return 0;
+  if (!direct_enabled(2) || !c1_geom(g) || (g->in_h & 3) || x->scale1) return 0;
   if (!aligned16(x->p1, x->sn1, 4) || !aligned16(dz, dz_sn, dz_sc)) return 0;
   C1WgParams p;
   p.x = x->p1; p.x_sn = x->sn1;

@@ -12,10 +12,17 @@ namespace {
 
 __device__ __forceinline__ float bf16_bits_to_float(uint16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
 
-bool direct_enabled() {
-  static int off = -1;
-  if (off < 0) { const char* e = getenv("PCUDA_NODIRECT"); off = (e && atoi(e)) ? 1 : 0; }
-  return off == 0;
+// PCUDA_NODIRECT=1 switches every direct kernel off; PCUDA_DIRECT_MASK selects them one by one (A/B and bisection):
+// 1 first-layer forward, 2 first-layer wgrad, 4 classifier forward, 8 classifier dgrad, 16 / 32 discriminator first
+// layer dgrad / wgrad, 64 discriminator last layer forward
+bool direct_enabled(int bit) {
+  static int mask = -1;
+  if (mask < 0) {
+    const char* e = getenv("PCUDA_NODIRECT");
+    const char* m = getenv("PCUDA_DIRECT_MASK");
+    mask = (e && atoi(e)) ? 0 : (m ? atoi(m) : 0x7f);
+  }
+  return (mask & bit) != 0;
 }
 bool aligned16(const void* p, long long sn, long long sc) { return (((uintptr_t)p) & 15) == 0 && (sn & 3) == 0 && (sc & 3) == 0; }
 
@@ -28,6 +35,7 @@ struct D1Params {
   int accumulate;
   int n, h, w, oh, ow, cin, cout;
   long long cls_stride;                       // dgrad: bf16 elements between the four parity-class images
+  int one;                                    // dgrad: 1 -- the element stride of dz, kept out of the compiler's sight (below)
 };
 
 // data gradient.  A 2x2 block of input pixels (2Y + py, 2X + px) sees the same four gradient pixels (Y + a, X + b),
@@ -63,13 +71,18 @@ __global__ __launch_bounds__(256) void d1_dgrad_kernel(const D1Params p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[ci][r][e] = 0.f;
   const float* zp = p.dz + (long long)n * p.dz_sn + (long long)Y * p.ow + X0;
+  // The five values of a row are read as five DWORD loads (index b * p.one, p.one == 1 at run time): the rows of dz are
+  // only 4-byte aligned (odd widths), and when the compiler merged them into one 4-byte-aligned global_load_dwordx4 plus a
+  // dword the kernel was not deterministic on a GPU shared by two processes -- 16-lane groups of single v_pk_fma_f32
+  // results differed between two launches on the same inputs (scripts/micro/d1_repro.py: 54 % of the launches; 0 of
+  // 48000 with dword loads; never seen with one process).  Wide loads in this library are naturally aligned.
   // (the next channel's ten gradient values are requested before this channel's FMAs: with the loads at the top of each
   // iteration the loop ran at one memory round trip per channel)
   float zn[2][5];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 5; ++b) zn[a][b] = zp[a * p.ow + b];
+    for (int b = 0; b < 5; ++b) zn[a][b] = zp[a * p.ow + b * p.one];
   for (int co = 0; co < p.cout; ++co) {
     float z[2][5];
 #pragma unroll
@@ -80,7 +93,7 @@ __global__ __launch_bounds__(256) void d1_dgrad_kernel(const D1Params p) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 5; ++b) zn[a][b] = zp[(long long)con * p.dz_sc + a * p.ow + b];
+      for (int b = 0; b < 5; ++b) zn[a][b] = zp[(long long)con * p.dz_sc + a * p.ow + b * p.one];
     const float* wc = sw + co * CIN * 16;
 #pragma unroll
     for (int ci = 0; ci < CIN; ++ci)
@@ -231,7 +244,7 @@ const int D1_WG_BLOCKS = 768;   // persistent grid of the weight gradient (3 wor
 int direct_d1_dgrad(const pcuda_conv_geom* g, int prec, const pcuda_src* dy, const void* packed_w_dgrad, const pcuda_dst* dx,
                     int accumulate, size_t cls_elems, hipStream_t s, int* rc) {
   *rc = PCUDA_OK;
-  if (!direct_enabled() || !d1_geom(g) || dy->scale1 || dy->c1 < g->cout || dx->c1 < g->cin) return 0;
+  if (!direct_enabled(16) || !d1_geom(g) || dy->scale1 || dy->c1 < g->cout || dx->c1 < g->cin) return 0;
   if (!aligned16(dx->p1, dx->sn1, dx->sc1)) return 0;
   D1Params p;
   memset(&p, 0, sizeof(p));
@@ -240,6 +253,7 @@ int direct_d1_dgrad(const pcuda_conv_geom* g, int prec, const pcuda_src* dy, con
   p.wpack = (const uint16_t*)packed_w_dgrad; p.rec = ig_rec_bytes(prec == PCUDA_PREC_BF16X3) / 2;
   p.cls_stride = (long long)cls_elems;
   p.accumulate = accumulate;
+  p.one = 1;
   p.n = g->n; p.h = g->in_h; p.w = g->in_w; p.oh = g->out_h; p.ow = g->out_w; p.cin = g->cin; p.cout = g->cout;
   const double flops = 2.0 * g->n * (double)g->out_h * g->out_w * g->cout * (double)g->cin * 16;
   char tag[96];
@@ -266,7 +280,7 @@ size_t direct_d1_wgrad_workspace(const pcuda_conv_geom* g) {
 int direct_d1_wgrad(const pcuda_conv_geom* g, const pcuda_src* x, const float* dz, long long dz_sn, long long dz_sc, float* dw,
                     float* db, int accumulate, void* workspace, hipStream_t s, int* rc) {
   *rc = PCUDA_OK;
-  if (!direct_enabled() || !d1_geom(g) || g->cin > 4 || x->scale1 || x->c1 < g->cin || db) return 0;
+  if (!direct_enabled(32) || !d1_geom(g) || g->cin > 4 || x->scale1 || x->c1 < g->cin || db) return 0;
   if (!aligned16(x->p1, x->sn1, x->sc1)) return 0;
   D1Params p;
   memset(&p, 0, sizeof(p));
@@ -407,7 +421,7 @@ bool d5_geom(const pcuda_conv_geom* g) {
 int direct_d5_forward(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const void* packed_w, const float* bias,
                       float slope, const pcuda_dst* y, float* bn_partials, hipStream_t s, int* rc) {
   *rc = PCUDA_OK;
-  if (!direct_enabled() || !d5_geom(g) || bn_partials || x->scale1 || x->c1 < g->cin) return 0;
+  if (!direct_enabled(64) || !d5_geom(g) || bn_partials || x->scale1 || x->c1 < g->cin) return 0;
   D5Params p;
   p.x = x->p1; p.x_sn = x->sn1; p.x_sc = x->sc1;
   p.y = y->p1; p.y_sn = y->sn1;

@@ -70,6 +70,41 @@ __global__ void pack_multi_kernel(const PackJobs jobs) {
   }
 }
 
+// every repack of a network in ONE launch: the jobs (one per layout: forward + each dgrad parity class of every layer)
+// live in device memory; a workgroup owns PACK_TABLE_ELEMS consecutive elements of one job and finds it in the table of
+// first-block indices behind the jobs.  (Packed lazily, layer by layer, the 43 small launches of the segmenter sat in the
+// dependent chain of the next forward pass.)
+#define PACK_TABLE_ELEMS 2048
+__global__ __launch_bounds__(256) void pack_table_kernel(const PackParams* __restrict__ jobs, const int* __restrict__ first_block,
+                                                         int njobs) {
+  int lo = 0, hi = njobs - 1;          // last job whose first block is <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (first_block[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PackParams& p = jobs[lo];
+  const long long total = (long long)p.n_co_tiles * p.nchunks * p.ntaps * p.co_tile * p.rec;
+  const long long base = (long long)((int)blockIdx.x - first_block[lo]) * PACK_TABLE_ELEMS;
+  for (int e = threadIdx.x; e < PACK_TABLE_ELEMS; e += 256) {
+    const long long idx = base + e;
+    if (idx >= total) break;
+    int col = (int)(idx % p.rec);
+    long long rest = idx / p.rec;
+    int row = (int)(rest % p.co_tile); rest /= p.co_tile;
+    int t = (int)(rest % p.ntaps); rest /= p.ntaps;
+    int ch = (int)(rest % p.nchunks);
+    int cot = (int)(rest / p.nchunks);
+    const bool is_lo = p.rec > IG_REC && col >= 32;
+    const int cc = is_lo ? col - 32 : col;
+    int r = cot * p.co_tile + row, c = ch * 32 + cc;
+    float v = 0.f;
+    if (cc < 32 && r < p.rows && c < p.red) v = p.w[r * p.s_row + c * p.s_red + p.tap_src[t]];
+    __bf16 hi16 = (__bf16)v;
+    if (is_lo) hi16 = (__bf16)(v - (float)hi16);
+    p.out[idx] = __builtin_bit_cast(uint16_t, hi16);
+  }
+}
+
 // ==========================================================================================
 // host side
 // ==========================================================================================
@@ -510,4 +545,44 @@ extern "C" int pcuda_conv2d_dgrad_bnred(const pcuda_conv_geom* g, int prec, cons
   p.red_a = a; p.red_sn = a_sn; p.red_sc = a_sc; p.red_mean = mean; p.red_invstd = invstd;
   p.n = g->n;
   return launch_igemm(p, prec, t, (hipStream_t)s);
+}
+
+// ------------------------------------------------------------------------------------------
+// batched repack: the caller collects the jobs of all its layers once (host side), keeps them in device memory and
+// replays them with one launch after every optimiser step
+// ------------------------------------------------------------------------------------------
+extern "C" size_t pcuda_conv2d_pack_job_bytes(void) { return sizeof(PackParams); }
+
+extern "C" int pcuda_conv2d_pack_jobs_fill(const pcuda_conv_geom* g, int prec, const float* w, void* packed_fwd,
+                                           void* packed_dgrad, void* host_jobs, int max_jobs, int* job_blocks) {
+  if (!geom_ok(g) || !w || !packed_fwd || !host_jobs || max_jobs < 1 || !job_blocks)
+    PCUDA_FAIL(PCUDA_E_BADARG, "pack_jobs_fill: bad arguments");
+  if (prec != PCUDA_PREC_BF16X3 && prec != PCUDA_PREC_BF16) PCUDA_FAIL(PCUDA_E_BADARG, "pack_jobs_fill: bad precision");
+  PackParams* jobs = (PackParams*)host_jobs;
+  const int kk = g->k * g->k;
+  int nj = 0;
+  size_t plane = fill_pack(jobs[nj], w, (uint16_t*)packed_fwd, prec, g->cout, g->cin, (long long)g->cin * kk, kk, fwd_taps(g));
+  job_blocks[nj++] = (int)((plane + PACK_TABLE_ELEMS - 1) / PACK_TABLE_ELEMS);
+  if (packed_dgrad) {
+    uint16_t* out = (uint16_t*)packed_dgrad;
+    for (int ry = 0; ry < g->stride; ++ry)
+      for (int rx = 0; rx < g->stride; ++rx) {
+        TapSet t = dgrad_taps(g, ry, rx);
+        if (t.n == 0) continue;
+        if (nj >= max_jobs) PCUDA_FAIL(PCUDA_E_BADARG, "pack_jobs_fill: more layouts than job slots");
+        plane = fill_pack(jobs[nj], w, out, prec, g->cin, g->cout, kk, (long long)g->cin * kk, t);
+        job_blocks[nj++] = (int)((plane + PACK_TABLE_ELEMS - 1) / PACK_TABLE_ELEMS);
+        out += plane;
+      }
+  }
+  return nj;
+}
+
+extern "C" int pcuda_conv2d_pack_table(const void* dev_jobs, const int* dev_first_block, int njobs, int total_blocks,
+                                       pcuda_stream_t s) {
+  if (!dev_jobs || !dev_first_block || njobs < 1 || total_blocks < 1) PCUDA_FAIL(PCUDA_E_BADARG, "pack_table: bad arguments");
+  hipLaunchKernelGGL(pack_table_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)s, (const PackParams*)dev_jobs,
+                     dev_first_block, njobs);
+  PCUDA_CHECK_LAUNCH("pack_table_kernel");
+  return PCUDA_OK;
 }

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -102,12 +103,17 @@ def make_dst(a: torch.Tensor, b: Optional[torch.Tensor] = None) -> Dst:
 _fuse_bnred = os.environ.get("PCUDA_BNRED", "1") != "0"
 
 
+_conv_ops = weakref.WeakSet()      # every ConvOp alive (repack_owner finds a network's layers through their ``owner``)
+
+
 class ConvOp:
     """Geometry + packed-weight cache of one nn.Conv2d (square kernel, groups=1)."""
 
     def __init__(self, cin, cout, k, stride=1, pad=0, dil=1, in_up=False):
         self.cin, self.cout, self.k, self.stride, self.pad, self.dil, self.in_up = cin, cout, k, stride, pad, dil, in_up
         self._pk = {}     # (kind, prec) -> (weight ptr, version, generation, packed tensor)
+        self._last_fwd = None   # (weight tensor, geometry) of the latest forward-layout pack: what repack_owner replays
+        _conv_ops.add(self)
         # training: a forward-layout repack is followed by a dgrad in the same step, so both go out in one launch;
         # set False for layers whose input never needs a gradient / for inference-only use
         self.pack_dgrad_with_fwd = os.environ.get("PCUDA_PACK_ALL", "1") != "0"
@@ -154,6 +160,8 @@ class ConvOp:
             fn = lib.pcuda_conv2d_pack_fwd if kind == "fwd" else lib.pcuda_conv2d_pack_dgrad
             check(fn(C.byref(g), _precision, w.data_ptr(), buf.data_ptr(), _stream()), "pack_" + kind)
         self._pk[key] = (w.data_ptr(), w._version, gen, buf)
+        if kind == "fwd":
+            self._last_fwd = (w, g)
         return buf
 
     def forward(self, x, w, b, slope, in_h, in_w, x2=None, out=None, want_stats=False):
@@ -217,6 +225,59 @@ class ConvOp:
         check(lib.pcuda_conv2d_wgrad(C.byref(g), _precision, C.byref(src), dy.data_ptr(), sn, sc, dw.data_ptr(),
                                      _ptr(db), 1 if accumulate else 0, ws.data_ptr(), ws_bytes, _stream()),
               "conv2d_wgrad")
+
+
+_batch_repack = os.environ.get("PCUDA_PACK_TABLE", "1") != "0"
+
+
+def repack_owner(owner):
+    """All packed-weight layouts of ``owner``'s convolutions in ONE launch (called behind the optimiser kernel that
+    changed the weights).  The jobs -- raw pointers of the flat master weights and of the packed buffers, which both
+    stay put -- are collected once into a device table and replayed every step; layers that have not run yet (no
+    packed buffers) keep the lazy per-layer path.  Lazily, the segmenter's 43 repack launches sat in the dependent
+    chain of the next forward pass."""
+    if not _batch_repack:
+        return False
+    lib = L.lib()
+    ops = [op for op in _conv_ops if op.owner is owner and op._last_fwd is not None]
+    if not ops:
+        return False
+    gen = getattr(owner, "_wgen", 0)
+    key, entries = [], []
+    for op in ops:
+        w, g = op._last_fwd
+        fhit = op._pk.get(("fwd", _precision))
+        dhit = op._pk.get(("dgrad", _precision)) if op.pack_dgrad_with_fwd else None
+        if fhit is None or fhit[0] != w.data_ptr() or (op.pack_dgrad_with_fwd and dhit is None):
+            continue
+        entries.append((op, w, g, fhit[3], None if dhit is None else dhit[3]))
+        key.append((id(op), w.data_ptr(), fhit[3].data_ptr(), 0 if dhit is None else dhit[3].data_ptr()))
+    if not entries:
+        return False
+    key = (tuple(sorted(key)), _precision)
+    tab = getattr(owner, "_pack_table", None)
+    if tab is None or tab[0] != key:
+        jb = lib.pcuda_conv2d_pack_job_bytes()
+        chunks, blocks = [], []
+        for op, w, g, fb, db in entries:
+            host = C.create_string_buffer(jb * 8)
+            jblk = (C.c_int * 8)()
+            nj = lib.pcuda_conv2d_pack_jobs_fill(C.byref(g), _precision, w.data_ptr(), fb.data_ptr(),
+                                                 None if db is None else db.data_ptr(), host, 8, jblk)
+            if nj < 0:
+                check(nj, "pack_jobs_fill")
+            chunks.append(host.raw[:jb * nj]); blocks += list(jblk[:nj])
+        dev = entries[0][1].device
+        blob = torch.frombuffer(bytearray(b"".join(chunks)), dtype=torch.uint8).to(dev)
+        first = torch.tensor([sum(blocks[:j]) for j in range(len(blocks))], dtype=torch.int32).to(dev)
+        tab = (key, blob, first, len(blocks), sum(blocks))
+        owner._pack_table = tab
+    check(lib.pcuda_conv2d_pack_table(tab[1].data_ptr(), tab[2].data_ptr(), tab[3], tab[4], _stream()), "pack_table")
+    for op, w, g, fb, db in entries:          # the caches are current for this weight generation
+        op._pk[("fwd", _precision)] = (w.data_ptr(), w._version, gen, fb)
+        if db is not None:
+            op._pk[("dgrad", _precision)] = (w.data_ptr(), w._version, gen, db)
+    return True
 
 
 # ------------------------------------------------------------------------------------------

@@ -143,6 +143,7 @@ class FusedAdam(_FlatOptimizer):
         self.module._wgen = getattr(self.module, "_wgen", 0) + 1   # packed conv weights are stale now
         K.adam_step_dev(self.p, self.g, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
                         self.step_t, grad_scale)
+        K.repack_owner(self.module)   # every packed conv-weight layout of the network, one launch behind the update
 
     def state_dict(self):
         return {"steps": int(self.step_t.item()), "lr": self.lr, "exp_avg": self.m, "exp_avg_sq": self.v}
@@ -188,6 +189,7 @@ class FusedSGD(_FlatOptimizer):
         self.module._wgen = getattr(self.module, "_wgen", 0) + 1
         K.sgd_step(self.p, self.g, self.buf, self.lr, self.momentum, self.wd, self.steps == 0, grad_scale)
         self.steps += 1
+        K.repack_owner(self.module)
 
     def state_dict(self):
         return {"steps": self.steps, "lr": self.lr, "momentum_buffer": self.buf}

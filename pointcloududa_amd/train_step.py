@@ -71,6 +71,7 @@ class AdversarialTrainer:
         self.d_overlap = os.environ.get("PCUDA_DOVERLAP", "1") != "0"   # discriminator update under the G backward
         self.early_fwd2 = os.environ.get("PCUDA_EARLY2", "1") != "0"    # target forward ahead of the source backward
         self.d_batch = os.environ.get("PCUDA_DBATCH", "1") != "0"       # d1 / d2: source + target as one batch
+        self.bucketed = os.environ.get("PCUDA_BUCKET", "1") != "0"      # data parallel: first all-reduce bucket from inside the backward pass
 
     def _side_streams(self, names):
         """One side stream PER DISCRIMINATOR, keyed by its name: a network's frozen pass (phase 2), its input-gradient
@@ -148,7 +149,7 @@ class AdversarialTrainer:
         g_works, split = [], 0
         if adv_t:
             eng = getattr(self.gen, "_engine", None)
-            if eng is not None and _collectives_on(self.group):
+            if eng is not None and self.bucketed and _collectives_on(self.group):
                 split = self.opt_gen.split_after("encoder.")
                 if split:
                     eng.after_deep_grads = lambda: g_works.append(
@@ -298,6 +299,8 @@ class AdversarialTrainer:
             # 5. update (:325-330)
             if g_work is not None:
                 self.opt_gen.finish_all_reduce(g_work)
+                if keep:
+                    self.last["grad_reduced"] = self.opt_gen.g.clone()     # (diagnostics: the summed gradient)
                 self.opt_gen.step(g_scale)
                 g_work = None
             for nm in ("d1", "d2", "d4"):

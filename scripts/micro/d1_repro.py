@@ -1,0 +1,68 @@
+"""debug aid: are the kernels deterministic when two processes with several busy streams share the GPU?
+Each process repeats the same launch and counts results that differ from its own first one.
+usage: d1_repro.py NPROC ITERS VICTIM HEAVY   (env SIDE = extra busy streams per process)"""
+import os, sys
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, root)
+import torch, torch.multiprocessing as mp
+
+
+def work(rank, iters, victim, heavy):
+    import pointcloududa_amd.kernels as K
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    rn = lambda *s: torch.randn(*s, generator=g).to(dev)
+    big = K.ConvOp(32, 32, 3, stride=1, pad=1)
+    wb, xb, bb = rn(32, 32, 3, 3) * 0.05, rn(4, 32, 256, 256), torch.zeros(32, device=dev)
+    ma = rn(2048, 2048)
+    if victim == "d1dgrad":
+        op, w, dy = K.ConvOp(4, 64, 4, stride=2, pad=2), rn(64, 4, 4, 4) * 0.05, rn(4, 64, 49, 49)
+        run = lambda: op.dgrad(dy, w, 96, 96)
+    elif victim == "d2dgrad":        # the discriminators' second layer (MFMA kernels, four parity classes)
+        op, w, dy = K.ConvOp(64, 128, 4, stride=2, pad=2), rn(128, 64, 4, 4) * 0.05, rn(4, 128, 25, 25)
+        run = lambda: op.dgrad(dy, w, 49, 49)
+    elif victim == "conv":
+        op, w, x, b = K.ConvOp(16, 16, 3, stride=1, pad=1), rn(16, 16, 3, 3) * 0.05, rn(4, 16, 128, 128), torch.zeros(16, device=dev)
+        run = lambda: op.forward(x, w, b, 1.0, 128, 128)[0]
+    elif victim == "c1fwd":
+        op, w, x, b = K.ConvOp(1, 4, 3, stride=1, pad=1), rn(4, 1, 3, 3) * 0.05, rn(4, 1, 256, 256), torch.zeros(4, device=dev)
+        run = lambda: op.forward(x, w, b, 1.0, 256, 256)[0]
+    elif victim == "pwdgrad":
+        op, w, dy = K.ConvOp(4, 4, 1), rn(4, 4, 1, 1) * 0.05, rn(4, 4, 256, 256)
+        run = lambda: op.dgrad(dy, w, 256, 256)
+    elif victim == "d5fwd":
+        op, w, x, b = K.ConvOp(512, 1, 4, stride=2, pad=2), rn(1, 512, 4, 4) * 0.05, rn(4, 512, 7, 7), torch.zeros(1, device=dev)
+        run = lambda: op.forward(x, w, b, 1.0, 7, 7)[0]
+    elif victim == "torchconv":
+        w, x = rn(64, 4, 4, 4) * 0.05, rn(4, 4, 96, 96)
+        run = lambda: torch.nn.functional.conv2d(x, w, stride=2, padding=2)
+    else:
+        raise SystemExit("victim?")
+    side = [torch.cuda.Stream() for _ in range(int(os.environ.get("SIDE", "4")))]
+    ref = run().clone()
+    torch.cuda.synchronize()
+    bad = torch.zeros((), dtype=torch.int64, device=dev)
+    worst = torch.zeros((), device=dev)
+    for it in range(iters):
+        if side and it % 8 == 0:
+            for st in side:
+                with torch.cuda.stream(st):
+                    torch.mm(ma, ma)
+        if heavy == "conv":
+            big.forward(xb, wb, bb, 1.0, 256, 256)
+        elif heavy == "mm":
+            torch.mm(ma, ma)
+        d = (run() - ref).abs().max()
+        bad += (d > 0).long()
+        worst = torch.maximum(worst, d)
+    torch.cuda.synchronize()
+    print("%-9s heavy=%-4s rank %d mismatching launches %5d of %d worst abs diff %.3e (max |ref| %.3e)" % (
+        victim, heavy, rank, int(bad), iters, float(worst), float(ref.abs().max())), flush=True)
+
+
+if __name__ == "__main__":
+    nproc, iters, victim, heavy = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    if nproc == 1:
+        work(0, iters, victim, heavy)
+    else:
+        mp.spawn(work, args=(iters, victim, heavy), nprocs=nproc, join=True)
