@@ -311,6 +311,13 @@ int pcuda_jaccard_bwd(const void* truth, int truth_is_u8, int n, int c, long lon
  * workspace: b*h*w*4 + 4096 bytes */
 int pcuda_surface_vertices(const uint8_t* mask, int b, int h, int w, int* verts, int max_verts, int* counts,
                            void* workspace, size_t workspace_bytes, pcuda_stream_t s);
+/* second vertex-list mode: marching-cubes traversal order on the 3-slice stack (cells nested slice / row / column, per
+ * cell the edges 6,5,10,0,1,2,3,4,7,8,9,11, one vertex per crossing edge at its background end, duplicates included);
+ * replaces mcubes.marching_cubes(vol, 0) at utils/npy2point.py:112,121 as far as the un-vendored library's published
+ * algorithm pins it (parity unpinned, oracle/sampler.py).  verts int32 [b][max_verts][3] rows (slice,row,col); counts[b]
+ * = vertices found (may exceed max_verts: only the first max_verts are written) */
+int pcuda_surface_vertices_mc(const uint8_t* mask, int b, int h, int w, int* verts, int max_verts, int* counts,
+                              pcuda_stream_t s);
 /* farthest point sampling (graipher): pts float64 [b][npts_max][3] with counts[b] valid rows;
  * first[b] = start index; out idx int32 [b][k].  Bit-exact with numpy float64 (no FMA contraction,
  * first-occurrence argmax).  counts[b] == 0 -> idx all -1 */

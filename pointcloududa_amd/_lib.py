@@ -102,6 +102,7 @@ _PROTOS = {
     "pcuda_max_points_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "pcuda_bmm": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "pcuda_surface_vertices": (i32, [vp, i32, i32, i32, vp, i32, vp, vp, sz, vp]),
+    "pcuda_surface_vertices_mc": (i32, [vp, i32, i32, i32, vp, i32, vp, vp]),
     "pcuda_fps": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
     "pcuda_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
     "pcuda_adam_step_dev": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, f32, vp]),

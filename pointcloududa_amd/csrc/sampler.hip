@@ -41,6 +41,63 @@ __global__ __launch_bounds__(256) void surface_vertices_kernel(const uint8_t* __
   if (threadIdx.x == 0) counts[b] = 3 * total;
 }
 
+// Marching-cubes-order mode (oracle/sampler.py: surface_vertices_mc; parity unpinned): cells of the 3-slice stack in
+// (slice, row, column)-nested order, per cell the edges 6, 5, 10, 0, 1, 2, 3, 4, 7, 8, 9, 11 (Bourke numbering), an edge
+// is emitted by the first cell that contains it, one vertex per crossing edge at its background end.
+// One workgroup per mask; thread t owns the cell rows (i, j) = t, t + 256, ...: count, LDS prefix, ordered write.
+__constant__ signed char MC_CORNER[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+__constant__ signed char MC_EDGE[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6}, {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+__constant__ signed char MC_ORDER[12] = {6, 5, 10, 0, 1, 2, 3, 4, 7, 8, 9, 11};
+// bit 0 / 1 / 2: the edge is new only if i / j / k == 0 (all named indices); 6, 5, 10: always
+__constant__ signed char MC_NEED0[12] = {6, 4, 4, 5, 2, 0, 0, 1, 3, 2, 0, 1};
+
+__global__ __launch_bounds__(256) void surface_vertices_mc_kernel(const uint8_t* __restrict__ mask, int h, int w,
+                                                                  int* __restrict__ verts, int max_verts,
+                                                                  int* __restrict__ counts) {
+  extern __shared__ int rowcnt[];   // 2 * (h - 1) + 1
+  const int b = blockIdx.x;
+  const uint8_t* m = mask + (long long)b * h * w;
+  const int nj = h - 1, nk = w - 1, nrows = 2 * nj;
+  int* out = verts + (long long)b * max_verts * 3;
+  // pass 0 counts, pass 1 writes
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int r = threadIdx.x; r < nrows; r += 256) {
+      const int i = r / nj, j = r - i * nj;
+      int pos = pass ? rowcnt[r] : 0;
+      for (int k = 0; k < nk; ++k) {
+        const bool f00 = m[(long long)j * w + k] > 0, f01 = m[(long long)j * w + k + 1] > 0;
+        const bool f10 = m[(long long)(j + 1) * w + k] > 0, f11 = m[(long long)(j + 1) * w + k + 1] > 0;
+        if (f00 == f01 && f00 == f10 && f00 == f11) continue;      // (the slices are copies: no crossing edge in this cell)
+        const int at0 = (i == 0 ? 1 : 0) | (j == 0 ? 2 : 0) | (k == 0 ? 4 : 0);
+        for (int q = 0; q < 12; ++q) {
+          const int e = MC_ORDER[q];
+          const signed char* ca = MC_CORNER[MC_EDGE[e][0]];
+          const signed char* cb = MC_CORNER[MC_EDGE[e][1]];
+          const bool fa = ca[1] ? (ca[2] ? f11 : f10) : (ca[2] ? f01 : f00);
+          const bool fb = cb[1] ? (cb[2] ? f11 : f10) : (cb[2] ? f01 : f00);
+          if (fa == fb || (MC_NEED0[e] & ~at0)) continue;
+          if (pass && pos < max_verts) {
+            const signed char* c = fa ? cb : ca;                   // the background end
+            out[pos * 3 + 0] = i + c[0]; out[pos * 3 + 1] = j + c[1]; out[pos * 3 + 2] = k + c[2];
+          }
+          ++pos;
+        }
+      }
+      if (!pass) rowcnt[r] = pos;
+    }
+    __syncthreads();
+    if (!pass) {
+      if (threadIdx.x == 0) {
+        int run = 0;
+        for (int r = 0; r < nrows; ++r) { const int c = rowcnt[r]; rowcnt[r] = run; run += c; }
+        rowcnt[nrows] = run;
+      }
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x == 0) counts[b] = rowcnt[nrows];
+}
+
 // one workgroup per cloud.  dist lives in LDS (npts_max doubles).
 __global__ __launch_bounds__(256) void fps_kernel(const double* __restrict__ pts, const int* __restrict__ counts,
                                                   const int* __restrict__ first, int npts_max, int k,
@@ -103,6 +160,16 @@ extern "C" int pcuda_surface_vertices(const uint8_t* mask, int b, int h, int w, 
   hipLaunchKernelGGL(surface_vertices_kernel, dim3(b), dim3(256), (h + 1) * sizeof(int), (hipStream_t)s, mask, h, w,
                      verts, max_verts, counts);
   PCUDA_CHECK_LAUNCH("surface_vertices_kernel");
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_surface_vertices_mc(const uint8_t* mask, int b, int h, int w, int* verts, int max_verts,
+                                         int* counts, pcuda_stream_t s) {
+  if (!mask || !verts || !counts || b <= 0 || h <= 1 || w <= 1 || max_verts <= 0 || h > 8192)
+    PCUDA_FAIL(PCUDA_E_BADARG, "surface_vertices_mc: bad arguments");
+  hipLaunchKernelGGL(surface_vertices_mc_kernel, dim3(b), dim3(256), (2 * (h - 1) + 1) * sizeof(int), (hipStream_t)s, mask,
+                     h, w, verts, max_verts, counts);
+  PCUDA_CHECK_LAUNCH("surface_vertices_mc_kernel");
   return PCUDA_OK;
 }
 

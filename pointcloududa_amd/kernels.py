@@ -721,11 +721,18 @@ def bmm(a, b, ta=False, tb=False):
 # ------------------------------------------------------------------------------------------
 # sampler
 # ------------------------------------------------------------------------------------------
-def surface_vertices(mask_u8: torch.Tensor, max_verts: int):
+def surface_vertices(mask_u8: torch.Tensor, max_verts: int, order: str = "lex"):
+    """order "lex": this build's canonical list; "mc": marching-cubes traversal order with coincident duplicates"""
     _req(mask_u8, torch.uint8)
     b, h, w = mask_u8.shape
     verts = torch.zeros((b, max_verts, 3), dtype=torch.int32, device=mask_u8.device)
     counts = torch.empty(b, dtype=torch.int32, device=mask_u8.device)
+    if order == "mc":
+        check(L.lib().pcuda_surface_vertices_mc(mask_u8.data_ptr(), b, h, w, verts.data_ptr(), max_verts,
+                                                counts.data_ptr(), _stream()), "surface_vertices_mc")
+        return verts, counts
+    if order != "lex":
+        raise ValueError("order must be 'lex' or 'mc'")
     check(L.lib().pcuda_surface_vertices(mask_u8.data_ptr(), b, h, w, verts.data_ptr(), max_verts, counts.data_ptr(),
                                          None, 0, _stream()), "surface_vertices")
     return verts, counts

@@ -42,13 +42,15 @@ def graipher(pts, K_, dim=2, first=None):
 
 
 def masks_to_pointclouds(mask_u8: torch.Tensor, firsts: torch.Tensor, number_points: int = 300,
-                         max_verts: int = 0) -> torch.Tensor:
+                         max_verts: int = 0, order: str = "lex") -> torch.Tensor:
     """mask_u8: uint8 [B,H,W] on the device (>0 = foreground); firsts: int32 [B].
-    -> int32 [B,number_points,3] rows (z,y,x); all zeros where the mask has <= 50 foreground pixels."""
+    -> int32 [B,number_points,3] rows (z,y,x); all zeros where the mask has <= 50 foreground pixels.
+    ``order``: "lex" = the canonical vertex list, "mc" = marching-cubes traversal order with the coincident
+    duplicates of one vertex per crossing edge (both parity-unpinned against PyMCubes, oracle/sampler.py)."""
     b, h, w = mask_u8.shape
     if max_verts <= 0:
-        max_verts = 3 * 8 * (h + w)
-    verts, counts = K.surface_vertices(mask_u8.contiguous(), max_verts)
+        max_verts = 3 * 8 * (h + w) * (2 if order == "mc" else 1)
+    verts, counts = K.surface_vertices(mask_u8.contiguous(), max_verts, order)
     # npy2point.py:116: sample only when the binarised mask has more than 50 foreground pixels
     area = (mask_u8 > 0).flatten(1).sum(1)
     counts = torch.where(area > 50, counts, torch.zeros_like(counts)).to(torch.int32)
@@ -62,7 +64,8 @@ def masks_to_pointclouds(mask_u8: torch.Tensor, firsts: torch.Tensor, number_poi
     return torch.where((idx >= 0)[..., None], out, torch.zeros_like(out))
 
 
-def npy2point_datagenerator(mask=None, number_points=300, dim=3, crop_size=112, tocrop=False, fps=True, first=0):
+def npy2point_datagenerator(mask=None, number_points=300, dim=3, crop_size=112, tocrop=False, fps=True, first=0,
+                            order="lex"):
     """npy2point.py:101-125 for one [H,W,1] (or [H,W]) integer mask -> int array [number_points, 3]."""
     if tocrop or not fps:
         raise NotImplementedError("tocrop=True / fps=False are not used by the data generators")
@@ -71,5 +74,5 @@ def npy2point_datagenerator(mask=None, number_points=300, dim=3, crop_size=112, 
         m = m[..., 0]
     dev = _dev()
     mu8 = torch.from_numpy((m > 0).astype(np.uint8))[None].to(dev)
-    out = masks_to_pointclouds(mu8, torch.tensor([int(first)], dtype=torch.int32, device=dev), number_points)
+    out = masks_to_pointclouds(mu8, torch.tensor([int(first)], dtype=torch.int32, device=dev), number_points, order=order)
     return out[0].cpu().numpy().astype(np.int64)

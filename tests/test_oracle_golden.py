@@ -112,6 +112,45 @@ def test_oracle_sampler_edge_cases():
     assert len(sv) == 3 * 16 and (sv[:16, 0] == 0).all()
 
 
+def _mc_walk(fg):
+    """cell-by-cell restatement of the marching-cubes-order mode: the first cell that contains a crossing edge emits it"""
+    from oracle import sampler as OS
+    h, w = fg.shape
+    vol = np.broadcast_to(fg[None], (3, h, w))
+    out, seen = [], set()
+    for i in range(2):
+        for j in range(h - 1):
+            for k in range(w - 1):
+                for e in OS._MC_ORDER:
+                    a, b = OS._MC_CORNER[OS._MC_EDGE[e][0]], OS._MC_CORNER[OS._MC_EDGE[e][1]]
+                    pa, pb = (i + a[0], j + a[1], k + a[2]), (i + b[0], j + b[1], k + b[2])
+                    if vol[pa] == vol[pb] or frozenset((pa, pb)) in seen:
+                        continue
+                    seen.add(frozenset((pa, pb)))
+                    out.append(pb if vol[pa] else pa)
+    return np.array(out, dtype=np.int64).reshape(-1, 3)
+
+
+def test_oracle_sampler_marching_cubes_order_mode():
+    """the second vertex-list mode (parity unpinned): one vertex per crossing edge, in cell traversal order"""
+    from oracle import sampler as OS
+    rng = np.random.default_rng(0)
+    for t in range(4):
+        m = (rng.random((20, 23)) > 0.6).astype(np.uint8)
+        if t == 3:
+            m[:, 0] = 1; m[0, :] = 1; m[-1, :] = 0          # foreground on the volume faces
+        v, fg = OS.surface_vertices_mc(m), m > 0
+        assert np.array_equal(v, _mc_walk(fg)), t
+        assert len(v) == 3 * ((fg[1:] != fg[:-1]).sum() + (fg[:, 1:] != fg[:, :-1]).sum())
+        assert set(map(tuple, v)) == set(map(tuple, OS.surface_vertices(m)))      # same points, other order / multiplicity
+    assert OS.surface_vertices_mc(np.zeros((16, 16), np.uint8)).shape == (0, 3)
+    assert OS.surface_vertices_mc(np.ones((16, 16), np.uint8)).shape == (0, 3)
+    sq = np.pad(np.ones((12, 12), np.uint8), 6)[..., None]
+    v = OS.mask_to_pointcloud(sq, 300, first=5, order="mc")
+    assert v.shape == (300, 3) and set(np.unique(v[:, 0])) <= {0, 1, 2}
+    assert not np.array_equal(v, OS.mask_to_pointcloud(sq, 300, first=5))
+
+
 def test_oracle_metrics_hand_cases():
     from oracle import metrics as OM
     pred = np.zeros((1, 3, 2, 2), np.float32)

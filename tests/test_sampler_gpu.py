@@ -46,6 +46,33 @@ def test_surface_and_batched_sampler_vs_oracle(dev):
                           OS.mask_to_pointcloud(lab[1][..., None], 300, first=9))
 
 
+def test_marching_cubes_order_mode_vs_oracle(dev):
+    """second vertex-list mode (cell traversal order, one vertex per crossing edge incl. coincident duplicates)"""
+    from oracle import sampler as OS
+    from oracle.synth import synth_labels
+    from pointcloududa_amd import kernels as K
+    from pointcloududa_amd.utils import npy2point as S
+    rng = np.random.default_rng(5)
+    lab = synth_labels(4, 4, 256, rng)
+    lab[2, :, 0:3] = 2                           # foreground on the volume faces (edges owned by boundary cells)
+    lab[2, 0:2, :] = 1
+    lab[3] = (rng.random((256, 256)) > 0.7)      # salt and pepper: many coincident duplicates
+    m = torch.from_numpy((lab > 0).astype(np.uint8)).to(dev)
+    verts, counts = K.surface_vertices(m, 3 * 70000, order="mc")
+    for i in range(4):
+        ref = OS.surface_vertices_mc(lab[i])
+        assert int(counts[i]) == len(ref), i
+        assert np.array_equal(verts[i, :len(ref)].cpu().numpy(), ref), i
+    small, cnt = K.surface_vertices(m[:1], 100, order="mc")           # truncated output: count still the full one
+    assert int(cnt[0]) == len(OS.surface_vertices_mc(lab[0])) and np.array_equal(small[0].cpu().numpy(), OS.surface_vertices_mc(lab[0])[:100])
+    firsts = np.array([0, 17, 123456], dtype=np.int32)
+    out = S.masks_to_pointclouds(m[:3], torch.from_numpy(firsts).to(dev), order="mc").cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(out[i], OS.mask_to_pointcloud(lab[i][..., None], 300, first=int(firsts[i]), order="mc")), i
+    assert np.array_equal(S.npy2point_datagenerator(lab[1][..., None], first=9, order="mc"),
+                          OS.mask_to_pointcloud(lab[1][..., None], 300, first=9, order="mc"))
+
+
 def test_fps_edge_cases(dev):
     from oracle import sampler as OS
     from pointcloududa_amd import kernels as K
