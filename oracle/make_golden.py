@@ -332,8 +332,36 @@ def gold_pncls(tag, ft, ext, b, seed):
         if (k.endswith("running_mean") or k.endswith("running_var")) and ".in" not in k and not k.startswith("in"):
             close(p2[k], sd_after[k], 1e-5, tag + " " + k)
             out["bn/" + k] = sd_after[k].numpy()
+    # The reference's OWN output / gradient spread at the kernels' error scale (as for the segmenter above): relative
+    # noise of 2^-17 on every Conv1d / Linear output, 5 draws.  The max over 300 points followed by BatchNorm1d over a
+    # batch of 12-16 amplifies rounding; the tests' tolerances derive from these numbers.
+    rel = lambda a, b_: float((a - b_).abs().max() / max(1e-30, float(b_.abs().max())))
+    sp = {"y": 0.0, "trans": 0.0, "trans_feat": 0.0, "loss": 0.0, "dx": 0.0}
+    gsp = {k: 0.0 for k, p in ref.named_parameters() if p.grad is not None}
+    for trial in range(5):
+        gen = torch.Generator().manual_seed(seed + 7000 + trial)
+        refn = load_into(PointNetCls(feature_transform=ft, ext=ext, drop=0.0), params).train()
+        hooks = [m.register_forward_hook(lambda mod, inp, o: o * (1.0 + 2.0 ** -17 * torch.randn(o.shape, generator=gen)))
+                 for m in refn.modules() if isinstance(m, (torch.nn.Conv1d, torch.nn.Linear))]
+        xn = x.clone().requires_grad_(True)
+        yn, trn, trfn = refn(xn)
+        ln = F.binary_cross_entropy_with_logits(yn, torch.zeros_like(yn))
+        ln.backward()
+        for h_ in hooks:
+            h_.remove()
+        sp["y"] = max(sp["y"], rel(yn.detach(), y.detach())); sp["trans"] = max(sp["trans"], rel(trn.detach(), tr.detach()))
+        if ft:
+            sp["trans_feat"] = max(sp["trans_feat"], rel(trfn.detach(), trf.detach()))
+        sp["loss"] = max(sp["loss"], abs(ln.item() - loss.item())); sp["dx"] = max(sp["dx"], rel(xn.grad, xr.grad))
+        for k, pp in refn.named_parameters():
+            if k in gsp and pp.grad is not None:
+                gsp[k] = max(gsp[k], rel(pp.grad, dict(ref.named_parameters())[k].grad))
+    for k, v in sp.items():
+        out["spread/" + k] = np.float64(v)
+    for k, v in gsp.items():
+        out["gspread/" + k] = np.float64(v)
     np.savez_compressed(os.path.join(GOLD, tag + ".npz"), **out)
-    print(tag, "ok")
+    print(tag, "ok  reference spread: " + "  ".join("%s %.2e" % kv for kv in sp.items()), " worst gradient %.2e" % max(gsp.values()))
 
 
 # --------------------------------------------------------------------------- #
@@ -822,6 +850,10 @@ def main():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "pncls":    # only the PointNetCls fixtures
+        gold_pncls("pncls", False, False, b=16, seed=300)
+        gold_pncls("pncls_ft_ext", True, True, b=12, seed=310)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "seg":      # only the segmenter fixtures
         _full = ON.SegCfg(filters=32, in_channels=1, n_class=4, pointnet=True, fc_inch=121)
         _small = ON.SegCfg(filters=4, in_channels=1, n_class=4, pointnet=True, fc_inch=9)

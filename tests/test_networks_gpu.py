@@ -162,13 +162,18 @@ def test_pointnet_cls_vs_reference_golden(dev, tag, ft, ext):
     y, trans, trans_feat = model(x)
     loss = L.bce_logits_const(y, 0.0)
     loss.backward()
-    # BatchNorm1d over a batch of 12-16 right after a max over 300 points (argmax routing) amplifies
-    # rounding: 5e-3 on outputs; gradients only to ~1e-1 (same discontinuity argument as above)
-    assert rel_err(y, g["y"]) < 5e-3 and rel_err(trans, g["trans"]) < 5e-3
-    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-3
-    assert rel_err(x.grad, g["dx"]) < 2e-1
+    # BatchNorm1d over a batch of 12-16 right after a max over 300 points (argmax routing) amplifies rounding.  The
+    # golden file carries the reference's OWN spread under 2^-17 relative noise on every Conv1d / Linear output
+    # (oracle/make_golden.py): outputs are held to max(1e-3, that spread) -- 1e-3 wherever the reference itself is
+    # reproducible to 1e-3 (trans; y of the plain network is at 1.6e-3, of the feature-transform one at 5.6e-3) --, the
+    # loss to max(1e-4, spread), the input gradient and the per-parameter gradients to max(2e-2, 3 x spread).
+    sp = lambda k: float(g["spread/" + k])
+    assert rel_err(y, g["y"]) < max(1e-3, sp("y")), (rel_err(y, g["y"]), sp("y"))
+    assert rel_err(trans, g["trans"]) < max(1e-3, sp("trans"))
+    assert abs(float(loss.detach()) - float(g["loss"])) < max(1e-4, sp("loss"))
+    assert rel_err(x.grad, g["dx"]) < max(2e-2, 3 * sp("dx")), (rel_err(x.grad, g["dx"]), sp("dx"))
     if ft:
-        assert rel_err(_strided(trans_feat), g["trans_feat_s"]) < 5e-3
+        assert rel_err(_strided(trans_feat), g["trans_feat_s"]) < max(1e-3, sp("trans_feat"))
     else:
         assert trans_feat is None
     _check_grads(model, g, 1e-1, 3.5e-1)
