@@ -145,6 +145,26 @@ int pcuda_conv2d_wgrad(const pcuda_conv_geom* g, int prec, const pcuda_src* x, c
                        long long dy_sn, long long dy_sc, float* dw, float* db, int accumulate,
                        void* workspace, size_t workspace_bytes, pcuda_stream_t s);
 
+/* The same weight gradient with its split-K reduce DEFERRED: the partial sums stay in `workspace` (which must live
+ * until the reduce has run) and *job describes the reduce; pcuda_wgrad_reduce_batch runs the reduces of many layers in
+ * one launch (host array of jobs; same per-output arithmetic and order as pcuda_conv2d_wgrad, bit-identical results).
+ * A backward pass issues one weight gradient per layer; no two jobs of one batch may name the same dw.
+ * job->ksplit == 0 on return: the layer's kernel wrote dw itself, nothing to reduce. */
+#define PCUDA_REDUCE_MAX_JOBS 56
+typedef struct {
+  const float* partial;      /* [ksplit][numel] */
+  long long numel;
+  float* dw;
+  const float* db_partial;   /* [ksplit][nb] or NULL */
+  long long nb;
+  float* db;
+  int ksplit, nkg, accumulate, ntaps;
+} pcuda_reduce_job;
+int pcuda_conv2d_wgrad_partial(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const float* dy,
+                               long long dy_sn, long long dy_sc, float* dw, float* db, int accumulate,
+                               void* workspace, size_t workspace_bytes, pcuda_reduce_job* job, pcuda_stream_t s);
+int pcuda_wgrad_reduce_batch(const pcuda_reduce_job* host_jobs, int njobs, pcuda_stream_t s);
+
 /* ------------------------------------------------------------------------------------
  * BatchNorm (training mode) around LeakyReLU: conv -> LeakyReLU -> BatchNorm2d
  * (unet.py:23-30,116-125); also BatchNorm1d of PointNetCls.py (hw = points or 1).

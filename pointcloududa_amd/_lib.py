@@ -24,6 +24,12 @@ class ConvGeom(C.Structure):
                 ("out_w", i32), ("k", i32), ("stride", i32), ("pad", i32), ("dil", i32), ("in_up", i32)]
 
 
+class ReduceJob(C.Structure):      # pcuda_reduce_job (include/pcuda_hip.h)
+    _fields_ = [("partial", C.c_void_p), ("numel", C.c_longlong), ("dw", C.c_void_p), ("db_partial", C.c_void_p),
+                ("nb", C.c_longlong), ("db", C.c_void_p), ("ksplit", C.c_int), ("nkg", C.c_int), ("accumulate", C.c_int),
+                ("ntaps", C.c_int)]
+
+
 class Src(C.Structure):
     _fields_ = [("p1", vp), ("sn1", i64), ("sc1", i64), ("scale1", vp), ("shift1", vp),
                 ("p2", vp), ("sn2", i64), ("sc2", i64), ("scale2", vp), ("shift2", vp), ("c1", i32)]
@@ -58,6 +64,9 @@ _PROTOS = {
                                        vp, vp, vp]),
     "pcuda_conv2d_wgrad_workspace_size": (sz, [C.POINTER(ConvGeom)]),
     "pcuda_conv2d_wgrad": (i32, [C.POINTER(ConvGeom), i32, C.POINTER(Src), vp, i64, i64, vp, vp, i32, vp, sz, vp]),
+    "pcuda_conv2d_wgrad_partial": (i32, [C.POINTER(ConvGeom), i32, C.POINTER(Src), vp, i64, i64, vp, vp, i32, vp, sz,
+                                         C.POINTER(ReduceJob), vp]),
+    "pcuda_wgrad_reduce_batch": (i32, [C.POINTER(ReduceJob), i32, vp]),
     "pcuda_bn_finalize": (i32, [vp, i32, i32, i64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp]),
     "pcuda_bn_stats": (i32, [vp, i64, i64, i32, i32, i64, vp, C.POINTER(i32), vp]),
     "pcuda_bn_apply": (i32, [vp, i64, i64, vp, vp, i32, vp, i64, i64, i32, i32, i64, vp]),

@@ -61,6 +61,86 @@ int launch_wgrad_reduce(const float* partial, long long numel, int ksplit, float
   return PCUDA_OK;
 }
 
+// ---- the split-K reduces of MANY weight gradients in one launch (a backward pass issues one per layer: 80 launches of
+// ~15 us per step, most of it launch and drain).  Jobs travel as kernel arguments; a workgroup finds its job in the
+// prefix of 64-output blocks.  Same arithmetic and order per output as wgrad_reduce_kernel with 16 k-groups ... except
+// that the number of k-groups is the job's own (nkg), so that the sums are bit-identical to the one-by-one form.
+struct ReduceJobs {
+  int n;
+  int first_block[PCUDA_REDUCE_MAX_JOBS + 1];
+  pcuda_reduce_job j[PCUDA_REDUCE_MAX_JOBS];
+};
+
+__global__ __launch_bounds__(1024) void wgrad_reduce_batch_kernel(const ReduceJobs jobs) {
+  __shared__ float sh[16][64];
+  int lo = 0, hi = jobs.n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs.first_block[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const pcuda_reduce_job& jb = jobs.j[lo];
+  const float* partial = jb.partial;
+  long long numel = jb.numel;
+  float* dw = jb.dw;
+  int ntaps = jb.ntaps;
+  const int ksplit = jb.ksplit, nkg = jb.nkg;
+  const int lane = threadIdx.x & 63, kg = threadIdx.x >> 6;
+  const long long nblk_w = (numel + 63) / 64;
+  long long blk = (int)blockIdx.x - jobs.first_block[lo];
+  if (blk >= nblk_w) { blk -= nblk_w; partial = jb.db_partial; numel = jb.nb; dw = jb.db; ntaps = 1; }
+  const long long i = blk * 64 + lane;
+  float s = 0.f;
+  if (i < numel && kg < nkg) {
+    int k = kg;
+    for (; k + 7 * nkg < ksplit; k += 8 * nkg) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partial[(long long)(k + u * nkg) * numel + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < ksplit; k += nkg) s += partial[(long long)k * numel + i];
+  }
+  sh[kg][lane] = s;
+  __syncthreads();
+  if (kg == 0 && i < numel) {
+    float t = 0.f;
+    for (int q = 0; q < nkg; ++q) t += sh[q][lane];
+    long long o = i;
+    if (ntaps > 1) {
+      const long long cc = numel / ntaps;
+      const long long tt = i / cc, r = i - tt * cc;
+      o = r * ntaps + tt;
+    }
+    dw[o] = jb.accumulate ? dw[o] + t : t;
+  }
+}
+
+extern "C" int pcuda_wgrad_reduce_batch(const pcuda_reduce_job* host_jobs, int njobs, pcuda_stream_t s) {
+  if (!host_jobs || njobs < 0) PCUDA_FAIL(PCUDA_E_BADARG, "wgrad_reduce_batch: bad arguments");
+  int done = 0;
+  while (done < njobs) {
+    ReduceJobs jobs;
+    jobs.n = 0;
+    int blocks = 0;
+    for (; done < njobs && jobs.n < PCUDA_REDUCE_MAX_JOBS; ++done) {
+      const pcuda_reduce_job& jb = host_jobs[done];
+      if (jb.ksplit <= 0) continue;      // (the layer's own kernel already wrote dw)
+      if (!jb.partial || !jb.dw || jb.numel <= 0 || jb.nkg < 1 || jb.nkg > 16 || (jb.db && !jb.db_partial))
+        PCUDA_FAIL(PCUDA_E_BADARG, "wgrad_reduce_batch: bad job %d", done);
+      jobs.first_block[jobs.n] = blocks;
+      jobs.j[jobs.n++] = jb;
+      blocks += (int)cdiv(jb.numel, 64) + (jb.db ? (int)cdiv(jb.nb, 64) : 0);
+    }
+    if (jobs.n == 0) break;
+    jobs.first_block[jobs.n] = blocks;
+    ProfScope prof(PCUDA_FAM_POINTWISE, 0.0, (hipStream_t)s, "wgrad reduce batch");
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)s, jobs);
+    PCUDA_CHECK_LAUNCH("wgrad_reduce_batch_kernel");
+  }
+  return PCUDA_OK;
+}
+
 namespace {
 
 struct WgradPlan {
@@ -137,9 +217,27 @@ int wgrad_dispatch_x3(const WgradParams& p, int co_blks, bool clamp, int taps_ma
 int wgrad_dispatch_bf16(const WgradParams& p, int co_blks, bool clamp, int taps_max, int pf, int x_cap, size_t lds,
                         float* dbp, dim3 grid, hipStream_t s);
 
+static int wgrad_impl(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const float* dy, long long dy_sn, long long dy_sc,
+                      float* dw, float* db, int accumulate, void* workspace, size_t workspace_bytes, pcuda_stream_t s_,
+                      pcuda_reduce_job* defer);
+
 extern "C" int pcuda_conv2d_wgrad(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const float* dy,
                                   long long dy_sn, long long dy_sc, float* dw, float* db, int accumulate,
                                   void* workspace, size_t workspace_bytes, pcuda_stream_t s_) {
+  return wgrad_impl(g, prec, x, dy, dy_sn, dy_sc, dw, db, accumulate, workspace, workspace_bytes, s_, nullptr);
+}
+
+extern "C" int pcuda_conv2d_wgrad_partial(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const float* dy,
+                                          long long dy_sn, long long dy_sc, float* dw, float* db, int accumulate,
+                                          void* workspace, size_t workspace_bytes, pcuda_reduce_job* job, pcuda_stream_t s_) {
+  if (!job) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_wgrad_partial: job is NULL");
+  memset(job, 0, sizeof(*job));
+  return wgrad_impl(g, prec, x, dy, dy_sn, dy_sc, dw, db, accumulate, workspace, workspace_bytes, s_, job);
+}
+
+static int wgrad_impl(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const float* dy, long long dy_sn, long long dy_sc,
+                      float* dw, float* db, int accumulate, void* workspace, size_t workspace_bytes, pcuda_stream_t s_,
+                      pcuda_reduce_job* defer) {
   hipStream_t s = (hipStream_t)s_;
   if (!geom_ok(g)) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_wgrad: inconsistent geometry");
   if (!src_ok(x, g->cin) || !dy || !dw) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_wgrad: bad tensors");
@@ -222,6 +320,12 @@ extern "C" int pcuda_conv2d_wgrad(const pcuda_conv_geom* g, int prec, const pcud
   {
     int nkg = 1;
     while (nkg < 16 && nkg * 2 <= w.ksplit) nkg <<= 1;
+    if (defer) {      // the caller batches the reduce (pcuda_wgrad_reduce_batch); the workspace must live until then
+      defer->partial = (const float*)workspace; defer->numel = welems; defer->ksplit = w.ksplit; defer->nkg = nkg;
+      defer->dw = dw; defer->accumulate = accumulate; defer->ntaps = t.n;
+      defer->db_partial = (const float*)dbp; defer->nb = db ? g->cout : 0; defer->db = db;
+      return PCUDA_OK;
+    }
     const unsigned nblk = (unsigned)cdiv(welems, 64) + (db ? (unsigned)cdiv(g->cout, 64) : 0u);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk), dim3(64 * nkg), 0, s, (const float*)workspace, welems, w.ksplit,
                        dw, accumulate, t.n, (const float*)dbp, (long long)(db ? g->cout : 0), db);

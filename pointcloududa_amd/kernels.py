@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 import weakref
 from typing import Optional, Tuple
 
@@ -222,9 +223,60 @@ class ConvOp:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
         _, _, _, sn, sc = _planes(dy)
         src = make_src(xa, x2)
+        pend = getattr(_deferred, "jobs", None)
+        if pend is not None:
+            # inside ``deferred_wgrad_reduces()``: only the partial sums now; the split-K reduce of every layer of the
+            # pass goes out in one launch when the block ends (the workspace lives in the pending list until then)
+            job = L.ReduceJob()
+            check(lib.pcuda_conv2d_wgrad_partial(C.byref(g), _precision, C.byref(src), dy.data_ptr(), sn, sc, dw.data_ptr(),
+                                                 _ptr(db), 1 if accumulate else 0, ws.data_ptr(), ws_bytes, C.byref(job),
+                                                 _stream()), "conv2d_wgrad_partial")
+            if job.ksplit > 0:
+                if any(j.dw == job.dw for j, _ in pend):
+                    flush_wgrad_reduces()        # two gradients into one buffer: keep their order
+                pend.append((job, ws))
+            return
         check(lib.pcuda_conv2d_wgrad(C.byref(g), _precision, C.byref(src), dy.data_ptr(), sn, sc, dw.data_ptr(),
                                      _ptr(db), 1 if accumulate else 0, ws.data_ptr(), ws_bytes, _stream()),
               "conv2d_wgrad")
+
+
+# PCUDA_BATCH_REDUCE=1: the split-K reduces of a backward pass in one launch per 56 layers instead of one per layer.
+# OFF by default -- measured SLOWER (51.7 vs 49.5 ms per step, same box): a layer's partial sums (~35 MB) are still in
+# the 256 MB infinity cache when its own reduce follows at once, and the workspace block is reused by the next layer; all
+# of a pass's partials together (~1.4 GB) go out to HBM and come back.  The launches were not the cost.
+_batch_reduce = os.environ.get("PCUDA_BATCH_REDUCE", "0") == "1"
+_deferred = threading.local()
+
+
+def flush_wgrad_reduces():
+    """Run the pending split-K reduces of this thread's ``deferred_wgrad_reduces`` block (one launch per 56 layers).
+    Call before anything reads the weight gradients inside the block (e.g. the all-reduce hook of the backward pass)."""
+    pend = getattr(_deferred, "jobs", None)
+    if not pend:
+        return
+    arr = (L.ReduceJob * len(pend))(*[j for j, _ in pend])
+    check(L.lib().pcuda_wgrad_reduce_batch(arr, len(pend), _stream()), "wgrad_reduce_batch")
+    del pend[:]          # (stream order keeps the workspaces valid: the allocator reuses them behind the reduce)
+
+
+class deferred_wgrad_reduces:
+    """``with deferred_wgrad_reduces():`` around one backward pass of a network (one stream, each weight once)."""
+
+    def __enter__(self):
+        self.outer = getattr(_deferred, "jobs", None)
+        if _batch_reduce and self.outer is None:
+            _deferred.jobs = []
+        return self
+
+    def __exit__(self, *exc):
+        if _batch_reduce and self.outer is None:
+            try:
+                if exc[0] is None:
+                    flush_wgrad_reduces()
+            finally:
+                _deferred.jobs = None
+        return False
 
 
 _batch_repack = os.environ.get("PCUDA_PACK_TABLE", "1") != "0"

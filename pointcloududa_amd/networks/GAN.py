@@ -62,20 +62,21 @@ class _ConvChainFn(torch.autograd.Function):
         nl = len(module._chain)
         dz = d_out.contiguous()
         dx = None
-        for li in reversed(range(nl)):
-            name, op = module._chain[li]
-            h, w = sizes[li]
-            wt = weights[li].view(op.cout, op.cin, op.k, op.k)
-            if ctx.needs_input_grad[2 + li]:
-                # (the first layer's weight gradient stays on the k x k kernel: the one-tap form of the weight-gradient
-                # kernel stages a tile per tap and measured 0.40 ms against 0.25 ms for this layer)
-                db = ensure_grad(biases[li]) if (biases[li] is not None and ctx.needs_input_grad[2 + nl + li]) else None
-                op.wgrad(acts[li], dz, ensure_grad(weights[li]).view(op.cout, op.cin, op.k, op.k), db, h, w)
-            if li > 0:
-                d_a = op.dgrad(dz, wt, h, w)
-                dz = K.lrelu_bwd(d_a, acts[li], module._slope)
-            elif ctx.needs_input_grad[1]:
-                dx = op.dgrad(dz, wt, h, w)
+        with K.deferred_wgrad_reduces():      # the five layers' split-K reduces leave in one launch
+            for li in reversed(range(nl)):
+                name, op = module._chain[li]
+                h, w = sizes[li]
+                wt = weights[li].view(op.cout, op.cin, op.k, op.k)
+                if ctx.needs_input_grad[2 + li]:
+                    # (the first layer's weight gradient stays on the k x k kernel: the one-tap form of the weight-gradient
+                    # kernel stages a tile per tap and measured 0.40 ms against 0.25 ms for this layer)
+                    db = ensure_grad(biases[li]) if (biases[li] is not None and ctx.needs_input_grad[2 + nl + li]) else None
+                    op.wgrad(acts[li], dz, ensure_grad(weights[li]).view(op.cout, op.cin, op.k, op.k), db, h, w)
+                if li > 0:
+                    d_a = op.dgrad(dz, wt, h, w)
+                    dz = K.lrelu_bwd(d_a, acts[li], module._slope)
+                elif ctx.needs_input_grad[1]:
+                    dx = op.dgrad(dz, wt, h, w)
         ctx.acts = None
         return (None, dx) + (None,) * (nin - 2)
 

@@ -243,6 +243,7 @@ class _SegEngine:
         # all-reduce here, under the encoder's backward pass (train_step.py)
         cb = self.after_deep_grads
         if cb is not None:
+            K.flush_wgrad_reduces()      # (the hook reads the gradients launched so far)
             cb()
         dA, dB = g_next, None
         for i in reversed(range(nb)):
@@ -285,7 +286,8 @@ class _SegFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_logits, d_verts=None):
-        dx = ctx.module._engine.backward(ctx.P, ctx.S, d_logits, d_verts, ctx.needs_input_grad[1])
+        with K.deferred_wgrad_reduces():      # the layers' split-K reduces leave in two launches (hook, end) instead of 43
+            dx = ctx.module._engine.backward(ctx.P, ctx.S, d_logits, d_verts, ctx.needs_input_grad[1])
         ctx.S = None
         return (None, dx) + (None,) * (len(ctx.needs_input_grad) - 2)
 

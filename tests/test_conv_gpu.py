@@ -168,3 +168,35 @@ def test_conv_full_batch_properties(dev, cin, cout, hw, k, s, p):
     y_lin, _, _ = op.forward(x, w, None, 1.0, hw, hw)
     lhs, rhs = float((gz.double() * y_lin.double()).sum()), float((dx.double() * x.double()).sum())
     assert abs(lhs - rhs) <= 2e-5 * max(abs(lhs), abs(rhs), 1.0)
+
+
+def test_deferred_split_k_reduces_are_bit_identical(dev, monkeypatch):
+    """pcuda_conv2d_wgrad_partial + pcuda_wgrad_reduce_batch (several layers' reduces in one launch) against the
+    one-launch-per-layer form: same arithmetic, same order -> identical bits, with and without accumulation."""
+    from pointcloududa_amd import kernels as K
+    monkeypatch.setattr(K, "_batch_reduce", True)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    rn = lambda *s: torch.randn(*s, generator=g).to(dev)
+    layers = [(K.ConvOp(8, 16, 3, pad=1), 2, 64), (K.ConvOp(16, 8, 3, pad=1), 2, 64), (K.ConvOp(4, 64, 4, stride=2, pad=2), 2, 32),
+              (K.ConvOp(64, 40, 1), 3, 24), (K.ConvOp(1, 4, 3, pad=1), 2, 64)]
+    cases = []
+    for op, n, hw in layers:
+        oh, ow = op.out_hw(hw, hw)
+        cases.append((op, rn(n, op.cin, hw, hw), rn(n, op.cout, oh, ow), hw))
+    ref = []
+    for op, x, dy, hw in cases:
+        dw, db = torch.ones(op.cout, op.cin, op.k, op.k, device=dev), torch.ones(op.cout, device=dev)
+        op.wgrad(x, dy, dw, db, hw, hw, accumulate=True)
+        ref.append((dw, db))
+    got = []
+    with K.deferred_wgrad_reduces():
+        for op, x, dy, hw in cases:
+            dw, db = torch.ones(op.cout, op.cin, op.k, op.k, device=dev), torch.ones(op.cout, device=dev)
+            op.wgrad(x, dy, dw, db, hw, hw, accumulate=True)
+            got.append((dw, db))
+        op, x, dy, hw = cases[0]
+        op.wgrad(x, dy, got[0][0], got[0][1], hw, hw, accumulate=True)     # same buffers again: flushes the first in between
+    op, x, dy, hw = cases[0]
+    op.wgrad(x, dy, ref[0][0], ref[0][1], hw, hw, accumulate=True)
+    for (a, b), (c, d) in zip(ref, got):
+        assert torch.equal(a, c) and torch.equal(b, d)
