@@ -332,8 +332,12 @@ def main():
                    "parallelism": "dp%d" % world, "ranks_in_group": ranks_in_group,
                    "collective": "RCCL all-reduce of the flat gradient buffers (G: 2 buckets, D: 1 each)" if world > 1 else "none",
                    "algorithmic_gflop_per_pair": wl["gflop_per_pair"],
-                   "box_to_box": "600-643 img/s measured for this command across MI355X boxes in round 2 (boxes of the pool differ by up to 10 % on one binary)",
+                   "box_to_box": "600-663 img/s measured for this command across MI355X boxes in round 2 (boxes of the pool differ by up to 10 % on one binary)",
                    "streams": "discriminators concurrent" if tr.d_streams else "single",
+                   # d1 / d2 see the target batch twice per step with the same weights and the same input values
+                   # (adversarial pass, then their own update): the second forward is replayed from the first's
+                   # activations.  PCUDA_DREUSE=0 runs it again (same bits, ~1.5 ms per step more).
+                   "d_target_forward": "replayed from the adversarial pass of the same step" if tr.d_reuse else "run twice",
                    "launch": "hipGraph replay" if (use_graph and getattr(tr, "_graph", None) is not None) else "eager",
                    "losses": {k: round(host[k], 5) for k in ("seg_loss", "adv_loss") if k in host}},
     }

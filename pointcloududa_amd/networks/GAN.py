@@ -50,35 +50,61 @@ class _ConvChainFn(torch.autograd.Function):
         ctx.module, ctx.acts, ctx.sizes, ctx.weights, ctx.biases = module, acts, sizes, weights, biases
         if getattr(module, "_keep_acts", False):      # tests (shared-routing backward checks)
             module._last_acts = list(acts)
+        if getattr(module, "_cache_next", False):     # forward_cached(): this pass can be replayed (replay())
+            module._cache_next = False
+            module._cache = (list(acts), list(sizes), cur)
         ctx.set_materialize_grads(False)
         return cur
 
     @staticmethod
     def backward(ctx, d_out):
-        nin = len(ctx.needs_input_grad)
-        if d_out is None:
-            return (None,) * nin
-        module, acts, sizes, weights, biases = ctx.module, ctx.acts, ctx.sizes, ctx.weights, ctx.biases
+        return _chain_backward(ctx, d_out)
+
+
+class _ConvChainReplayFn(torch.autograd.Function):
+    """The output of an EARLIER forward pass of the chain (``forward_cached``), with a backward pass of its own through
+    the activations that pass kept: weights unchanged in between, same input -> the forward would recompute the same
+    bits.  The train step's discriminator update sees the target batch this way: the frozen adversarial pass of phase 2
+    already ran the network on it (train_mscmrseg.py:222-241 and :283-322 call D on the same tensor values)."""
+
+    @staticmethod
+    def forward(ctx, module, cache, *wb):
         nl = len(module._chain)
-        dz = d_out.contiguous()
-        dx = None
-        with K.deferred_wgrad_reduces():      # the five layers' split-K reduces leave in one launch
-            for li in reversed(range(nl)):
-                name, op = module._chain[li]
-                h, w = sizes[li]
-                wt = weights[li].view(op.cout, op.cin, op.k, op.k)
-                if ctx.needs_input_grad[2 + li]:
-                    # (the first layer's weight gradient stays on the k x k kernel: the one-tap form of the weight-gradient
-                    # kernel stages a tile per tap and measured 0.40 ms against 0.25 ms for this layer)
-                    db = ensure_grad(biases[li]) if (biases[li] is not None and ctx.needs_input_grad[2 + nl + li]) else None
-                    op.wgrad(acts[li], dz, ensure_grad(weights[li]).view(op.cout, op.cin, op.k, op.k), db, h, w)
-                if li > 0:
-                    d_a = op.dgrad(dz, wt, h, w)
-                    dz = K.lrelu_bwd(d_a, acts[li], module._slope)
-                elif ctx.needs_input_grad[1]:
-                    dx = op.dgrad(dz, wt, h, w)
-        ctx.acts = None
-        return (None, dx) + (None,) * (nin - 2)
+        acts, sizes, out = cache
+        ctx.module, ctx.acts, ctx.sizes, ctx.weights, ctx.biases = module, acts, sizes, wb[:nl], wb[nl:]
+        ctx.set_materialize_grads(False)
+        return out.detach()
+
+    @staticmethod
+    def backward(ctx, d_out):
+        return _chain_backward(ctx, d_out)
+
+
+def _chain_backward(ctx, d_out):
+    nin = len(ctx.needs_input_grad)
+    if d_out is None:
+        return (None,) * nin
+    module, acts, sizes, weights, biases = ctx.module, ctx.acts, ctx.sizes, ctx.weights, ctx.biases
+    nl = len(module._chain)
+    dz = d_out.contiguous()
+    dx = None
+    with K.deferred_wgrad_reduces():      # (PCUDA_BATCH_REDUCE=1: the five layers' split-K reduces in one launch)
+        for li in reversed(range(nl)):
+            name, op = module._chain[li]
+            h, w = sizes[li]
+            wt = weights[li].view(op.cout, op.cin, op.k, op.k)
+            if ctx.needs_input_grad[2 + li]:
+                # (the first layer's weight gradient stays on the k x k kernel: the one-tap form of the weight-gradient
+                # kernel stages a tile per tap and measured 0.40 ms against 0.25 ms for this layer)
+                db = ensure_grad(biases[li]) if (biases[li] is not None and ctx.needs_input_grad[2 + nl + li]) else None
+                op.wgrad(acts[li], dz, ensure_grad(weights[li]).view(op.cout, op.cin, op.k, op.k), db, h, w)
+            if li > 0:
+                d_a = op.dgrad(dz, wt, h, w)
+                dz = K.lrelu_bwd(d_a, acts[li], module._slope)
+            elif ctx.needs_input_grad[1]:
+                dx = op.dgrad(dz, wt, h, w)
+    ctx.acts = None
+    return (None, dx) + (None,) * (nin - 2)
 
 
 class _ConvChain(nn.Module):
@@ -117,6 +143,29 @@ class _ConvChain(nn.Module):
         ws = [getattr(self, n).weight for n, _ in self._chain]
         bs = [getattr(self, n).bias for n, _ in self._chain]
         return _ConvChainFn.apply(self, x, *(ws + bs))
+
+    def forward_cached(self, x):
+        """``forward`` that keeps its activations for ONE later ``replay()`` (dropped by ``drop_cache()``)"""
+        self._cache_next = True
+        return self(x)
+
+    def replay(self):
+        """The cached pass's output as a new autograd node whose backward pass produces THIS call's parameter
+        gradients (the parameters must not have changed since ``forward_cached``)."""
+        cache = getattr(self, "_cache", None)
+        if cache is None:
+            raise RuntimeError("replay() without a cached forward pass")
+        ws = [getattr(self, n).weight for n, _ in self._chain]
+        bs = [getattr(self, n).bias for n, _ in self._chain]
+        return _ConvChainReplayFn.apply(self, cache, *(ws + bs))
+
+    def drop_cache(self):
+        self._cache = None
+        self._cache_next = False
+
+    @property
+    def can_replay(self):
+        return type(self).forward is _ConvChain.forward
 
 
 class UncertaintyDiscriminator(_ConvChain):

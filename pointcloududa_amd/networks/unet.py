@@ -286,7 +286,7 @@ class _SegFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_logits, d_verts=None):
-        with K.deferred_wgrad_reduces():      # the layers' split-K reduces leave in two launches (hook, end) instead of 43
+        with K.deferred_wgrad_reduces():      # (PCUDA_BATCH_REDUCE=1: the layers' split-K reduces in two launches instead of 43)
             dx = ctx.module._engine.backward(ctx.P, ctx.S, d_logits, d_verts, ctx.needs_input_grad[1])
         ctx.S = None
         return (None, dx) + (None,) * (len(ctx.needs_input_grad) - 2)

@@ -72,6 +72,9 @@ class AdversarialTrainer:
         self.early_fwd2 = os.environ.get("PCUDA_EARLY2", "1") != "0"    # target forward ahead of the source backward
         self.d_batch = os.environ.get("PCUDA_DBATCH", "1") != "0"       # d1 / d2: source + target as one batch
         self.bucketed = os.environ.get("PCUDA_BUCKET", "1") != "0"      # data parallel: first all-reduce bucket from inside the backward pass
+        # d1 / d2 update on the target batch replays the frozen adversarial pass of phase 2 (same weights, same input
+        # values -> the same activations) instead of running the network forward on it again
+        self.d_reuse = os.environ.get("PCUDA_DREUSE", "1") != "0"
 
     def _side_streams(self, names):
         """One side stream PER DISCRIMINATOR, keyed by its name: a network's frozen pass (phase 2), its input-gradient
@@ -97,6 +100,9 @@ class AdversarialTrainer:
 
     def _dis(self):
         return [m for m in (self.dis1, self.dis2, self.dis4) if m is not None]
+
+    def _replays(self, m):
+        return self.d_reuse and bool(getattr(m, "can_replay", False))
 
     def _d_opts(self):
         return [o for o in (self.opt_d1, self.opt_d2, self.opt_d4) if o is not None]
@@ -188,13 +194,14 @@ class AdversarialTrainer:
         # the frozen discriminators' forward passes (and, through autograd's per-node streams, their input-gradient
         # passes) run next to each other like phases 3-4 below
         heads = []
+        run_d = lambda m, x: m.forward_cached(x) if self._replays(m) else m(x)
         if c.d2:
-            heads.append(("adv2", lambda: self.dis2(ent_t), c.dr * (1.0 if ms else c.w2)))
+            heads.append(("adv2", lambda: run_d(self.dis2, ent_t), c.dr * (1.0 if ms else c.w2)))
         if c.d4:
             out["ver_t_loss"] = L.batch_NN_loss(vert_t.detach(), vert_b)
             heads.append(("adv4", lambda: self.dis4(vert_t.transpose(2, 1), drop_mask)[0], c.dr * (1.0 if ms else c.w4)))
         if c.d1:
-            heads.append(("adv1", lambda: self.dis1(tap_t if ms else pred_t), c.dr * (1.0 if ms else c.w1)))
+            heads.append(("adv1", lambda: run_d(self.dis1, tap_t if ms else pred_t), c.dr * (1.0 if ms else c.w1)))
         cur = torch.cuda.current_stream()
         side = (self._side_streams(["d" + nm[-1] for nm, _, _ in heads]) if (self.d_streams and len(heads) > 1)
                 else [None] * len(heads))
@@ -265,7 +272,20 @@ class AdversarialTrainer:
                     else:
                         st.wait_stream(main)
                 with torch.cuda.stream(st if st is not None else main):
-                    if nm != "d4" and self.d_batch:
+                    dnet = getattr(self, "dis" + nm[1])
+                    if nm != "d4" and self._replays(dnet) and getattr(dnet, "_cache", None) is not None:
+                        # source batch: a forward pass; target batch: the activations of phase 2's frozen pass (the
+                        # weights have not moved and the input values are the same).  Both backward passes add into
+                        # the network's gradient buffer, as the reference's two backward calls do (:262-263,:296-297).
+                        ls = []
+                        for tag, label in (("src", 1.0), ("tgt", 0.0)):
+                            d = fwd(ent_s, in1_s, None) if tag == "src" else dnet.replay()
+                            l, acc = L.bce_logits_const(d, label, 1.0, want_acc=True)
+                            ls.append(l)
+                            out[nm + "_loss_" + tag], out[hit + "_hit_" + tag] = l.detach(), acc
+                        torch.autograd.backward(ls, [self._one, self._one])
+                        dnet.drop_cache()
+                    elif nm != "d4" and self.d_batch:
                         # d1 / d2 have no batch statistics: the source and the target batch go through the network as
                         # ONE batch of 2B samples (twice the tiles per launch on the 17x17 / 9x9 maps, half the launches);
                         # the two mean losses of :262-263,:296-297 are taken over the halves of the output, and their

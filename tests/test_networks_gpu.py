@@ -237,3 +237,34 @@ def test_block_backward_exact(dev):
     d1, d2 = torch.empty(2, 4, 128, 128, device=dev), torch.empty(2, 4, 128, 128, device=dev)
     op0.dgrad(dz0, P[blk + ".0.weight"], 128, 128, dx=d1, dx2=d2)
     assert rel_err(torch.cat([d1, d2], 1), xin.grad) < 1e-4
+
+
+def test_discriminator_replay_is_bit_identical_to_a_second_forward(dev):
+    """The train step's d1 / d2 update replays the target batch's activations from the frozen adversarial pass instead of
+    running the network on it again (same weights, same input values): outputs and every parameter gradient must be the
+    bits a second forward + backward produces, and the frozen pass's own input gradient must be untouched."""
+    from oracle import nets as ON
+    from pointcloududa_amd.networks import UncertaintyDiscriminator
+    from pointcloududa_amd.utils import loss as L
+    params = ON.make_params(ON.disc_param_shapes(4, False), 77, std=0.02)
+    rng = np.random.default_rng(78)
+    x_np = rng.normal(0, 1, (3, 4, 96, 96)).astype(np.float32)
+
+    def grads(replay):
+        m = _load(UncertaintyDiscriminator(4), params, dev)
+        x = torch.from_numpy(x_np).to(dev).requires_grad_(True)
+        m.requires_grad_(False)                                   # phase 2: frozen, gradient to the input only
+        d = m.forward_cached(x) if replay else m(x)
+        L.bce_logits_const(d, 1.0, weight=0.01).backward()
+        m.requires_grad_(True)                                    # phases 3-4: the update on the same (detached) values
+        d2 = m.replay() if replay else m(x.detach())
+        assert torch.equal(d2, d)
+        L.bce_logits_const(d2, 0.0).backward()
+        m.drop_cache()
+        return [x.grad.clone()] + [p.grad.clone() for p in m.parameters()]
+
+    for a, b in zip(grads(False), grads(True)):
+        assert torch.equal(a, b)
+    m = _load(UncertaintyDiscriminator(4), params, dev)
+    with pytest.raises(RuntimeError):
+        m.replay()
