@@ -61,14 +61,18 @@ __global__ __launch_bounds__(256) void c1_fwd_kernel(const C1Params p) {
   for (int i = tid; i < p.cout * 12; i += 256) {
     const int co = i / 12, k = i - co * 12;
     float v = 0.f;
+    const uint16_t* wq = p.wpack;
     if (k < 9) {
       const long long idx = (((long long)(co / p.co_tile) * 9 + k) * p.co_tile + co % p.co_tile) * p.rec;
-      v = bf16_bits_to_float(p.wpack[idx]);
-      if (p.rec > IG_REC) v += bf16_bits_to_float(p.wpack[idx + 32]);
-    } else if (k == 9) {
-      v = p.bias ? p.bias[co] : 0.f;
+      wq = p.wpack + idx;
+      v = bf16_bits_to_float(wq[0]);
+      if (p.rec > IG_REC) v += bf16_bits_to_float(wq[32]);
+    } else if (k == 9 && p.bias) {
+      wq = (const uint16_t*)(p.bias + co);
+      v = *(const float*)wq;
     }
     sw[i] = v;
+    PCUDA_KEEP(wq);      // (VMEM address rule, common.h)
   }
   __syncthreads();
   const int n = blockIdx.y, nq = (p.h * p.w) >> 2;
@@ -83,11 +87,15 @@ __global__ __launch_bounds__(256) void c1_fwd_kernel(const C1Params p) {
     const int yy = y + r - 1;
     const bool rok = (unsigned)yy < (unsigned)p.h;
     const float* row = xp + (long long)min(max(yy, 0), p.h - 1) * p.w;
-    const f32x4 m = *(const f32x4*)(row + x);
-    const float l = row[max(x - 1, 0)], rr = row[min(x + 4, p.w - 1)];
+    const float* pm = row + x;
+    const float* pl = row + max(x - 1, 0);
+    const float* pr = row + min(x + 4, p.w - 1);
+    const f32x4 m = *(const f32x4*)pm;
+    const float l = *pl, rr = *pr;
     in[r][0] = (rok && x > 0) ? l : 0.f;
     in[r][1] = rok ? m[0] : 0.f; in[r][2] = rok ? m[1] : 0.f; in[r][3] = rok ? m[2] : 0.f; in[r][4] = rok ? m[3] : 0.f;
     in[r][5] = (rok && x + 4 < p.w) ? rr : 0.f;
+    PCUDA_KEEP(pm); PCUDA_KEEP(pl); PCUDA_KEEP(pr);      // (VMEM address rule, common.h)
   }
   float* yp = p.y + (long long)n * p.y_sn + 4 * qq;
   for (int co = 0; co < p.cout; ++co) {
@@ -149,11 +157,15 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(const C1WgParams p) {
     const int yy = y0 + r - 1;
     const bool rok = valid && (unsigned)yy < (unsigned)p.h;
     const float* row = xp + (long long)min(max(yy, 0), p.h - 1) * p.w;
-    const f32x4 m = *(const f32x4*)(row + x);
-    const float l = row[max(x - 1, 0)], rr = row[min(x + 4, p.w - 1)];
+    const float* pm = row + x;
+    const float* pl = row + max(x - 1, 0);
+    const float* pr = row + min(x + 4, p.w - 1);
+    const f32x4 m = *(const f32x4*)pm;
+    const float l = *pl, rr = *pr;
     in[r][0] = (rok && x > 0) ? l : 0.f;
     in[r][1] = rok ? m[0] : 0.f; in[r][2] = rok ? m[1] : 0.f; in[r][3] = rok ? m[2] : 0.f; in[r][4] = rok ? m[3] : 0.f;
     in[r][5] = (rok && x + 4 < p.w) ? rr : 0.f;
+    PCUDA_KEEP(pm); PCUDA_KEEP(pl); PCUDA_KEEP(pr);      // (VMEM address rule, common.h)
   }
   const float* zp = p.dz + (long long)n * p.dz_sn + (long long)y0 * p.w + x;
   // output channels are split over blockIdx.z (twice the workgroups: 512 of them left the chip at two per CU)
@@ -161,15 +173,17 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(const C1WgParams p) {
   // (the next channel's four rows are requested before this channel's FMAs and reductions: loaded at the top of each
   // iteration, the loop ran at one memory round trip per channel)
   f32x4 zn[4];
+  const float* zq[4];      // addresses of the rows in flight (VMEM address rule, common.h)
 #pragma unroll
-  for (int r = 0; r < 4; ++r) zn[r] = *(const f32x4*)(zp + (long long)co_lo * p.dz_sc + (long long)r * p.w);
+  for (int r = 0; r < 4; ++r) { zq[r] = zp + (long long)co_lo * p.dz_sc + (long long)r * p.w; zn[r] = *(const f32x4*)zq[r]; }
   for (int co = co_lo; co < co_hi; ++co) {
     f32x4 z[4];
+    const float* zc[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) z[r] = zn[r];
+    for (int r = 0; r < 4; ++r) { z[r] = zn[r]; zc[r] = zq[r]; }
     const int con = min(co + 1, co_hi - 1);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) zn[r] = *(const f32x4*)(zp + (long long)con * p.dz_sc + (long long)r * p.w);
+    for (int r = 0; r < 4; ++r) { zq[r] = zp + (long long)con * p.dz_sc + (long long)r * p.w; zn[r] = *(const f32x4*)zq[r]; }
     float part[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) part[k] = 0.f;
@@ -188,7 +202,11 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(const C1WgParams p) {
       const float s = wave_sum_l63(part[k]);
       if (lane == 63) sred[wv][co * 10 + k] = s;
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) PCUDA_KEEP(zc[r]);
   }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) PCUDA_KEEP(zq[r]);
   __syncthreads();
   const long long blk = (long long)n * gridDim.x + blockIdx.x;
   for (int i = co_lo * 10 + tid; i < co_hi * 10; i += 256) {
@@ -232,12 +250,15 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const PwParams p) {
   for (int i = tid; i < p.cin * CO; i += 256) {
     const int ci = i / CO, co = i - ci * CO;
     float v = 0.f;
+    const uint16_t* wq = p.wpack;
     if (co < p.cout) {
       const long long idx = ((long long)(ci >> 5) * p.row_tile + co) * p.rec + (ci & 31);
-      v = bf16_bits_to_float(p.wpack[idx]);
-      if (p.rec > IG_REC) v += bf16_bits_to_float(p.wpack[idx + 32]);
+      wq = p.wpack + idx;
+      v = bf16_bits_to_float(wq[0]);
+      if (p.rec > IG_REC) v += bf16_bits_to_float(wq[32]);
     }
     sw[i] = v;
+    PCUDA_KEEP(wq);      // (VMEM address rule, common.h)
   }
   for (int i = tid; i < p.cin; i += 256) {
     const bool first = i < p.x.c1;
@@ -247,7 +268,11 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const PwParams p) {
     ssc[i] = scp ? scp[cc] : 1.f;
     ssh[i] = scp ? shp[cc] : 0.f;
   }
-  if (tid < CO) sb[tid] = (p.bias && tid < p.cout) ? p.bias[tid] : 0.f;
+  if (tid < CO) {
+    const float* bq = p.bias ? p.bias + min(tid, p.cout - 1) : nullptr;
+    sb[tid] = (bq && tid < p.cout) ? *bq : 0.f;
+    PCUDA_KEEP(bq);
+  }
   __syncthreads();
   const int n = blockIdx.y, nq = p.hw >> 2;
   const int q = blockIdx.x * 256 + tid;
@@ -257,7 +282,8 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const PwParams p) {
   for (int co = 0; co < CO; ++co) acc[co] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
   for (int ci = 0; ci < p.cin; ++ci) {
-    f32x4 a = *(const f32x4*)(pw_src_plane(p.x, n, ci) + 4 * q);
+    const float* src = pw_src_plane(p.x, n, ci) + 4 * q;
+    f32x4 a = *(const f32x4*)src;
     const float sc = ssc[ci], sh = ssh[ci];
 #pragma unroll
     for (int e = 0; e < 4; ++e) a[e] = fmaf(a[e], sc, sh);
@@ -267,6 +293,7 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const PwParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[co][e] = fmaf(w, a[e], acc[co][e]);
     }
+    PCUDA_KEEP(src);      // (VMEM address rule, common.h)
   }
 #pragma unroll
   for (int co = 0; co < CO; ++co) {
@@ -291,12 +318,15 @@ __global__ __launch_bounds__(256) void pw_dgrad_kernel(const PwParams p) {
   for (int i = tid; i < p.cin * CO; i += 256) {
     const int ci = i / CO, co = i - ci * CO;
     float v = 0.f;
+    const uint16_t* wq = p.wpack;
     if (co < p.cout) {
       const long long idx = (long long)ci * p.rec + co;
-      v = bf16_bits_to_float(p.wpack[idx]);
-      if (p.rec > IG_REC) v += bf16_bits_to_float(p.wpack[idx + 32]);
+      wq = p.wpack + idx;
+      v = bf16_bits_to_float(wq[0]);
+      if (p.rec > IG_REC) v += bf16_bits_to_float(wq[32]);
     }
     sw[i] = v;
+    PCUDA_KEEP(wq);      // (VMEM address rule, common.h)
   }
   __syncthreads();
   const int n = blockIdx.y, nq = p.hw >> 2;
@@ -305,10 +335,12 @@ __global__ __launch_bounds__(256) void pw_dgrad_kernel(const PwParams p) {
   if (!RED && !valid) return;
   const int q = min(q0, nq - 1);
   f32x4 z[CO];
+  const float* zsrc[CO];      // (VMEM address rule, common.h: kept until the loop below has used the data)
 #pragma unroll
   for (int co = 0; co < CO; ++co) {
     z[co] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (co < p.cout) z[co] = *(const f32x4*)(pw_src_plane(p.x, n, co) + 4 * q);
+    zsrc[co] = pw_src_plane(p.x, n, __builtin_amdgcn_readfirstlane(min(co, p.cout - 1))) + 4 * q;
+    if (co < p.cout) z[co] = *(const f32x4*)zsrc[co];
   }
 #pragma unroll 4
   for (int ci = 0; ci < p.cin; ++ci) {
@@ -325,17 +357,23 @@ __global__ __launch_bounds__(256) void pw_dgrad_kernel(const PwParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] += old[e];
     }
-    if (valid) *(f32x4*)d = o;
+    if (valid) *(f32x4*)d = o;      // (d stays live up to its store: the accumulate load's address is never reused early)
     if (RED) {
-      const f32x4 av = *(const f32x4*)(p.red_a + (long long)n * p.red_sn + (long long)ci * p.red_sc + 4 * q);
-      const float m = p.red_mean[ci], is = p.red_invstd[ci];
+      const float* pav = p.red_a + (long long)n * p.red_sn + (long long)ci * p.red_sc + 4 * q;
+      const f32x4 av = *(const f32x4*)pav;
+      const float* pmean = p.red_mean + ci;
+      const float* pinv = p.red_invstd + ci;
+      const float m = *pmean, is = *pinv;
       float s1 = (o[0] + o[1]) + (o[2] + o[3]);
       float s2 = (o[0] * ((av[0] - m) * is) + o[1] * ((av[1] - m) * is)) + (o[2] * ((av[2] - m) * is) + o[3] * ((av[3] - m) * is));
       s1 = wave_sum_l63(valid ? s1 : 0.f);
       s2 = wave_sum_l63(valid ? s2 : 0.f);
       if (lane == 63) { sred[wv][ci][0] = s1; sred[wv][ci][1] = s2; }
+      PCUDA_KEEP(pav); PCUDA_KEEP(pmean); PCUDA_KEEP(pinv);
     }
   }
+#pragma unroll
+  for (int co = 0; co < CO; ++co) PCUDA_KEEP(zsrc[co]);
   if (RED) {
     __syncthreads();
     if (tid < p.cin) {

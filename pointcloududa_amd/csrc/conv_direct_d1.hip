@@ -53,9 +53,11 @@ __global__ __launch_bounds__(256) void d1_dgrad_kernel(const D1Params p) {
     const int ry = ky & 1, rx = kx & 1, t = (ky >> 1) * 2 + (kx >> 1);
     const long long idx = (long long)(ry * 2 + rx) * p.cls_stride +
                           ((((long long)(co >> 5)) * 4 + t) * 32 + ci) * p.rec + (co & 31);
-    float v = bf16_bits_to_float(p.wpack[idx]);
-    if (p.rec > IG_REC) v += bf16_bits_to_float(p.wpack[idx + 32]);
+    const uint16_t* wq = p.wpack + idx;
+    float v = bf16_bits_to_float(wq[0]);
+    if (p.rec > IG_REC) v += bf16_bits_to_float(wq[32]);
     sw[i] = v;
+    PCUDA_KEEP(wq);      // (VMEM address rule, common.h)
   }
   __syncthreads();
   const int n = blockIdx.y;
@@ -71,29 +73,37 @@ __global__ __launch_bounds__(256) void d1_dgrad_kernel(const D1Params p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[ci][r][e] = 0.f;
   const float* zp = p.dz + (long long)n * p.dz_sn + (long long)Y * p.ow + X0;
-  // The five values of a row are read as five DWORD loads (index b * p.one, p.one == 1 at run time): the rows of dz are
-  // only 4-byte aligned (odd widths), and when the compiler merged them into one 4-byte-aligned global_load_dwordx4 plus a
-  // dword the kernel was not deterministic on a GPU shared by two processes -- 16-lane groups of single v_pk_fma_f32
-  // results differed between two launches on the same inputs (scripts/micro/d1_repro.py: 54 % of the launches; 0 of
-  // 48000 with dword loads; never seen with one process).  Wide loads in this library are naturally aligned.
+  // The five values of a row are read as five DWORD loads (index b * p.one, p.one == 1 at run time: the compiler cannot
+  // merge them; rows of dz are only 4-byte aligned) and the row addresses of the loads in flight are kept alive until
+  // their data has been used (VMEM address rule, common.h: the first build of this kernel -- one merged dwordx4 + a
+  // dword whose destination was the wide load's address register -- returned wrong 16-lane groups in 54 % of its
+  // launches on a GPU shared by two processes; scripts/micro/d1_repro.py).
   // (the next channel's ten gradient values are requested before this channel's FMAs: with the loads at the top of each
   // iteration the loop ran at one memory round trip per channel)
   float zn[2][5];
+  const float* zq[2];      // rows in flight
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < 2; ++a) {
+    zq[a] = zp + a * p.ow;
 #pragma unroll
-    for (int b = 0; b < 5; ++b) zn[a][b] = zp[a * p.ow + b * p.one];
+    for (int b = 0; b < 5; ++b) zn[a][b] = zq[a][b * p.one];
+  }
   for (int co = 0; co < p.cout; ++co) {
     float z[2][5];
+    const float* zc[2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a) {
+      zc[a] = zq[a];
 #pragma unroll
       for (int b = 0; b < 5; ++b) z[a][b] = zn[a][b];
+    }
     const int con = min(co + 1, p.cout - 1);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a) {
+      zq[a] = zp + (long long)con * p.dz_sc + a * p.ow;
 #pragma unroll
-      for (int b = 0; b < 5; ++b) zn[a][b] = zp[(long long)con * p.dz_sc + a * p.ow + b * p.one];
+      for (int b = 0; b < 5; ++b) zn[a][b] = zq[a][b * p.one];
+    }
     const float* wc = sw + co * CIN * 16;
 #pragma unroll
     for (int ci = 0; ci < CIN; ++ci)
@@ -109,7 +119,9 @@ __global__ __launch_bounds__(256) void d1_dgrad_kernel(const D1Params p) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) acc[ci][py][2 * j + px] = fmaf(wv, z[a][j + b], acc[ci][py][2 * j + px]);
             }
+    PCUDA_KEEP(zc[0]); PCUDA_KEEP(zc[1]);
   }
+  PCUDA_KEEP(zq[0]); PCUDA_KEEP(zq[1]);
 #pragma unroll
   for (int ci = 0; ci < CIN; ++ci)
 #pragma unroll
@@ -153,23 +165,30 @@ __global__ __launch_bounds__(256) void d1_wgrad_kernel(const D1Params p, const i
   // row) and the four input rows of channel w (one 16-byte load per lane and row); the loads of item i + 1 are in
   // flight during item i's FMAs.  (A plain strided copy loop issued one load per iteration and waited for it: the
   // kernel ran at a memory round trip per 256 elements.)
-  const int lane = tid & 63, wv = tid >> 6;
+  const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   float rz[16][3];
   f32x4 rx[4];
+  const float* xq[4] = {p.x, p.x, p.x, p.x};      // addresses of the input rows in flight
+  // VMEM address rule (common.h): these loads stay in flight through a whole item's FMAs.  Every address is a
+  // wave-uniform row base (SGPRs) + one of four per-lane offsets that live for the whole kernel (kept after the loop),
+  // so no load's address registers can be handed to a destination.
+  const unsigned zoff[3] = {(unsigned)min(lane, p.ow - 1), (unsigned)min(lane + 64, p.ow - 1), (unsigned)min(lane + 128, p.ow - 1)};
+  const unsigned xoff = (unsigned)min(4 * lane, p.w - 4);
   auto issue = [&](int it) {
     const int n = it / p.oh, oy = it - n * p.oh;
     const float* zb = p.dz + (long long)n * p.dz_sn + (long long)oy * p.ow;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      const int co = min(wv + 4 * k, p.cout - 1);
+      const float* zrow = zb + (long long)min(wv + 4 * k, p.cout - 1) * p.dz_sc;      // wave-uniform
 #pragma unroll
-      for (int u = 0; u < 3; ++u) rz[k][u] = zb[(long long)co * p.dz_sc + min(lane + 64 * u, p.ow - 1)];
+      for (int u = 0; u < 3; ++u) rz[k][u] = zrow[zoff[u]];
     }
     const float* xb = p.x + (long long)n * p.x_sn + (long long)min(wv, CIN - 1) * p.x_sc;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int yy = min(max(2 * oy + r - 2, 0), p.h - 1);
-      rx[r] = *(const f32x4*)(xb + (long long)yy * p.w + min(4 * lane, p.w - 4));
+      const float* xrow = xb + (long long)min(max(2 * oy + r - 2, 0), p.h - 1) * p.w;  // wave-uniform
+      xq[r] = xrow + xoff;
+      rx[r] = *(const f32x4*)xq[r];
     }
   };
   auto commit = [&](int it) {
@@ -192,6 +211,7 @@ __global__ __launch_bounds__(256) void d1_wgrad_kernel(const D1Params p, const i
         float* d = sx + (wv * 4 + r) * D1_XP + 2 + 4 * lane;      // (column c of the row holds input column c - 2)
 #pragma unroll
         for (int e = 0; e < 4; ++e) d[e] = ok ? rx[r][e] : 0.f;
+        PCUDA_KEEP(xq[r]);
         if (lane < 2) sx[(wv * 4 + r) * D1_XP + lane] = 0.f;                                  // left halo
         if (lane < D1_XP - 2 - 256) sx[(wv * 4 + r) * D1_XP + 2 + 256 + lane] = 0.f;          // right halo / pad
       }
@@ -222,6 +242,7 @@ __global__ __launch_bounds__(256) void d1_wgrad_kernel(const D1Params p, const i
       }
     }
   }
+  PCUDA_KEEP(zoff[0]); PCUDA_KEEP(zoff[1]); PCUDA_KEEP(zoff[2]); PCUDA_KEEP(xoff);
   if (live) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -358,6 +379,7 @@ __global__ __launch_bounds__(D5_NT) void d5_fwd_kernel(const D5Params p) {
   }
   const int per = (D5_CH * hw + D5_NT - 1) / D5_NT;   // staged elements per thread and chunk (<= 19)
   float rx[19], rw;
+  const uint16_t* wq = p.wpack;
   auto issue = [&](int c0) {
     const float* xb = p.x + (long long)n * p.x_sn + (long long)c0 * p.x_sc;
 #pragma unroll
@@ -370,8 +392,9 @@ __global__ __launch_bounds__(D5_NT) void d5_fwd_kernel(const D5Params p) {
     {
       const int c = tid >> 4, t = tid & 15, ci = min(c0 + c, p.cin - 1);
       const long long idx = (((long long)(ci >> 5)) * 16 + t) * 32 * p.rec + (ci & 31);
-      rw = bf16_bits_to_float(p.wpack[idx]);
-      if (p.rec > IG_REC) rw += bf16_bits_to_float(p.wpack[idx + 32]);
+      wq = p.wpack + idx;
+      rw = bf16_bits_to_float(wq[0]);
+      if (p.rec > IG_REC) rw += bf16_bits_to_float(wq[32]);
       if (c0 + c >= p.cin) rw = 0.f;
     }
   };
@@ -385,6 +408,7 @@ __global__ __launch_bounds__(D5_NT) void d5_fwd_kernel(const D5Params p) {
       if (u < per && i < D5_CH * hw) sx[(i / hw) * D5_MAXPIX + (i - (i / hw) * hw)] = rx[u];
     }
     swt[tid] = rw;
+    PCUDA_KEEP(wq);      // (VMEM address rule, common.h: the weight's address outlives its load)
     __syncthreads();
     if (c0 + D5_CH < p.cin) issue(c0 + D5_CH);
     if (live) {
@@ -405,7 +429,12 @@ __global__ __launch_bounds__(D5_NT) void d5_fwd_kernel(const D5Params p) {
   if (tid < op) {
     float s = 0.f;
     for (int k = 0; k < ng; ++k) s += spart[k * op + tid];   // fixed order
-    s += p.bias ? p.bias[0] : 0.f;
+    // (VMEM address rule, common.h: SGPR base + a VGPR offset of its own that outlives the load -- the constant 0 the
+    // compiler would use is a register it hands to the destination)
+    int boff = 0;
+    asm volatile("" : "+v"(boff));
+    s += p.bias ? p.bias[boff] : 0.f;
+    PCUDA_KEEP(boff);
     s = s > 0.f ? s : s * p.slope;
     p.y[(long long)n * p.y_sn + tid] = s;
   }

@@ -30,6 +30,56 @@ def work(rank, iters, victim, heavy):
     elif victim == "pwdgrad":
         op, w, dy = K.ConvOp(4, 4, 1), rn(4, 4, 1, 1) * 0.05, rn(4, 4, 256, 256)
         run = lambda: op.dgrad(dy, w, 256, 256)
+    elif victim == "c1wgrad":
+        op, x, dy = K.ConvOp(1, 32, 3, stride=1, pad=1), rn(4, 1, 256, 256), rn(4, 32, 256, 256)
+        def run():
+            dw, db = torch.zeros(32, 1, 3, 3, device=dev), torch.zeros(32, device=dev)
+            op.wgrad(x, dy, dw, db, 256, 256)
+            return torch.cat([dw.flatten(), db])
+    elif victim == "c1fwd32":
+        op, w, x, b = K.ConvOp(1, 32, 3, stride=1, pad=1), rn(32, 1, 3, 3) * 0.05, rn(4, 1, 256, 256), torch.zeros(32, device=dev)
+        run = lambda: torch.cat([t.flatten() for t in op.forward(x, w, b, 0.2, 256, 256, want_stats=True)[:2]])
+    elif victim == "pwfwd":
+        op, w, x, b = K.ConvOp(32, 4, 1), rn(4, 32, 1, 1) * 0.05, rn(4, 32, 256, 256), torch.zeros(4, device=dev)
+        run = lambda: op.forward(x, w, b, 1.0, 256, 256)[0]
+    elif victim == "pwdgrad32":
+        op, w, dy = K.ConvOp(32, 4, 1), rn(4, 32, 1, 1) * 0.05, rn(4, 4, 256, 256)
+        a = rn(4, 32, 256, 256)
+        p_, nt_, cnt_ = K.bn_stats(a)
+        bst = K.bn_finalize(p_, nt_, cnt_, torch.ones(32, device=dev), torch.zeros(32, device=dev), None, None)
+        def run():
+            dx, red = op.dgrad(dy, w, 256, 256, bnred=(a, bst))
+            return torch.cat([dx.flatten(), red[0].flatten()])
+    elif victim.startswith("mfma:"):      # mfma:cin,cout,hw,k,stride,pad,which(fwd|dgrad|wgrad),n
+        cin, cout, hw_, k_, s_, p_, which, n_ = victim[5:].split(",")
+        cin, cout, hw_, k_, s_, p_, n_ = int(cin), int(cout), int(hw_), int(k_), int(s_), int(p_), int(n_)
+        op = K.ConvOp(cin, cout, k_, stride=s_, pad=p_)
+        oh, ow = op.out_hw(hw_, hw_)
+        x, w, b, dy = rn(n_, cin, hw_, hw_), rn(cout, cin, k_, k_) * 0.05, torch.zeros(cout, device=dev), rn(n_, cout, oh, ow)
+        if which == "fwd":
+            run = lambda: torch.cat([t.flatten() for t in op.forward(x, w, b, 0.2, hw_, hw_, want_stats=True)[:2]])
+        elif which == "dgrad":
+            run = lambda: op.dgrad(dy, w, hw_, hw_)
+        else:
+            def run():
+                dw, db = torch.zeros_like(w), torch.zeros_like(b)
+                op.wgrad(x, dy, dw, db, hw_, hw_)
+                return torch.cat([dw.flatten(), db])
+    elif victim == "clone":
+        x = rn(4, 32, 256, 256)
+        run = lambda: x.clone()
+    elif victim == "axpb":
+        x = rn(4, 32, 256, 256)
+        run = lambda: x * 1.5 + 2.0
+    elif victim == "lrelubwd":
+        a, dy = rn(4, 32, 256, 256), rn(4, 32, 256, 256)
+        run = lambda: K.lrelu_bwd(dy, a, 0.2)
+    elif victim == "d1wgrad":
+        op, x, dy = K.ConvOp(4, 64, 4, stride=2, pad=2), rn(4, 4, 96, 96), rn(4, 64, 49, 49)
+        def run():
+            dw = torch.zeros(64, 4, 4, 4, device=dev)
+            op.wgrad(x, dy, dw, None, 96, 96)
+            return dw
     elif victim == "d5fwd":
         op, w, x, b = K.ConvOp(512, 1, 4, stride=2, pad=2), rn(1, 512, 4, 4) * 0.05, rn(4, 512, 7, 7), torch.zeros(1, device=dev)
         run = lambda: op.forward(x, w, b, 1.0, 7, 7)[0]

@@ -1,0 +1,34 @@
+"""Build-time rule for the direct (vector-ALU) kernels: no vector-memory load may have destination registers that overlap
+its own address registers.  The compiler allows it; on a GPU shared by two processes such loads returned wrong data
+(pointcloududa_amd/csrc/common.h, "VMEM address rule"; profiles/r02_two_process_determinism.txt).  These kernels have a
+small LDS footprint and therefore share compute units with other processes' workgroups; they keep every in-flight
+load's address alive with PCUDA_KEEP, and this test scans their device assembly for the pattern."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "pointcloududa_amd", "csrc")
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc (cross-compiles without a GPU)")
+def test_direct_kernels_keep_load_addresses_alive():
+    r = subprocess.run(["make", "-C", CSRC, "isa"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import vmem_overlap_scan as V
+    rows = V.scan(os.path.join(CSRC, "build", "isa"))
+    assert len(rows) >= 20, "expected the direct kernels' instantiations in the assembly"
+    bad = [(f, k, n, ex) for f, k, n, ex in rows if n]
+    assert not bad, "loads whose destination overlaps their address: %s" % bad[:4]
+
+
+def test_scanner_sees_the_pattern(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import vmem_overlap_scan as V
+    (tmp_path / "k.s").write_text("_Z1kv:\n\tglobal_load_dwordx4 v[46:49], v[46:47], off\n\tglobal_load_dword v3, v[4:5], off\n"
+                                  "\tglobal_load_dword v2, v2, s[12:13]\n\tglobal_load_dword v68, v[68:69], off offset:16\n\ts_endpgm\n")
+    rows = V.scan(str(tmp_path))
+    assert len(rows) == 1 and rows[0][2] == 3
