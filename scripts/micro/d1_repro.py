@@ -65,6 +65,55 @@ def work(rank, iters, victim, heavy):
                 dw, db = torch.zeros_like(w), torch.zeros_like(b)
                 op.wgrad(x, dy, dw, db, hw_, hw_)
                 return torch.cat([dw.flatten(), db])
+    elif victim.startswith("pw:"):        # the LDS-free pointwise / loss / dense kernels on segmenter-sized tensors
+        name = victim[3:]
+        a, dyv = rn(4, 32, 256, 256), rn(4, 32, 256, 256)
+        gam, bet = torch.ones(32, device=dev), torch.zeros(32, device=dev)
+        p_, nt_, cnt_ = K.bn_stats(a)
+        bst = K.bn_finalize(p_, nt_, cnt_, gam, bet, None, None)
+        logits = rn(4, 4, 256, 256)
+        onehot = torch.nn.functional.one_hot(torch.randint(0, 4, (4, 256, 256), generator=g), 4).permute(0, 3, 1, 2).contiguous().to(torch.uint8).to(dev)
+        if name == "bnstats":
+            run = lambda: K.bn_stats(a)[0]
+        elif name == "bnapply":
+            run = lambda: K.bn_apply(a, bst)
+        elif name == "bnbwd":
+            run = lambda: K.bn_backward(dyv, a, bst, gam, torch.zeros(32, device=dev), torch.zeros(32, device=dev), act_slope=0.2)
+        elif name == "maxpool":
+            run = lambda: K.maxpool2_fwd(a)[0]
+        elif name == "maxpoolbwd":
+            pooled, idx = K.maxpool2_fwd(a)
+            dyp = rn(*pooled.shape)
+            run = lambda: K.maxpool2_bwd(dyp, idx, 256, 256)
+        elif name == "upbwd":
+            run = lambda: K.upsample2_bwd(dyv)
+        elif name == "addn":
+            b2, b3 = rn(4, 32, 256, 256), rn(4, 32, 256, 256)
+            run = lambda: K.add_n([a, b2, b3])
+        elif name == "entropy":
+            run = lambda: K.entropy_fwd(logits, "sigmoid", 1.0, False)[0]
+        elif name == "entropybwd":
+            de = rn(4, 4, 256, 256)
+            run = lambda: K.entropy_bwd(logits, "sigmoid", 1.0, de, None)
+        elif name == "segloss":
+            run = lambda: torch.stack(list(K.seg_loss_fwd(logits, onehot, "sigmoid")[:2]))
+        elif name == "seglossbwd":
+            ws = K.seg_loss_fwd(logits, onehot, "sigmoid")[2]
+            run = lambda: K.seg_loss_bwd(logits, onehot, "sigmoid", ws)
+        elif name == "adam":
+            pp, gg = rn(1 << 22), rn(1 << 22)
+            def run():
+                q, m_, v_ = pp.clone(), torch.zeros_like(pp), torch.zeros_like(pp)
+                K.adam_step(q, gg, m_, v_, 1e-3, 0.9, 0.99, 1e-8, 0.0, 1)
+                return q
+        elif name == "linear":
+            xl, wl, bl = rn(9600, 121), rn(3, 121), rn(3)
+            run = lambda: K.linear_fwd(xl, wl, bl)
+        elif name == "unfold":
+            xu = rn(4, 4, 256, 256)
+            run = lambda: K.unfold_taps(xu, 4, 2, 2)
+        else:
+            raise SystemExit("pw victim?")
     elif victim == "clone":
         x = rn(4, 32, 256, 256)
         run = lambda: x.clone()
