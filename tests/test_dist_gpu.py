@@ -81,3 +81,37 @@ def test_two_rank_step_on_one_gpu(dev, tmp_path):
         assert torch.equal(r0["same"][i], single[i]), name + ": two ranks on one shard != single process"
         assert torch.equal(r0["diff"][i], r1["diff"][i]), name + ": replicas diverged"
         assert not torch.equal(r0["diff"][i], single[i]), name
+
+
+def _shared_gpu_worker(rank, tmp, iters):
+    """two of these run at once: a persistent MFMA convolution in front of every launch of two direct kernels"""
+    sys.path.insert(0, ROOT)
+    import pointcloududa_amd.kernels as K
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    rn = lambda *s: torch.randn(*s, generator=g).to(dev)
+    big, wb, xb, bb = K.ConvOp(32, 32, 3, pad=1), rn(32, 32, 3, 3) * 0.05, rn(4, 32, 256, 256), torch.zeros(32, device=dev)
+    cls, wc, xc, bc = K.ConvOp(32, 4, 1), rn(4, 32, 1, 1) * 0.05, rn(4, 32, 256, 256), torch.zeros(4, device=dev)
+    d1, wd, dyd = K.ConvOp(4, 64, 4, stride=2, pad=2), rn(64, 4, 4, 4) * 0.05, rn(4, 64, 49, 49)
+    victims = {"classifier forward": lambda: cls.forward(xc, wc, bc, 1.0, 256, 256)[0],
+               "discriminator first-layer dgrad": lambda: d1.dgrad(dyd, wd, 96, 96)}
+    refs = {k: f().clone() for k, f in victims.items()}
+    bad = {k: torch.zeros((), dtype=torch.int64, device=dev) for k in victims}
+    torch.cuda.synchronize()
+    for _ in range(iters):
+        big.forward(xb, wb, bb, 1.0, 256, 256)
+        for k, f in victims.items():
+            bad[k] += (f() != refs[k]).any().long()
+    torch.cuda.synchronize()
+    torch.save({k: int(v) for k, v in bad.items()}, os.path.join(tmp, "shared%d.pt" % rank))
+
+
+def test_direct_kernels_return_the_same_bits_on_a_shared_gpu(dev, tmp_path):
+    """Regression test of the VMEM address rule (csrc/common.h): before it, the classifier forward and the
+    discriminators' first-layer data gradient returned wrong 16-lane groups in 20-70 % of their launches whenever a
+    second process ran this library's MFMA convolution on the same GPU (never with one process)."""
+    iters = 400
+    mp.spawn(_shared_gpu_worker, args=(str(tmp_path), iters), nprocs=2, join=True)
+    for r in range(2):
+        got = torch.load(os.path.join(str(tmp_path), "shared%d.pt" % r))
+        assert all(v == 0 for v in got.values()), (r, got, iters)
