@@ -19,6 +19,41 @@ from ..kernels import ConvOp
 from ._holders import Conv2d, LeakyReLU, Linear, Marker, ensure_grad
 
 
+def _chain_forward(module, x, weights, biases, outs=None):
+    """the layers in turn; ``outs``: optional preallocated output tensor per layer.  -> (acts, sizes, out)"""
+    nl = len(module._chain)
+    acts, sizes = [x], []
+    h, w = x.shape[2], x.shape[3]
+    cur = x
+    for li, (name, op) in enumerate(module._chain):
+        slope = module._slope if li < nl - 1 else 1.0
+        sizes.append((h, w))
+        wt = weights[li].view(op.cout, op.cin, op.k, op.k)
+        dst = None if outs is None else outs[li]
+        if li == 0 and module._fold1 is not None:
+            # a handful of input channels: unfold the taps into channels and run the layer as a 1x1 convolution
+            # whose 32-deep reduction chunks are full (16 taps x 4 of 32 channels otherwise)
+            unfolded = K.unfold_taps(cur, op.k, op.stride, op.pad, op.dil)
+            oh, ow = op.out_hw(h, w)
+            cur, _, _ = module._fold1.forward(unfolded, wt.view(wt.shape[0], -1, 1, 1), biases[0], slope, oh, ow, out=dst)
+        else:
+            cur, _, _ = op.forward(cur, wt, biases[li], slope, h, w, out=dst)
+        h, w = op.out_hw(h, w)
+        acts.append(cur)
+    return acts, sizes, cur
+
+
+def _joint_buffers(module, x, room):
+    """per layer one output tensor for (1 + room) batches of x's size: a cached pass writes the LAST batch slot, the
+    batches filled in later (``forward_fill``) the ones in front, and ``replay`` walks all of them as one batch"""
+    b, h, w = x.shape[0], x.shape[2], x.shape[3]
+    full = []
+    for name, op in module._chain:
+        h, w = op.out_hw(h, w)
+        full.append(torch.empty(((1 + room) * b, op.cout, h, w), dtype=torch.float32, device=x.device))
+    return full
+
+
 class _ConvChainFn(torch.autograd.Function):
     """x -> [conv (+bias) -> LeakyReLU(slope)]* -> conv (+bias)   over a list of Conv2d / Linear holders.
     ``wb``: the chain's weights followed by its biases (None where a layer has none)."""
@@ -30,29 +65,18 @@ class _ConvChainFn(torch.autograd.Function):
         x = x.contiguous().float()
         nl = len(module._chain)
         weights, biases = wb[:nl], wb[nl:]
-        acts, sizes = [x], []
-        h, w = x.shape[2], x.shape[3]
-        cur = x
-        for li, (name, op) in enumerate(module._chain):
-            slope = module._slope if li < nl - 1 else 1.0
-            sizes.append((h, w))
-            wt = weights[li].view(op.cout, op.cin, op.k, op.k)
-            if li == 0 and module._fold1 is not None:
-                # a handful of input channels: unfold the taps into channels and run the layer as a 1x1 convolution
-                # whose 32-deep reduction chunks are full (16 taps x 4 of 32 channels otherwise)
-                unfolded = K.unfold_taps(cur, op.k, op.stride, op.pad, op.dil)
-                oh, ow = op.out_hw(h, w)
-                cur, _, _ = module._fold1.forward(unfolded, wt.view(wt.shape[0], -1, 1, 1), biases[0], slope, oh, ow)
-            else:
-                cur, _, _ = op.forward(cur, wt, biases[li], slope, h, w)
-            h, w = op.out_hw(h, w)
-            acts.append(cur)
+        caching, room = getattr(module, "_cache_next", False), getattr(module, "_cache_room", 0)
+        full = _joint_buffers(module, x, room) if (caching and room) else None
+        b = x.shape[0]
+        acts, sizes, cur = _chain_forward(module, x, weights, biases,
+                                          None if full is None else [f[room * b:] for f in full])
         ctx.module, ctx.acts, ctx.sizes, ctx.weights, ctx.biases = module, acts, sizes, weights, biases
         if getattr(module, "_keep_acts", False):      # tests (shared-routing backward checks)
             module._last_acts = list(acts)
-        if getattr(module, "_cache_next", False):     # forward_cached(): this pass can be replayed (replay())
+        if caching:                                   # forward_cached(): this pass can be replayed (replay())
             module._cache_next = False
-            module._cache = (list(acts), list(sizes), cur)
+            module._cache = dict(acts=list(acts), sizes=list(sizes), out=cur, full=full, b=b,
+                                 x=[None] * room + [x])
         ctx.set_materialize_grads(False)
         return cur
 
@@ -65,13 +89,17 @@ class _ConvChainReplayFn(torch.autograd.Function):
     """The output of an EARLIER forward pass of the chain (``forward_cached``), with a backward pass of its own through
     the activations that pass kept: weights unchanged in between, same input -> the forward would recompute the same
     bits.  The train step's discriminator update sees the target batch this way: the frozen adversarial pass of phase 2
-    already ran the network on it (train_mscmrseg.py:222-241 and :283-322 call D on the same tensor values)."""
+    already ran the network on it (train_mscmrseg.py:222-241 and :283-322 call D on the same tensor values).  With
+    room for more batches in the cached pass's buffers (``forward_fill``) the node spans all of them as ONE batch."""
 
     @staticmethod
     def forward(ctx, module, cache, *wb):
         nl = len(module._chain)
-        acts, sizes, out = cache
-        ctx.module, ctx.acts, ctx.sizes, ctx.weights, ctx.biases = module, acts, sizes, wb[:nl], wb[nl:]
+        if cache["full"] is not None:
+            acts, out = [list(cache["x"])] + cache["full"], cache["full"][-1]
+        else:
+            acts, out = cache["acts"], cache["out"]
+        ctx.module, ctx.acts, ctx.sizes, ctx.weights, ctx.biases = module, acts, cache["sizes"], wb[:nl], wb[nl:]
         ctx.set_materialize_grads(False)
         return out.detach()
 
@@ -97,7 +125,13 @@ def _chain_backward(ctx, d_out):
                 # (the first layer's weight gradient stays on the k x k kernel: the one-tap form of the weight-gradient
                 # kernel stages a tile per tap and measured 0.40 ms against 0.25 ms for this layer)
                 db = ensure_grad(biases[li]) if (biases[li] is not None and ctx.needs_input_grad[2 + nl + li]) else None
-                op.wgrad(acts[li], dz, ensure_grad(weights[li]).view(op.cout, op.cin, op.k, op.k), db, h, w)
+                dw = ensure_grad(weights[li]).view(op.cout, op.cin, op.k, op.k)
+                if isinstance(acts[li], list):      # (joint replay: the network's inputs stay separate tensors)
+                    bq = acts[li][0].shape[0]
+                    for q, xq in enumerate(acts[li]):
+                        op.wgrad(xq, dz[q * bq:(q + 1) * bq], dw, db, h, w)
+                else:
+                    op.wgrad(acts[li], dz, dw, db, h, w)
             if li > 0:
                 d_a = op.dgrad(dz, wt, h, w)
                 dz = K.lrelu_bwd(d_a, acts[li], module._slope)
@@ -144,17 +178,37 @@ class _ConvChain(nn.Module):
         bs = [getattr(self, n).bias for n, _ in self._chain]
         return _ConvChainFn.apply(self, x, *(ws + bs))
 
-    def forward_cached(self, x):
-        """``forward`` that keeps its activations for ONE later ``replay()`` (dropped by ``drop_cache()``)"""
-        self._cache_next = True
-        return self(x)
+    def forward_cached(self, x, room=0):
+        """``forward`` that keeps its activations for ONE later ``replay()`` (dropped by ``drop_cache()``).
+        ``room``: batches of the same size that ``forward_fill`` will put IN FRONT of this one before the replay."""
+        self._cache_next, self._cache_room = True, int(room)
+        try:
+            return self(x)
+        finally:
+            self._cache_next, self._cache_room = False, 0
+
+    def forward_fill(self, x, slot=0):
+        """Run the network on another batch (no autograd node) into slot ``slot`` of the cached pass's buffers."""
+        cache = getattr(self, "_cache", None)
+        if cache is None or cache["full"] is None or slot >= len(cache["x"]) - 1 or x.shape[0] != cache["b"]:
+            raise RuntimeError("forward_fill() needs a cached pass with room for a batch of this size")
+        ws = [getattr(self, n).weight for n, _ in self._chain]
+        bs = [getattr(self, n).bias for n, _ in self._chain]
+        b = cache["b"]
+        x = x.detach().contiguous().float()
+        with torch.no_grad():
+            _chain_forward(self, x, ws, bs, [f[slot * b:(slot + 1) * b] for f in cache["full"]])
+        cache["x"][slot] = x
 
     def replay(self):
-        """The cached pass's output as a new autograd node whose backward pass produces THIS call's parameter
-        gradients (the parameters must not have changed since ``forward_cached``)."""
+        """The cached pass's output -- with room: the outputs of all batches in its buffers, filled ones first -- as a
+        new autograd node whose backward pass produces THIS call's parameter gradients (the parameters must not have
+        changed since ``forward_cached``)."""
         cache = getattr(self, "_cache", None)
         if cache is None:
             raise RuntimeError("replay() without a cached forward pass")
+        if any(t is None for t in cache["x"]):
+            raise RuntimeError("replay(): a batch slot of the cached pass was never filled")
         ws = [getattr(self, n).weight for n, _ in self._chain]
         bs = [getattr(self, n).bias for n, _ in self._chain]
         return _ConvChainReplayFn.apply(self, cache, *(ws + bs))

@@ -75,6 +75,8 @@ class AdversarialTrainer:
         # d1 / d2 update on the target batch replays the frozen adversarial pass of phase 2 (same weights, same input
         # values -> the same activations) instead of running the network forward on it again
         self.d_reuse = os.environ.get("PCUDA_DREUSE", "1") != "0"
+        # ... with the source batch's activations written in front of the cached target ones: one backward pass over 2B
+        self.d_joint = os.environ.get("PCUDA_DJOINT", "1") != "0"
 
     def _side_streams(self, names):
         """One side stream PER DISCRIMINATOR, keyed by its name: a network's frozen pass (phase 2), its input-gradient
@@ -194,7 +196,8 @@ class AdversarialTrainer:
         # the frozen discriminators' forward passes (and, through autograd's per-node streams, their input-gradient
         # passes) run next to each other like phases 3-4 below
         heads = []
-        run_d = lambda m, x: m.forward_cached(x) if self._replays(m) else m(x)
+        # (PCUDA_DJOINT=1: with room for the source batch in front, the update then walks source + target as ONE batch)
+        run_d = lambda m, x: m.forward_cached(x, room=1 if self.d_joint else 0) if self._replays(m) else m(x)
         if c.d2:
             heads.append(("adv2", lambda: run_d(self.dis2, ent_t), c.dr * (1.0 if ms else c.w2)))
         if c.d4:
@@ -278,9 +281,16 @@ class AdversarialTrainer:
                         # weights have not moved and the input values are the same).  Both backward passes add into
                         # the network's gradient buffer, as the reference's two backward calls do (:262-263,:296-297).
                         ls = []
-                        for tag, label in (("src", 1.0), ("tgt", 0.0)):
-                            d = fwd(ent_s, in1_s, None) if tag == "src" else dnet.replay()
-                            l, acc = L.bce_logits_const(d, label, 1.0, want_acc=True)
+                        if dnet._cache["full"] is not None:
+                            # the source batch's activations go in front of the target batch's in the cached pass's
+                            # buffers: one backward pass over 2B samples, the arithmetic of the one-batch form below
+                            dnet.forward_fill(ent_s if nm == "d2" else in1_s)
+                            d, bsz = dnet.replay(), o_s.shape[0]
+                            parts = (("src", 1.0, d[:bsz]), ("tgt", 0.0, d[bsz:]))
+                        else:
+                            parts = (("src", 1.0, fwd(ent_s, in1_s, None)), ("tgt", 0.0, dnet.replay()))
+                        for tag, label, part in parts:
+                            l, acc = L.bce_logits_const(part, label, 1.0, want_acc=True)
                             ls.append(l)
                             out[nm + "_loss_" + tag], out[hit + "_hit_" + tag] = l.detach(), acc
                         torch.autograd.backward(ls, [self._one, self._one])

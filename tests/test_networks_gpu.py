@@ -268,3 +268,43 @@ def test_discriminator_replay_is_bit_identical_to_a_second_forward(dev):
     m = _load(UncertaintyDiscriminator(4), params, dev)
     with pytest.raises(RuntimeError):
         m.replay()
+
+
+def test_discriminator_joint_replay_matches_the_one_batch_form(dev):
+    """forward_cached(target, room=1) + forward_fill(source) + replay(): the update's backward pass over source + target
+    as ONE batch without a second forward on the target -- against the network run on cat([source, target])."""
+    from oracle import nets as ON
+    from pointcloududa_amd.networks import UncertaintyDiscriminator
+    from pointcloududa_amd.utils import loss as L
+    params = ON.make_params(ON.disc_param_shapes(4, False), 81, std=0.02)
+    rng = np.random.default_rng(82)
+    xs_np, xt_np = (rng.normal(0, 1, (3, 4, 96, 96)).astype(np.float32) for _ in range(2))
+
+    def run(joint):
+        m = _load(UncertaintyDiscriminator(4), params, dev)
+        xs = torch.from_numpy(xs_np).to(dev)
+        xt = torch.from_numpy(xt_np).to(dev).requires_grad_(True)
+        m.requires_grad_(False)
+        d_t = m.forward_cached(xt, room=1) if joint else m(xt)
+        L.bce_logits_const(d_t, 1.0, weight=0.01).backward()
+        m.requires_grad_(True)
+        if joint:
+            m.forward_fill(xs)
+            d = m.replay()
+        else:
+            d = m(torch.cat([xs, xt.detach()], 0))
+        assert torch.equal(d[3:], d_t)
+        ls = [L.bce_logits_const(d[:3], 1.0), L.bce_logits_const(d[3:], 0.0)]
+        torch.autograd.backward(ls, [torch.ones((), device=dev)] * 2)
+        if joint:
+            m.drop_cache()
+        return [d.detach().clone(), xt.grad.clone()] + [p.grad.clone() for p in m.parameters()]
+
+    one, joint = run(False), run(True)
+    # outputs, the frozen pass's input gradient and every layer's weight gradient are the same bits; the FIRST layer's
+    # weight gradient is accumulated batch by batch (its inputs stay two tensors): same sum, other rounding order
+    for i, (a, b) in enumerate(zip(one, joint)):
+        if i == 2:
+            assert rel_err(b, a) < 1e-6
+        else:
+            assert torch.equal(a, b), i
