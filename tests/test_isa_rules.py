@@ -19,7 +19,7 @@ def test_direct_kernels_keep_load_addresses_alive():
     assert r.returncode == 0, r.stderr[-2000:]
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import vmem_overlap_scan as V
-    rows = V.scan(os.path.join(CSRC, "build", "isa"))
+    rows = [r for r in V.scan(os.path.join(CSRC, "build", "isa")) if r[0] in ("conv_direct.s", "conv_direct_d1.s")]
     assert len(rows) >= 20, "expected the direct kernels' instantiations in the assembly"
     bad = [(f, k, n, ex) for f, k, n, ex in rows if n]
     assert not bad, "loads whose destination overlaps their address: %s" % bad[:4]
