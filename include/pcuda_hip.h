@@ -51,7 +51,8 @@ const char* pcuda_last_error(void);      /* text of the last failing call on thi
 #define PCUDA_FAM_CONV_FWD 0   /* implicit-GEMM forward + dgrad launches */
 #define PCUDA_FAM_CONV_WGRAD 1
 #define PCUDA_FAM_POINTWISE 2
-#define PCUDA_FAM_COUNT 3
+#define PCUDA_FAM_DENSE_F32 3 /* exact-fp32 MFMA k=1 Conv1d of PointNetCls (forward, dgrad, wgrad): fp32 matrix peak, not bf16 */
+#define PCUDA_FAM_COUNT 4
 int pcuda_prof_enable(int on);
 int pcuda_prof_reset(void);
 /* synchronises the recorded events; ms = summed kernel time, work = summed algorithmic
@@ -307,6 +308,21 @@ int pcuda_linear_bwd_x(const float* dy, const float* w, float* dx, int m, int k,
 size_t pcuda_linear_bwd_w_workspace_size(int m, int k, int n);
 int pcuda_linear_bwd_w(const float* dy, const float* x, float* dw, float* db, int m, int k, int n, int accumulate,
                        void* workspace, size_t workspace_bytes, pcuda_stream_t s);
+/* torch.nn.Conv1d(cin, cout, 1) on dense [b][c][l] point clouds (PointNetCls.py:26-28 STN3d, :76-78 STNkd, :116-131
+ * PointNetfeat) in EXACT fp32 on the matrix cores (v_mfma_f32_32x32x2_f32: a k-ordered fp32 fma chain; no bf16
+ * operand split).  w = [cout][cin] (the Conv1d weight with its unit kernel axis dropped), bias may be NULL.
+ * fwd: y[b][co][l]; bn_partials (optional) = [pcuda_conv1d_k1_fwd_tiles(b, l)][cout][2] per-tile (sum, sum of squares)
+ * of y for the BatchNorm1d that follows (pcuda_bn_finalize reduces them in a fixed order).
+ * dgrad: dx[b][ci][l] = sum_co w[co][ci] dy[b][co][l].
+ * wgrad: dw[co][ci] (+)= sum_{b,l} dy x, db[co] (+)= sum_{b,l} dy (db may be NULL); split-K slabs in the caller's
+ * workspace, summed in a fixed order (deterministic). */
+int pcuda_conv1d_k1_fwd_tiles(int b, int l);
+int pcuda_conv1d_k1_fwd(const float* x, const float* w, const float* bias, float* y, int b, int cin, int cout, int l,
+                        float* bn_partials, pcuda_stream_t s);
+int pcuda_conv1d_k1_dgrad(const float* dy, const float* w, float* dx, int b, int cin, int cout, int l, pcuda_stream_t s);
+size_t pcuda_conv1d_k1_wgrad_workspace_size(int b, int cin, int cout, int l);
+int pcuda_conv1d_k1_wgrad(const float* x, const float* dy, float* dw, float* db, int b, int cin, int cout, int l,
+                          int accumulate, void* workspace, size_t workspace_bytes, pcuda_stream_t s);
 /* max over the last axis of x[b][c][l] with argmax (PointNetCls.py:44,162) */
 int pcuda_max_points_fwd(const float* x, int b, int c, int l, float* y, int* idx, pcuda_stream_t s);
 int pcuda_max_points_bwd(const float* dy, const int* idx, int b, int c, int l, float* dx, pcuda_stream_t s);

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("PCUDA_LIB") or os.path.join(_HERE, "lib", "libpcuda_h
 
 PREC_BF16X3, PREC_BF16 = 0, 1
 ACT_SIGMOID, ACT_SOFTMAX = 0, 1
-FAM_CONV_FWD, FAM_CONV_WGRAD, FAM_POINTWISE = 0, 1, 2
+FAM_CONV_FWD, FAM_CONV_WGRAD, FAM_POINTWISE, FAM_DENSE_F32 = 0, 1, 2, 3
 
 c_f32p = C.c_void_p      # all device pointers travel as integers
 i32, i64, f32, vp, sz = C.c_int, C.c_longlong, C.c_float, C.c_void_p, C.c_size_t
@@ -107,6 +107,11 @@ _PROTOS = {
     "pcuda_linear_bwd_x": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "pcuda_linear_bwd_w_workspace_size": (sz, [i32, i32, i32]),
     "pcuda_linear_bwd_w": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
+    "pcuda_conv1d_k1_fwd_tiles": (i32, [i32, i32]),
+    "pcuda_conv1d_k1_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "pcuda_conv1d_k1_dgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "pcuda_conv1d_k1_wgrad_workspace_size": (sz, [i32, i32, i32, i32]),
+    "pcuda_conv1d_k1_wgrad": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
     "pcuda_max_points_fwd": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "pcuda_max_points_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "pcuda_bmm": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),

@@ -742,6 +742,47 @@ def linear_bwd_w(dy, x, dw, db, accumulate=True):
                                  1 if accumulate else 0, _ptr(ws), nb, _stream()), "linear_bwd_w")
 
 
+def conv1d_fwd(x, w, b, want_stats=False):
+    """torch.nn.Conv1d(cin, cout, 1) on [B,cin,L] in exact fp32 (MFMA f32): -> (y [B,cout,L], bn partials|None, ntiles)"""
+    _req(x); _req(w)
+    if not (x.is_contiguous() and w.is_contiguous()):
+        raise ValueError("conv1d_fwd needs contiguous tensors")
+    bsz, cin, l = x.shape
+    cout = w.shape[0]
+    lib = L.lib()
+    y = torch.empty((bsz, cout, l), dtype=torch.float32, device=x.device)
+    part, nt = None, 0
+    if want_stats:
+        nt = lib.pcuda_conv1d_k1_fwd_tiles(bsz, l)
+        part = torch.empty((nt, cout, 2), dtype=torch.float32, device=x.device)
+    check(lib.pcuda_conv1d_k1_fwd(x.data_ptr(), w.data_ptr(), _ptr(b), y.data_ptr(), bsz, cin, cout, l, _ptr(part),
+                                  _stream()), "conv1d_k1_fwd")
+    return y, part, nt
+
+
+def conv1d_dgrad(dy, w):
+    _req(dy); _req(w)
+    dy = dy.contiguous()
+    bsz, cout, l = dy.shape
+    cin = w.shape[1]
+    dx = torch.empty((bsz, cin, l), dtype=torch.float32, device=dy.device)
+    check(L.lib().pcuda_conv1d_k1_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), bsz, cin, cout, l, _stream()),
+          "conv1d_k1_dgrad")
+    return dx
+
+
+def conv1d_wgrad(x, dy, dw, db, accumulate=True):
+    _req(x); _req(dy)
+    dy = dy.contiguous()
+    bsz, cin, l = x.shape
+    cout = dy.shape[1]
+    lib = L.lib()
+    nb = lib.pcuda_conv1d_k1_wgrad_workspace_size(bsz, cin, cout, l)
+    ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    check(lib.pcuda_conv1d_k1_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(db), bsz, cin, cout, l,
+                                    1 if accumulate else 0, ws.data_ptr(), nb, _stream()), "conv1d_k1_wgrad")
+
+
 def max_points_fwd(x):
     _req(x)
     b, c, l = x.shape

@@ -1,8 +1,8 @@
 """HIP-backed drop-in for the reference's ``src/networks/PointNetCls.py`` (the d4 discriminator).
 
 Same classes / constructor arguments / parameter names (PointNetCls.py:11-224).  The k=1 Conv1d
-layers run on the MFMA convolution kernels (a [B,C,L] tensor is an NCHW image with H = 1), with
-the BatchNorm1d partial statistics taken from the convolution epilogue; Linear layers, the
+layers run in EXACT fp32 on the matrix cores (csrc/conv1d_f32.hip: v_mfma_f32_32x32x2_f32, forward, data and weight
+gradient), with the BatchNorm1d partial statistics taken from the forward kernel's epilogue; Linear layers, the
 3x3 / 64x64 transforms and the max over points use the small dense kernels.  The whole classifier
 is one autograd node with a recorded tape of backward steps; parameter gradients are accumulated
 into ``param.grad`` directly.
@@ -18,7 +18,6 @@ import torch
 from torch import nn
 
 from .. import kernels as K
-from ..kernels import ConvOp
 from ._holders import BatchNorm1d, Conv1d, InstanceNorm1d, Linear, Marker, ensure_grad
 
 
@@ -64,21 +63,19 @@ class _Tape:
             raise NotImplementedError("PointNet Conv1d kernel_size must be 1")
         bsz, cin, l = x.t.shape
         cout = w.shape[0]
-        op = self.m._conv_op(conv, cin, cout)
-        w4 = w.view(cout, cin, 1, 1)
-        a4, part, nt = op.forward(x.t.view(bsz, cin, 1, l), w4, b, 1.0, 1, l, want_stats=self.training)
-        a = _Var(a4.view(bsz, cout, l))
+        w2 = w.view(cout, cin)
+        a_t, part, nt = K.conv1d_fwd(x.t, w2, b, want_stats=self.training)
+        a = _Var(a_t)
         self._rec(conv, a.t)
         y = self._bn(a, bn, relu, part, nt)
 
         def bwd():
             if a.g is None:
                 return
-            dz = a.g.view(bsz, cout, 1, l)
+            dz = a.g.contiguous()
             if self.G(conv + ".weight") is not None:
-                op.wgrad(x.t.view(bsz, cin, 1, l), dz, self.G(conv + ".weight").view(cout, cin, 1, 1),
-                         self.G(conv + ".bias"), 1, l)
-            x.acc(op.dgrad(dz, w4, 1, l).view(bsz, cin, l))
+                K.conv1d_wgrad(x.t, dz, self.G(conv + ".weight").view(cout, cin), self.G(conv + ".bias"))
+            x.acc(K.conv1d_dgrad(dz, w2))
         # the BN backward was recorded after this closure's position would be wrong: insert before it
         self.steps.insert(len(self.steps) - 1, bwd)
         return y
@@ -312,14 +309,7 @@ class PointNetCls(nn.Module):
         self.in2 = InstanceNorm1d(256, track_running_stats=True)
         self.relu = Marker("ReLU")
         # heinit / cvinit only touch nn.Conv2d modules in the reference (PointNetCls.py:187-202): none exist here
-        self._ops, self._eyes = {}, {}
-
-    def _conv_op(self, name, cin, cout):
-        op = self._ops.get(name)
-        if op is None:
-            op = self._ops[name] = ConvOp(cin, cout, 1)
-            op.owner = self
-        return op
+        self._eyes = {}
 
     def _identity(self, k, device):
         key = (k, str(device))

@@ -32,7 +32,13 @@ def _unlrelu(a, slope):
     return a if slope == 1.0 else torch.where(a > 0, a, a / slope)
 
 
-def _anchor_from(table, used):
+PRE_TOL = 2e-4      # layer-local forward bound (below)
+
+
+def _anchor_from(table, used, worst=None):
+    """With every upstream output anchored, the difference between the restatement's output of a layer and the HIP
+    kernels' BEFORE it is anchored is that layer's own arithmetic error (bf16x3 products, fp32 accumulation order):
+    held to 2e-4 of the tensor's scale; ``worst`` collects the largest one per network for the test's report."""
     def fn(tag, z):
         if tag not in table:
             return z
@@ -43,7 +49,10 @@ def _anchor_from(table, used):
             tgt = torch.where(y > 0, y, torch.clamp(z.detach(), max=0.0))
         else:
             tgt = v.reshape(z.shape)
-        assert rel_err(z, tgt) < 2e-3, (tag, rel_err(z, tgt))      # the two forward passes agree before anchoring
+        e = rel_err(z, tgt)
+        if worst is not None and e > worst.get("e", 0.0):
+            worst["e"], worst["tag"] = e, tag
+        assert e < PRE_TOL, (tag, e)      # the two forward passes agree, layer by layer, before anchoring
         return z + (tgt - z).detach()
     return fn
 
@@ -114,8 +123,8 @@ def test_segmenter_backward_shared_routing(dev, cfg_kw, softmax, b, hw, seed):
 
     p2 = {k: (v.clone().requires_grad_(True) if ON.is_trainable(k) else v.clone()) for k, v in params.items()}
     xo = torch.from_numpy(img).requires_grad_(True)
-    used = set()
-    with ON.anchored(_anchor_from(table, used)):
+    used, pre = set(), {}
+    with ON.anchored(_anchor_from(table, used, pre)):
         lo2, ve2 = ON.seg_forward(p2, xo, cfg, training=True)
     assert used == set(table), set(table) - used
     m2, j2 = (OL.seg_loss_softmax if softmax else OL.seg_loss_sigmoid)(lo2, torch.from_numpy(mask))
@@ -125,7 +134,8 @@ def test_segmenter_backward_shared_routing(dev, cfg_kw, softmax, b, hw, seed):
     worst = _compare_grads(model.named_parameters(), ref)
     e_dx = rel_err(x.grad, xo.grad)
     assert e_dx < TOL, e_dx
-    print("worst parameter gradient error %s %.2e, dx %.2e" % (worst[0], worst[1], e_dx))
+    print("worst parameter gradient error %s %.2e, dx %.2e; worst layer-local forward error %s %.2e"
+          % (worst[0], worst[1], e_dx, pre.get("tag"), pre.get("e", 0.0)))
 
 
 @pytest.mark.parametrize("inch,ext,hw,seed", [(4, False, 64, 1200), (5, True, 128, 1210), (4, False, 256, 1220)])
@@ -149,15 +159,16 @@ def test_discriminator_backward_shared_routing(dev, inch, ext, hw, seed):
     table = {n: _unlrelu(acts[i + 1], 0.2 if i < len(names) - 1 else 1.0) for i, n in enumerate(names)}
     p2 = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     xo = torch.from_numpy(xn).requires_grad_(True)
-    used = set()
-    with ON.anchored(_anchor_from(table, used)):
+    used, pre = set(), {}
+    with ON.anchored(_anchor_from(table, used, pre)):
         d2 = ON.disc_forward(p2, xo, ext)
     assert used == set(table)
     OL.bce_logits_const(d2, 1.0).backward()
     worst = _compare_grads(model.named_parameters(), {k: v.grad for k, v in p2.items()})
     e_dx = rel_err(x.grad, xo.grad)
     assert e_dx < TOL, e_dx
-    print("worst parameter gradient error %s %.2e, dx %.2e" % (worst[0], worst[1], e_dx))
+    print("worst parameter gradient error %s %.2e, dx %.2e; worst layer-local forward error %s %.2e"
+          % (worst[0], worst[1], e_dx, pre.get("tag"), pre.get("e", 0.0)))
 
 
 @pytest.mark.parametrize("ft,ext,b,seed", [(False, False, 16, 1300), (True, True, 12, 1310), (False, False, 4, 1320)])
@@ -183,8 +194,8 @@ def test_pointnet_cls_backward_shared_routing(dev, ft, ext, b, seed):
             table[k] = table[k].detach().float().cpu()
     p2 = {k: (v.clone().requires_grad_(True) if ON.is_trainable(k) else v.clone()) for k, v in params.items()}
     xo = torch.from_numpy(xn).requires_grad_(True)
-    used = set()
-    with ON.anchored(_anchor_from(table, used)):
+    used, pre = set(), {}
+    with ON.anchored(_anchor_from(table, used, pre)):
         y2, _, _ = ON.pointnet_cls_forward(p2, xo, feature_transform=ft, ext=ext, drop=0.0, training=True)
     assert used == set(table), set(table) - used
     OL.bce_logits_const(y2, 0.0).backward()
@@ -192,4 +203,5 @@ def test_pointnet_cls_backward_shared_routing(dev, ft, ext, b, seed):
     worst = _compare_grads(model.named_parameters(), ref)
     e_dx = rel_err(x.grad, xo.grad)
     assert e_dx < TOL, e_dx
-    print("worst parameter gradient error %s %.2e, dx %.2e" % (worst[0], worst[1], e_dx))
+    print("worst parameter gradient error %s %.2e, dx %.2e; worst layer-local forward error %s %.2e"
+          % (worst[0], worst[1], e_dx, pre.get("tag"), pre.get("e", 0.0)))

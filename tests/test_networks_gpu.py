@@ -162,20 +162,20 @@ def test_pointnet_cls_vs_reference_golden(dev, tag, ft, ext):
     y, trans, trans_feat = model(x)
     loss = L.bce_logits_const(y, 0.0)
     loss.backward()
-    # BatchNorm1d over a batch of 12-16 right after a max over 300 points (argmax routing) amplifies rounding.  The
-    # golden file carries the reference's OWN spread under 2^-17 relative noise on every Conv1d / Linear output
-    # (oracle/make_golden.py): outputs are held to max(1e-3, that spread) -- 1e-3 wherever the reference itself is
-    # reproducible to 1e-3 (trans; y of the plain network is at 1.6e-3, of the feature-transform one at 5.6e-3) --, the
-    # loss to max(1e-4, spread), the input gradient and the per-parameter gradients to max(2e-2, 3 x spread).
+    # Outputs at the north-star bar, flat: 1e-3 of the tensor's scale.  (Rounds 1-2 ran the k=1 Conv1d layers on the
+    # bf16x3 image convolution; BatchNorm1d over 12-16 clouds right behind a max over 300 points turned its 2^-17 noise
+    # into 0.5-2.4e-3 of y, and the test had to fall back on the reference's own spread.  They now run in exact fp32
+    # on the matrix cores, csrc/conv1d_f32.hip.)  The input gradient and the per-parameter gradients go through ReLU /
+    # argmax routing and keep max(2e-2, 3 x the reference's own spread); test_backward_exact_gpu.py holds them to 1e-4
+    # with the routing shared.
     sp = lambda k: float(g["spread/" + k])
-    assert rel_err(y, g["y"]) < max(1e-3, sp("y")), (rel_err(y, g["y"]), sp("y"))
-    assert rel_err(trans, g["trans"]) < max(1e-3, sp("trans"))
-    assert abs(float(loss.detach()) - float(g["loss"])) < max(1e-4, sp("loss"))
+    e_y, e_t, e_l = rel_err(y, g["y"]), rel_err(trans, g["trans"]), abs(float(loss.detach()) - float(g["loss"]))
+    e_tf = rel_err(_strided(trans_feat), g["trans_feat_s"]) if ft else 0.0
+    print("%s: y %.2e trans %.2e trans_feat %.2e loss %.2e (reference's own spread under 2^-17 noise: y %.2e)"
+          % (tag, e_y, e_t, e_tf, e_l, sp("y")))
+    assert e_y < 1e-3 and e_t < 1e-3 and e_tf < 1e-3 and e_l < 1e-4, (e_y, e_t, e_tf, e_l)
     assert rel_err(x.grad, g["dx"]) < max(2e-2, 3 * sp("dx")), (rel_err(x.grad, g["dx"]), sp("dx"))
-    if ft:
-        assert rel_err(_strided(trans_feat), g["trans_feat_s"]) < max(1e-3, sp("trans_feat"))
-    else:
-        assert trans_feat is None
+    assert (trans_feat is not None) == ft
     _check_grads(model, g, 1e-1, 3.5e-1)
     sd = model.state_dict()
     for k in params:

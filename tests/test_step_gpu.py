@@ -53,11 +53,12 @@ def _sample(t, n=256):
     return f[::step][:n].double().cpu().numpy()
 
 
-# Loss scalars, per key.  1e-3 (the north-star figure) for everything that does not pass through the point-cloud
-# discriminator; d4 normalises over the batch of 4-8 point clouds with BatchNorm1d right behind a max over 300 points,
-# which turns 1e-6 input differences into percents (test_pointnet_cls_vs_reference_golden), so the three d4-derived
-# scalars (and d4's share of the summed adversarial loss) keep a 2e-2 bound.
-TIGHT, LOOSE = 1e-3, 2e-2
+# Loss scalars, per key: 1e-3, the north-star figure, for every one of them on the first step -- the d4-derived ones
+# included since the point-cloud discriminator's k=1 convolutions run in exact fp32 (csrc/conv1d_f32.hip; on the bf16x3
+# image convolution BatchNorm1d over 4-8 clouds behind a max over 300 points had turned 2^-17 noise into percents and
+# these three scalars sat behind a 2e-2 bound).  LOOSE is what remains for the SECOND step, which starts from
+# Adam-updated parameters (sign-sensitive for near-zero gradients).
+TIGHT, LOOSE = 1e-3, 1e-3
 
 
 def _check_losses(h, g, pre, cfg, it):
