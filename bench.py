@@ -45,6 +45,13 @@ WORKLOADS = {
                            " ext), train_mmwhs.py loop",
                       batch=16, d1=True, d2=True, d4=True, gflop_per_pair=286.0, variant="mmwhs", in_channels=3,
                       n_class=5, pn=dict(feature_transform=True, ext=True)),
+    # BASELINE.json configs[4] names a 512x512 input on a DeepLab-v3+ backbone; the reference holds no such model (SURVEY
+    # section 0).  STAND-IN, labelled as such: the reference's own segmenter at that input size (fc_inch=729:
+    # unet.py:169-178) with the three discriminators, per rank 8 of the global batch of 64.  Work per pair: 4x the
+    # 256x256 figure for everything except the 6x6 valid head convolution (27x27 instead of 11x11 outputs).
+    "uda_512": dict(desc="STAND-IN for config 5 (no DeepLab in the reference): UNet(PointNet head, fc_inch=729) + d1 + d2 + d4, "
+                         "512x512x1, 4 classes",
+                    batch=8, d1=True, d2=True, d4=True, gflop_per_pair=1166.0, hw=512, fc_inch=729),
 }
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
@@ -85,7 +92,8 @@ def build_trainer(wl, dev, seed, group=None):
     torch.manual_seed(seed)                       # train_mscmrseg.py:668-670 seeds torch + numpy with 0
     np.random.seed(seed)
     nc, cin, variant = wl.get("n_class", 4), wl.get("in_channels", 1), wl.get("variant", "mscmrseg")
-    gen = Segmentation_model_Point(filters=32, in_channels=cin, n_class=nc, pointnet=wl["d4"], fc_inch=121).to(dev)
+    gen = Segmentation_model_Point(filters=32, in_channels=cin, n_class=nc, pointnet=wl["d4"],
+                                   fc_inch=wl.get("fc_inch", 121)).to(dev)
     d1 = UncertaintyDiscriminator(in_channel=nc).to(dev) if wl["d1"] else None
     d2 = UncertaintyDiscriminator(in_channel=nc).to(dev) if wl["d2"] else None
     d4 = PointNetCls(**wl.get("pn", {})).to(dev) if wl["d4"] else None          # dropout p = 0.3 as in the reference
@@ -108,7 +116,8 @@ def cpu_baseline(wl, budget_s=20.0, batches=(2, 16)):
     torch.set_num_threads(cores)
     nc, cin, variant = wl.get("n_class", 4), wl.get("in_channels", 1), wl.get("variant", "mscmrseg")
     pn = wl.get("pn", {})
-    cfg = ON.SegCfg(filters=32, in_channels=cin, n_class=nc, pointnet=wl["d4"], fc_inch=121)
+    hw = wl.get("hw", 256)
+    cfg = ON.SegCfg(filters=32, in_channels=cin, n_class=nc, pointnet=wl["d4"], fc_inch=wl.get("fc_inch", 121))
     scfg = StepCfg(variant=variant, d1=wl["d1"], d2=wl["d2"], d4=wl["d4"], n_class=nc,
                    d_momentum=0.95 if variant == "mmwhs" else 0.99,
                    pn_feature_transform=pn.get("feature_transform", False), pn_ext=pn.get("ext", False))
@@ -122,7 +131,7 @@ def cpu_baseline(wl, budget_s=20.0, batches=(2, 16)):
 
     orc = fresh()
     b = batches[0]
-    batch = synth_batch(b, cin, nc, 256, seed=5, gaussian=variant == "mmwhs")
+    batch = synth_batch(b, cin, nc, hw, seed=5, gaussian=variant == "mmwhs")
     t0 = time.perf_counter()
     orc.step(*batch)                                           # warm-up (also the fallback sample)
     warm = time.perf_counter() - t0
@@ -143,7 +152,7 @@ def cpu_baseline(wl, budget_s=20.0, batches=(2, 16)):
             res["batch%d" % b2] = {"value": None, "skipped": "predicted %.0f s for one step on this host" % est}
             continue
         orc2 = fresh()
-        batch2 = synth_batch(b2, cin, nc, 256, seed=5, gaussian=variant == "mmwhs")
+        batch2 = synth_batch(b2, cin, nc, hw, seed=5, gaussian=variant == "mmwhs")
         t0 = time.perf_counter()
         orc2.step(*batch2)
         d2 = time.perf_counter() - t0
@@ -159,16 +168,24 @@ def pmc_traffic_per_launch():
     MI355X_MICROARCH.md, HBM section -- exact for the float4 staging loads, uncalibrated for the dword path)."""
     import csv
     import glob
+    from pointcloududa_amd._lib import csrc_hash
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.csv")))
     if not files:
-        return None, None
+        return None, "no profiles/r*_pmc_traffic.csv"
+    lines = open(files[-1]).read().split("\n")
+    # first line: "# csrc_sha256=<hash>" of the kernel sources the counters were collected on (scripts/gpu_pmc_step.sh)
+    have = lines[0].split("=", 1)[1].strip() if lines and lines[0].startswith("# csrc_sha256=") else None
+    if have != csrc_hash():
+        return None, ("%s was collected on kernel sources %s, this tree is %s: not quoted (re-run scripts/gpu_pmc_step.sh)"
+                      % (os.path.basename(files[-1]), have, csrc_hash()))
     n = fetch = write = 0.0
-    for r in csv.DictReader(open(files[-1])):
+    for r in csv.DictReader([l for l in lines if l and not l.startswith("#")]):
         if r["kernel"].startswith(("igemm_pipe_kernel", "igemm8_kernel", "igemm_kernel")):
             n += float(r["launches"]); fetch += float(r["FETCH_SIZE_KB_sum_raw"]); write += float(r["WRITE_SIZE_KB_sum"])
     if n == 0:
-        return None, None
-    return int((2.0 * fetch + write) * 1024.0 / n), "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE)" % os.path.basename(files[-1])
+        return None, "no forward / dgrad launches in " + os.path.basename(files[-1])
+    return int((2.0 * fetch + write) * 1024.0 / n), "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE; same kernel sources: %s)" % (
+        os.path.basename(files[-1]), have)
 
 
 def spawn_ranks(n, argv):
@@ -189,32 +206,54 @@ def spawn_ranks(n, argv):
                    PCUDA_BENCH_CHILD="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    last = None
-    for line in procs[0].stdout:
-        line = line.decode("utf-8", "replace").rstrip("\n")
-        if line.startswith("{") and '"metric"' in line:
-            last = line
-        else:
-            print(line, file=sys.stderr)
+    # rank 0's stdout is read on a thread; the parent polls EVERY child: the first one that exits non-zero ends the
+    # run at once (the others would sit in an RCCL collective until its watchdog fires) -- the children we started are
+    # terminated by their exact PIDs, nothing is re-executed.
+    import threading
+    box = {"last": None}
+
+    def relay():
+        for line in procs[0].stdout:
+            line = line.decode("utf-8", "replace").rstrip("\n")
+            if line.startswith("{") and '"metric"' in line:
+                box["last"] = line
+            else:
+                print(line, file=sys.stderr)
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
     rc = 0
-    for pr in procs:
-        code = pr.wait()
-        if code != 0 and rc == 0:
-            rc = code
-    if rc == 0 and last is None:
-        rc = 1
-    if rc != 0:       # a failed rank leaves the others in a collective: end them (exact PIDs, nothing by pattern)
+    while True:
+        codes = [pr.poll() for pr in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            rc = bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.2)
+    if rc != 0:
         for pr in procs:
             if pr.poll() is None:
+                pr.terminate()
+        t_end = time.time() + 10.0
+        for pr in procs:
+            try:
+                pr.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
                 pr.kill()
         raise SystemExit(rc if rc > 0 else 1)
-    print(last, flush=True)
+    th.join(timeout=10.0)
+    if box["last"] is None:
+        raise SystemExit(1)
+    print(box["last"], flush=True)
 
 
 def dry_run(args, world, rank):
     """``--dry-run``: the launcher and the collective plumbing without a GPU (CPU tests): a gloo group of the spawned
     ranks, the same barrier + max-over-ranks timing, a surrogate step (an all-reduced vector), ONE JSON line."""
     import torch.distributed as dist
+    if os.environ.get("PCUDA_DRYRUN_FAIL_RANK") == str(rank):      # (tests: a rank that dies during start-up)
+        raise SystemExit(3)
     if world > 1:
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     g = torch.full((1024,), float(rank + 1))
@@ -283,7 +322,7 @@ def main():
     wl = WORKLOADS[args.workload]
     b = args.batch or wl["batch"]
     tr = build_trainer(wl, dev, seed=0, group=None)     # (the trainer broadcasts rank 0's parameters and buffers)
-    batch = synth_device_batch(b, 256, wl.get("n_class", 4), seed=100 + rank, dev=dev, in_channels=wl.get("in_channels", 1),
+    batch = synth_device_batch(b, wl.get("hw", 256), wl.get("n_class", 4), seed=100 + rank, dev=dev, in_channels=wl.get("in_channels", 1),
                                gaussian=wl.get("variant") == "mmwhs")
 
     def sync():
@@ -320,7 +359,7 @@ def main():
         raise SystemExit("non-finite loss in the benchmark step: %r" % host)
 
     result = {
-        "metric": "adversarial train-step images/sec (seg+3 discr) at 256x256",
+        "metric": "adversarial train-step images/sec (seg+3 discr) at %dx%d" % (wl.get("hw", 256), wl.get("hw", 256)),
         "value": round(b * world * args.steps / dt, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "settle": args.settle, "ms_per_step": round(1000.0 * dt / args.steps, 3),
         "higher_is_better": True,
@@ -332,6 +371,10 @@ def main():
                    "parallelism": "dp%d" % world, "ranks_in_group": ranks_in_group,
                    "collective": "RCCL all-reduce of the flat gradient buffers (G: 2 buckets, D: 1 each)" if world > 1 else "none",
                    "algorithmic_gflop_per_pair": wl["gflop_per_pair"],
+                   # the SURVEY 8d convention counts 8 passes per discriminator; with the target forward of d1 / d2
+                   # replayed from the adversarial pass, 7 of them execute for those two networks
+                   "executed_gflop_per_pair": round(wl["gflop_per_pair"] - (2 * 3.60 * (wl.get("hw", 256) / 256.0) ** 2
+                                                    * (int(wl["d1"]) + int(wl["d2"])) / 2.0 if tr.d_reuse else 0.0), 1),
                    "box_to_box": "600-663 img/s measured for this command across MI355X boxes in round 2 (boxes of the pool differ by up to 10 % on one binary)",
                    "streams": "discriminators concurrent" if tr.d_streams else "single",
                    # d1 / d2 see the target batch twice per step with the same weights and the same input values
@@ -359,6 +402,7 @@ def main():
         ms, flops, launches = K.prof_read(0)
         wms, wflops, wl_n = K.prof_read(1)
         pms, pbytes, pl_n = K.prof_read(2)
+        dms, dflops, dl_n = K.prof_read(3)
         K.prof_reset()
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         # the committed PMC passes were taken on the default command (full_uda, batch 32, bf16x3): only that run quotes them
@@ -374,6 +418,9 @@ def main():
             "other": {
                 "wgrad_kernel": {"achieved_tflops": round(wflops / (wms * 1e-3) / 1e12, 2) if wms > 0 else 0.0,
                                  "ms_per_step": round(wms / nprof, 3), "launches_per_step": wl_n // nprof},
+                "conv1d_f32": {"what": "PointNetCls k=1 Conv1d layers, exact fp32 MFMA (peak 157 TFLOP/s)",
+                               "achieved_tflops": round(dflops / (dms * 1e-3) / 1e12, 2) if dms > 0 else 0.0,
+                               "ms_per_step": round(dms / nprof, 3), "launches_per_step": dl_n // nprof},
                 "pointwise": {"achieved_gbps": round(pbytes / (pms * 1e-3) / 1e9, 1) if pms > 0 else 0.0,
                               "ms_per_step": round(pms / nprof, 3), "launches_per_step": pl_n // nprof,
                               "peak_gbps": 8000.0},

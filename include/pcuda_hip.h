@@ -256,6 +256,16 @@ int pcuda_entropy_fwd(const float* logits, int mode, float norm, float* ent, flo
 /* dlogits (+)= d(ent)/dlogits . dent  (+ dprob through p when dprob != NULL) */
 int pcuda_entropy_bwd(const float* logits, int mode, float norm, const float* dent, const float* dprob,
                       float* dlogits, int accumulate, int n, int c, long long hw, pcuda_stream_t s);
+/* the same with the gradient of the map's mean on top: dmean (device scalar, may be NULL) is d/d[mean over n and pixels of
+ * sum_c ent] -- the entropy terms of train_mmwhs.py:225-230 (-etpls) and :243-247 (-Tetpls); every element receives
+ * dmean / (n * hw) in addition to its dent (which may then be NULL) */
+int pcuda_entropy_bwd2(const float* logits, int mode, float norm, const float* dent, const float* dprob, const float* dmean,
+                       float* dlogits, int accumulate, int n, int c, long long hw, pcuda_stream_t s);
+/* out[0] = scale * sum(x[0..numel)), fixed summation order (deterministic): torch.mean(torch.sum(uncertainty_map, dim=1))
+ * of train_mmwhs.py:225,243 with scale = 1 / (n * hw) */
+size_t pcuda_sum_all_workspace_size(void);
+int pcuda_sum_all(const float* x, long long numel, double scale, float* out, void* workspace, size_t workspace_bytes,
+                  pcuda_stream_t s);
 /* segmentation loss: mode SIGMOID: BCE(sigmoid(o), y) + jaccard(sigmoid(o), y)
  *                    mode SOFTMAX: cross_entropy(softmax(o), argmax y) ("double softmax") + jaccard(softmax(o), y)
  * y: one-hot uint8 [n][c][hw].  out[0] = bce|ce, out[1] = jaccard.  workspace from *_workspace_size.

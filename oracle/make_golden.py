@@ -646,9 +646,10 @@ def gold_step(tag, cfg: ON.SegCfg, b, hw, seed, n_steps=2, full=True, d1=True, d
     print(tag, "ok")
 
 
-def ref_step_mmwhs(gen, d1, d2, d4, opt_g, opt1, opt2, opt4, batch, dr, wp, w1, w2, w4):
+def ref_step_mmwhs(gen, d1, d2, d4, opt_g, opt1, opt2, opt4, batch, dr, wp, w1, w2, w4, etpls=False, Tetpls=False,
+                   d4aux=False):
     """One iteration of train_epoch's loop, re-typed from train_mmwhs.py:187-360 around the imported reference
-    modules (-softmax, no -etpls/-Tetpls/-d4aux; CPU tensors instead of .cuda(); host metrics omitted).  Any of the
+    modules (-softmax; -etpls / -Tetpls / -d4aux as keyword flags; CPU tensors instead of .cuda(); host metrics omitted).  Any of the
     discriminators may be None (their flags off); with none at all the adversarial backward is skipped by the
     script's ``if loss_adv_diff != 0`` guard (:271) and phases 3-5 by ``if args.d1 or args.d2 or args.d4`` (:282)."""
     import math
@@ -668,27 +669,35 @@ def ref_step_mmwhs(gen, d1, d2, d4, opt_g, opt1, opt2, opt4, batch, dr, wp, w1, 
     l_seg = F.cross_entropy(pred_s, torch.from_numpy(np.argmax(mask_a, axis=1)).long())
     l_seg2 = ref_loss.jaccard_loss(logits=pred_s, true=torch.from_numpy(mask_a).float(), activation=False)
     l_seg3 = 0
-    if d4 is not None:
+    if d4 is not None or d4aux:
         l_seg3 = ref_loss.batch_NN_loss(x=v_s, y=torch.from_numpy(vert_a).float())
         res["ver_s_loss"] = l_seg3.item()
     c = pred_s.size()[1]
     emap_s = -1.0 * pred_s * torch.log(pred_s + smooth) / math.log(c)
-    res["entropy_s"] = torch.mean(torch.sum(emap_s, dim=1)).item()
-    (l_seg + l_seg2 + wp * l_seg3 + 0).backward()
+    temp_loss = torch.mean(torch.sum(emap_s, dim=1))
+    res["entropy_s"] = temp_loss.item()
+    l_entropy = 0
+    if d2 is not None and etpls:
+        l_entropy = temp_loss
+    (l_seg + l_seg2 + wp * l_seg3 + l_entropy).backward()
     res["seg_loss"] = (l_seg + l_seg2).item()
     res["grad_seg"] = {k: p.grad.clone() for k, p in gen.named_parameters() if p.grad is not None}
     o_t, _, v_t = gen(torch.from_numpy(img_b).float())
     pred_t = F.softmax(o_t, dim=1)
     emap_t = -1.0 * pred_t * torch.log(pred_t + smooth) / math.log(pred_t.size()[1])
-    res["entropy_t"] = torch.mean(torch.sum(emap_t, dim=1)).item()
+    temp_loss = torch.mean(torch.sum(emap_t, dim=1))
+    res["entropy_t"] = temp_loss.item()
     adv = 0
-    if d1 is not None or d2 is not None or d4 is not None:
+    if Tetpls:
+        adv += temp_loss
+    if d1 is not None or d2 is not None or d4 is not None or d4aux:
         a2 = a4 = a1 = 0
         if d2 is not None:
             do = d2(emap_t)
             a2 = dr * F.binary_cross_entropy_with_logits(do, torch.FloatTensor(do.data.size()).fill_(1))
-        if d4 is not None:
+        if d4 is not None or d4aux:
             res["ver_t_loss"] = ref_loss.batch_NN_loss(x=v_t, y=torch.from_numpy(vert_b).float()).item()
+        if d4 is not None:
             do = d4(v_t.transpose(2, 1))[0]
             a4 = dr * F.binary_cross_entropy_with_logits(do, torch.FloatTensor(do.data.size()).fill_(1))
         if d1 is not None:
@@ -733,12 +742,14 @@ def ref_step_mmwhs(gen, d1, d2, d4, opt_g, opt1, opt2, opt4, batch, dr, wp, w1, 
     return res
 
 
-def gold_step_mmwhs(tag, cfg: ON.SegCfg, b, hw, seed, d1=True, d2=True, d4=True):
+def gold_step_mmwhs(tag, cfg: ON.SegCfg, b, hw, seed, d1=True, d2=True, d4=True, etpls=False, Tetpls=False, d4aux=False,
+                    gen_sgd=False):
     """The MM-WHS loop (train_mmwhs.py:187-360, optimisers :453-489) with the repository README's point-cloud
-    discriminator PointNetCls(feature_transform=True, ext=True): one step from identical parameters."""
+    discriminator PointNetCls(feature_transform=True, ext=True): one step from identical parameters.  The optional
+    branches -etpls (:227-230), -Tetpls (:245-247), -d4aux (:220,248,256) and -sgd (:453-459) as keyword flags."""
     scfg = StepCfg(variant="mmwhs", d1=d1, d2=d2, d4=d4, n_class=cfg.n_class, softmax=True, d_momentum=0.95,
-                   pn_feature_transform=True, pn_ext=True)
-    assert cfg.pointnet == d4
+                   pn_feature_transform=True, pn_ext=True, etpls=etpls, Tetpls=Tetpls, d4aux=d4aux, gen_sgd=gen_sgd)
+    assert cfg.pointnet == (d4 or d4aux)
     pg = ON.make_params(ON.seg_param_shapes(cfg), seed)
     p1 = ON.make_params(ON.disc_param_shapes(cfg.n_class), seed + 1, std=0.02) if d1 else None
     p2 = ON.make_params(ON.disc_param_shapes(cfg.n_class), seed + 2, std=0.02) if d2 else None
@@ -747,15 +758,24 @@ def gold_step_mmwhs(tag, cfg: ON.SegCfg, b, hw, seed, d1=True, d2=True, d4=True)
     d1 = load_into(UncertaintyDiscriminator(in_channel=cfg.n_class), p1).train() if d1 else None
     d2 = load_into(UncertaintyDiscriminator(in_channel=cfg.n_class), p2).train() if d2 else None
     d4 = load_into(PointNetCls(feature_transform=True, ext=True, drop=0.0), p4).train() if d4 else None
-    og = torch.optim.Adam(gen.parameters(), lr=scfg.lr, betas=(0.9, 0.99))
+    if gen_sgd:      # train_mmwhs.py:453-459
+        og = torch.optim.SGD(gen.parameters(), lr=scfg.lr, momentum=.95, weight_decay=.0005)
+    else:
+        og = torch.optim.Adam(gen.parameters(), lr=scfg.lr, betas=(0.9, 0.99))
     mk = lambda m, lr: None if m is None else torch.optim.SGD(m.parameters(), lr=lr, momentum=.95, weight_decay=.0005)
     o1, o2, o4 = mk(d1, scfg.d1lr), mk(d2, scfg.d2lr), mk(d4, scfg.d4lr)
     orc = OracleTrainer(cfg, scfg, pg, p1, p2, p4)
     batch = synth_batch(b, cfg.in_channels, cfg.n_class, hw, seed=seed + 100)
-    r = ref_step_mmwhs(gen, d1, d2, d4, og, o1, o2, o4, batch, scfg.dr, scfg.wp, scfg.w1, scfg.w2, scfg.w4)
+    r = ref_step_mmwhs(gen, d1, d2, d4, og, o1, o2, o4, batch, scfg.dr, scfg.wp, scfg.w1, scfg.w2, scfg.w4,
+                       **({"etpls": etpls, "Tetpls": Tetpls, "d4aux": d4aux} if (etpls or Tetpls or d4aux) else {}))
     q = orc.step(*batch, keep=True)
     out = {"seed": np.int64(seed), "b": np.int64(b), "hw": np.int64(hw)}
-    keys = ["seg_loss", "adv_loss"] + (["ver_s_loss", "ver_t_loss", "d4_loss_src", "d4_loss_tgt"] if d4 is not None else [])
+    keys = ["seg_loss", "adv_loss"] + (["ver_s_loss", "ver_t_loss"] if (d4 is not None or d4aux) else [])
+    keys += ["d4_loss_src", "d4_loss_tgt"] if d4 is not None else []
+    if etpls or Tetpls or d4aux or gen_sgd:      # (the earlier fixtures keep their key set: they regenerate bit for bit)
+        close(torch.tensor(q["entropy_loss"]), torch.tensor(r["entropy_s"]), 2e-5, tag + " entropy_loss")
+        close(torch.tensor(q["entropy_loss_T"]), torch.tensor(r["entropy_t"]), 2e-5, tag + " entropy_loss_T")
+        out["entropy_loss"], out["entropy_loss_T"] = np.float64(r["entropy_s"]), np.float64(r["entropy_t"])
     keys += (["d2_loss_src", "d2_loss_tgt"] if d2 is not None else []) + (["d1_loss_src", "d1_loss_tgt"] if d1 is not None else [])
     keys += [k for k in ("adv1", "adv2", "adv4") if k in r]
     for k in keys:
@@ -779,9 +799,32 @@ def gold_step_mmwhs(tag, cfg: ON.SegCfg, b, hw, seed, d1=True, d2=True, d4=True)
     post_step_samples(out, "", (("gen", gen), ("d1", d1), ("d2", d2), ("d4", d4)),
                       {"gen": r["grad_total"], "d1": r.get("grad_d1", {}), "d2": r.get("grad_d2", {}),
                        "d4": r.get("grad_d4", {})}, {"d1": o1, "d2": o2, "d4": o4})
+    if gen_sgd:      # the segmenter's momentum buffers (first step: buf = g + wd * p), strided samples
+        for i, (k, p_) in enumerate(gen.named_parameters()):
+            st = og.state.get(p_, {})
+            if st.get("momentum_buffer") is not None:
+                out["mb/gen/" + k] = sample(st["momentum_buffer"], 256)
     np.savez_compressed(os.path.join(GOLD, tag + ".npz"), **out)
     print(tag, "ok", {k: round(float(out[k]), 5) for k in ("seg_loss", "adv_loss")})
 
+
+
+def gold_seg_full512():
+    """BASELINE config 5 names a 512x512 input on a DeepLab-v3+ backbone that does not exist in the reference (SURVEY
+    section 0).  Stand-in, labelled as such: the reference's own segmenter at that input size --
+    Segmentation_model_Point(fc_inch=729): 512 / 16 = 32, the 6x6 valid head convolution leaves 27 x 27 = 729 per
+    channel (unet.py:169-178,85-86) -- forward + backward under the supervised loss."""
+    gold_seg("seg_full512", ON.SegCfg(filters=32, in_channels=1, n_class=4, pointnet=True, fc_inch=729), b=2, hw=512,
+             seed=510, full_tensors=False)
+
+
+def gold_mmwhs_flags():
+    """The optional branches of the MM-WHS loop, two fixtures: (a) -d1 -d2 -d4 -etpls -Tetpls (both entropy terms in the
+    losses), (b) -d2 -d4aux -sgd (point head trained without d4; SGD on the segmenter)."""
+    gold_step_mmwhs("step_mmwhs_etpls_small", ON.SegCfg(filters=4, in_channels=3, n_class=5, pointnet=True, fc_inch=9), b=8,
+                    hw=128, seed=1000, etpls=True, Tetpls=True)
+    gold_step_mmwhs("step_mmwhs_d4aux_sgd_small", ON.SegCfg(filters=4, in_channels=3, n_class=5, pointnet=True, fc_inch=9),
+                    b=4, hw=128, seed=1050, d1=False, d2=True, d4=False, d4aux=True, gen_sgd=True)
 
 
 def gold_valid(tag, cfg: ON.SegCfg, b, hw, seed):
@@ -843,16 +886,24 @@ def main():
               seed=900, n_steps=2, full=True, d1=False, d2=True, d4=False)
     gold_step_mmwhs("step_segonly_small", ON.SegCfg(filters=4, in_channels=3, n_class=5, pointnet=False), b=4, hw=128,
                     seed=950, d1=False, d2=False, d4=False)
+    gold_mmwhs_flags()
     if os.environ.get("GOLDEN_FULL", "1") == "1":
         full = ON.SegCfg(filters=32, in_channels=1, n_class=4, pointnet=True, fc_inch=121)
         gold_seg("seg_full256", full, b=2, hw=256, seed=500, full_tensors=False)
         gold_step("step_full256", full, b=4, hw=256, seed=600, n_steps=1, full=False)
+        gold_seg_full512()
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "pncls":    # only the PointNetCls fixtures
         gold_pncls("pncls", False, False, b=16, seed=300)
         gold_pncls("pncls_ft_ext", True, True, b=12, seed=310)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "full512":
+        gold_seg_full512()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "flags":    # only the MM-WHS optional-branch fixtures
+        gold_mmwhs_flags()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "seg":      # only the segmenter fixtures
         _full = ON.SegCfg(filters=32, in_channels=1, n_class=4, pointnet=True, fc_inch=121)

@@ -50,6 +50,7 @@ class StepCfg:
     etpls: bool = False
     Tetpls: bool = False
     d4aux: bool = False
+    gen_sgd: bool = False            # -sgd: SGD(momentum .95, weight decay 5e-4) for the segmenter (train_mmwhs.py:453-459)
     disc_ext: bool = False           # UncertaintyDiscriminator(ext=...)
     pn_feature_transform: bool = False
     pn_ext: bool = False
@@ -86,7 +87,10 @@ class OracleTrainer:
         self.dis1 = _leafify(dis1) if (cfg.d1 and dis1 is not None) else None
         self.dis2 = _leafify(dis2) if (cfg.d2 and dis2 is not None) else None
         self.dis4 = _leafify(dis4) if (cfg.d4 and dis4 is not None) else None
-        self.opt_gen = torch.optim.Adam(_trainables(self.gen), lr=cfg.lr, betas=(0.9, 0.99))
+        if cfg.gen_sgd and cfg.variant == "mmwhs":
+            self.opt_gen = torch.optim.SGD(_trainables(self.gen), lr=cfg.lr, momentum=.95, weight_decay=.0005)
+        else:
+            self.opt_gen = torch.optim.Adam(_trainables(self.gen), lr=cfg.lr, betas=(0.9, 0.99))
         mk = lambda p, lr: torch.optim.SGD(_trainables(p), lr=lr, momentum=cfg.d_momentum,
                                            weight_decay=0.0005)
         self.opt_d1 = mk(self.dis1, cfg.d1lr) if self.dis1 is not None else None
@@ -226,6 +230,11 @@ class OracleTrainer:
 
         if c.d1 or c.d2 or c.d4:
             d_phase("src", 1.0, emap_s, in1_s, vert_s)
+            if keep:      # (the two passes' gradients largely cancel at initialisation: tests scale errors by the parts)
+                for nm, p in (("grad_d1_src", self.dis1), ("grad_d2_src", self.dis2), ("grad_d4_src", self.dis4)):
+                    if p is not None:
+                        self.kept[nm] = {k: v.grad.clone() for k, v in p.items()
+                                         if is_trainable(k) and v.grad is not None}
             d_phase("tgt", 0.0, emap_t, in1_t, vert_t)
             if keep:
                 for nm, p in (("grad_d1", self.dis1), ("grad_d2", self.dis2), ("grad_d4", self.dis4)):

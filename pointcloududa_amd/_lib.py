@@ -89,6 +89,9 @@ _PROTOS = {
     "pcuda_mul": (i32, [vp, vp, vp, i64, vp]),
     "pcuda_entropy_fwd": (i32, [vp, i32, f32, vp, vp, i32, i32, i64, vp]),
     "pcuda_entropy_bwd": (i32, [vp, i32, f32, vp, vp, vp, i32, i32, i32, i64, vp]),
+    "pcuda_entropy_bwd2": (i32, [vp, i32, f32, vp, vp, vp, vp, i32, i32, i32, i64, vp]),
+    "pcuda_sum_all_workspace_size": (sz, []),
+    "pcuda_sum_all": (i32, [vp, i64, C.c_double, vp, vp, sz, vp]),
     "pcuda_seg_loss_workspace_size": (sz, [i32, i32, i64]),
     "pcuda_seg_loss_fwd": (i32, [vp, vp, i32, i32, i32, i64, vp, vp, sz, vp]),
     "pcuda_seg_loss_bwd": (i32, [vp, vp, i32, i32, i32, i64, vp, vp, vp, vp, vp]),
@@ -143,6 +146,23 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = handle
     return _lib
+
+
+def csrc_hash() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, *.h, Makefile and include/pcuda_hip.h; names and bytes, sorted): what a
+    committed profile records next to its numbers, so that a figure measured on another build is never quoted as this
+    build's (bench.py refuses a traffic summary whose hash differs from the running tree's)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) +
+                   [os.path.join(csrc, "Makefile"), os.path.join(os.path.dirname(_HERE), "include", "pcuda_hip.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def check(rc: int, what: str = ""):

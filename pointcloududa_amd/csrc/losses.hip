@@ -46,7 +46,12 @@ __global__ __launch_bounds__(256) void entropy_fwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void entropy_bwd_kernel(const float* __restrict__ logits, int mode, float norm,
                                                           const float* __restrict__ dent,
                                                           const float* __restrict__ dprob, float* __restrict__ dlogits,
-                                                          int accumulate, int c, long long hw, long long npix) {
+                                                          int accumulate, int c, long long hw, long long npix,
+                                                          const float* __restrict__ dmean, float mscale) {
+  // dmean: gradient of mean_{n,pixels} sum_c ent (train_mmwhs.py:225,243), a device scalar: every element of the map
+  // receives dmean * mscale (mscale = 1 / (n * hw)) on top of its own dent
+  const float dm = dmean ? dmean[0] * mscale : 0.f;
+  const bool has_e = dent != nullptr || dmean != nullptr;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < npix; i += 256ll * gridDim.x) {
     const long long n = i / hw, px = i - n * hw;
     const long long base = n * c * hw + px;
@@ -54,7 +59,7 @@ __global__ __launch_bounds__(256) void entropy_bwd_kernel(const float* __restric
       for (int k = 0; k < c; ++k) {
         const float pr = sigmoidf_(logits[base + k * hw]);
         float gp = 0.f;
-        if (dent) gp += dent[base + k * hw] * norm * (-logf(pr + SMOOTHF) - pr / (pr + SMOOTHF));
+        if (has_e) gp += ((dent ? dent[base + k * hw] : 0.f) + dm) * norm * (-logf(pr + SMOOTHF) - pr / (pr + SMOOTHF));
         if (dprob) gp += dprob[base + k * hw];
         const float g = gp * pr * (1.f - pr);
         dlogits[base + k * hw] = accumulate ? dlogits[base + k * hw] + g : g;
@@ -70,7 +75,7 @@ __global__ __launch_bounds__(256) void entropy_bwd_kernel(const float* __restric
         const float pr = v[k] / ssum;
         v[k] = pr;
         float g = 0.f;
-        if (dent) g += dent[base + k * hw] * norm * (-logf(pr + SMOOTHF) - pr / (pr + SMOOTHF));
+        if (has_e) g += ((dent ? dent[base + k * hw] : 0.f) + dm) * norm * (-logf(pr + SMOOTHF) - pr / (pr + SMOOTHF));
         if (dprob) g += dprob[base + k * hw];
         gp[k] = g;
         dot += g * pr;
@@ -405,15 +410,56 @@ extern "C" int pcuda_entropy_fwd(const float* logits, int mode, float norm, floa
   return PCUDA_OK;
 }
 
-extern "C" int pcuda_entropy_bwd(const float* logits, int mode, float norm, const float* dent, const float* dprob,
-                                 float* dlogits, int accumulate, int n, int c, long long hw, pcuda_stream_t s) {
-  if (!logits || !dlogits || (!dent && !dprob) || n <= 0 || c <= 0 || c > MAXC || hw <= 0)
+extern "C" int pcuda_entropy_bwd2(const float* logits, int mode, float norm, const float* dent, const float* dprob,
+                                  const float* dmean, float* dlogits, int accumulate, int n, int c, long long hw,
+                                  pcuda_stream_t s) {
+  if (!logits || !dlogits || (!dent && !dprob && !dmean) || n <= 0 || c <= 0 || c > MAXC || hw <= 0)
     PCUDA_FAIL(PCUDA_E_BADARG, "entropy_bwd: bad arguments");
   const long long npix = (long long)n * hw;
   ProfScope prof(PCUDA_FAM_POINTWISE, 12.0 * npix * c, (hipStream_t)s);
   hipLaunchKernelGGL(entropy_bwd_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)s, logits, mode, norm, dent,
-                     dprob, dlogits, accumulate, c, hw, npix);
+                     dprob, dlogits, accumulate, c, hw, npix, dmean, (float)(1.0 / (double)npix));
   PCUDA_CHECK_LAUNCH("entropy_bwd_kernel");
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_entropy_bwd(const float* logits, int mode, float norm, const float* dent, const float* dprob,
+                                 float* dlogits, int accumulate, int n, int c, long long hw, pcuda_stream_t s) {
+  return pcuda_entropy_bwd2(logits, mode, norm, dent, dprob, nullptr, dlogits, accumulate, n, c, hw, s);
+}
+
+// out = scale * sum(x): two fixed-order stages (SUM_BLOCKS block partials in fp32, their sum in fp64): deterministic
+#define SUM_BLOCKS 512
+__global__ __launch_bounds__(256) void sum_partial_kernel(const float* __restrict__ x, long long numel,
+                                                          float* __restrict__ part) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < numel; i += 256ll * gridDim.x) acc += x[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ __launch_bounds__(64) void sum_final_kernel(const float* __restrict__ part, int nparts, double scale,
+                                                       float* __restrict__ out) {
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 64) acc += (double)part[i];
+  acc = wave_sum_d(acc);
+  if (threadIdx.x == 0) *out = (float)(acc * scale);
+}
+
+extern "C" size_t pcuda_sum_all_workspace_size(void) { return SUM_BLOCKS * sizeof(float); }
+
+extern "C" int pcuda_sum_all(const float* x, long long numel, double scale, float* out, void* workspace,
+                             size_t workspace_bytes, pcuda_stream_t s) {
+  if (!x || !out || numel <= 0 || !workspace || workspace_bytes < pcuda_sum_all_workspace_size())
+    PCUDA_FAIL(PCUDA_E_BADARG, "sum_all: bad arguments");
+  long long nb = (numel + 1023) / 1024;
+  if (nb > SUM_BLOCKS) nb = SUM_BLOCKS;
+  ProfScope prof(PCUDA_FAM_POINTWISE, 4.0 * numel, (hipStream_t)s);
+  hipLaunchKernelGGL(sum_partial_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)s, x, numel, (float*)workspace);
+  hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, (const float*)workspace, (int)nb, scale, out);
+  PCUDA_CHECK_LAUNCH("sum_all");
   return PCUDA_OK;
 }
 

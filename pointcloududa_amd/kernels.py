@@ -548,15 +548,29 @@ def entropy_fwd(logits, mode="sigmoid", norm=1.0, want_prob=False):
     return ent, prob
 
 
-def entropy_bwd(logits, mode, norm, dent=None, dprob=None, out=None, accumulate=False):
+def entropy_bwd(logits, mode, norm, dent=None, dprob=None, out=None, accumulate=False, dmean=None):
+    """``dmean``: device scalar, gradient of the map's mean over batch and pixels (sum over channels)"""
     n, c = logits.shape[:2]
     hw = logits.numel() // (n * c)
     if out is None:
         out = torch.empty_like(logits)
-    check(L.lib().pcuda_entropy_bwd(logits.data_ptr(), _mode(mode), float(norm),
-                                    _ptr(None if dent is None else dent.contiguous()),
-                                    _ptr(None if dprob is None else dprob.contiguous()), out.data_ptr(),
-                                    1 if accumulate else 0, n, c, hw, _stream()), "entropy_bwd")
+    check(L.lib().pcuda_entropy_bwd2(logits.data_ptr(), _mode(mode), float(norm),
+                                     _ptr(None if dent is None else dent.contiguous()),
+                                     _ptr(None if dprob is None else dprob.contiguous()),
+                                     _ptr(None if dmean is None else dmean.contiguous()), out.data_ptr(),
+                                     1 if accumulate else 0, n, c, hw, _stream()), "entropy_bwd")
+    return out
+
+
+def sum_all(x, scale=1.0):
+    """scale * sum(x) as a 0-dim device tensor (fixed summation order)"""
+    _req(x)
+    x = x.contiguous()
+    lib = L.lib()
+    nb = lib.pcuda_sum_all_workspace_size()
+    ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    check(lib.pcuda_sum_all(x.data_ptr(), x.numel(), float(scale), out.data_ptr(), ws.data_ptr(), nb, _stream()), "sum_all")
     return out
 
 

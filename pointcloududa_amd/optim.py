@@ -180,14 +180,31 @@ class FusedAdam(_FlatOptimizer):
 
 
 class FusedSGD(_FlatOptimizer):
-    def __init__(self, module, lr=2.5e-5, momentum=0.99, weight_decay=0.0005):
+    def __init__(self, module, lr=2.5e-5, momentum=0.99, weight_decay=0.0005, skip_prefixes=()):
         super().__init__(module, lr)
         self.momentum, self.wd = momentum, weight_decay
         self.buf = torch.zeros_like(self.p) if momentum != 0 else None
+        # ``skip_prefixes``: parameters that never receive a gradient in the reference (``.grad is None``): torch.optim
+        # skips them altogether -- no weight decay, no momentum buffer.  The flat buffer is updated in the contiguous
+        # ranges between them.
+        self.ranges = [(0, self.p.numel())]
+        if skip_prefixes:
+            self.ranges, lo, off = [], 0, 0
+            for name, p in module.named_parameters():
+                n = (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+                if name.startswith(tuple(skip_prefixes)):
+                    if off > lo:
+                        self.ranges.append((lo, off))
+                    lo = off + n
+                off += n
+            if off > lo:
+                self.ranges.append((lo, off))
 
     def step(self, grad_scale: float = 1.0):
         self.module._wgen = getattr(self.module, "_wgen", 0) + 1
-        K.sgd_step(self.p, self.g, self.buf, self.lr, self.momentum, self.wd, self.steps == 0, grad_scale)
+        for lo, hi in self.ranges:
+            K.sgd_step(self.p[lo:hi], self.g[lo:hi], None if self.buf is None else self.buf[lo:hi], self.lr, self.momentum,
+                       self.wd, self.steps == 0, grad_scale)
         self.steps += 1
         K.repack_owner(self.module)
 

@@ -44,6 +44,11 @@ class TrainCfg:
     w2: float = 1.0
     w4: float = 1.0
     n_class: int = 4
+    # optional branches of the MM-WHS loop (ignored by the mscmrseg variant, which has none of them)
+    etpls: bool = False              # -etpls: source entropy mean added to the supervised loss, with -d2 (train_mmwhs.py:227-230)
+    Tetpls: bool = False             # -Tetpls: target entropy mean added to the adversarial loss (:245-247)
+    d4aux: bool = False              # -d4aux: point head trained (and its target loss reported) without d4 (:220,248,256)
+    gen_sgd: bool = False            # -sgd: SGD(momentum .95, weight decay 5e-4) for the segmenter (:453-459)
 
 
 class AdversarialTrainer:
@@ -56,7 +61,13 @@ class AdversarialTrainer:
         self.dis2 = model_dis2 if c.d2 else None
         self.dis4 = model_dis4 if c.d4 else None
         self.group = process_group
-        self.opt_gen = FusedAdam(self.gen, lr=c.lr, betas=(0.9, 0.99))
+        if c.gen_sgd and c.variant == "mmwhs":
+            # torch.optim.SGD skips parameters whose .grad is None (no weight decay either): the reference's unused
+            # encoder.conv1_1 always, and the point head when no loss is attached to it
+            skip = ["encoder.conv1_1."] + ([] if (c.d4 or c.d4aux) else ["pointNet."])
+            self.opt_gen = FusedSGD(self.gen, lr=c.lr, momentum=0.95, weight_decay=0.0005, skip_prefixes=tuple(skip))
+        else:
+            self.opt_gen = FusedAdam(self.gen, lr=c.lr, betas=(0.9, 0.99))
         mk = lambda m, lr: FusedSGD(m, lr=lr, momentum=c.d_momentum, weight_decay=0.0005)
         self.opt_d1 = mk(self.dis1, c.d1lr) if self.dis1 is not None else None
         self.opt_d2 = mk(self.dis2, c.d2lr) if self.dis2 is not None else None
@@ -99,6 +110,15 @@ class AdversarialTrainer:
             bufs += [b for b in opt.module.buffers() if b.numel() > 0]
             for t in bufs:
                 dist.broadcast(t, src=src, group=self.group)
+            # the host-side step count decides whether SGD's next step INITIALISES its momentum buffer (optim.py): a
+            # fresh replica next to a resumed rank 0 would overwrite the buffer it has just received
+            steps = torch.tensor([opt.steps], dtype=torch.int64, device=opt.p.device)
+            dist.broadcast(steps, src=src, group=self.group)
+            opt.steps = int(steps.item())
+            # the flat parameter buffer changed behind torch's back (no ``_version`` bump): packed convolution weights
+            # cached by an earlier forward pass are stale on every rank but ``src``
+            opt.module._wgen = getattr(opt.module, "_wgen", 0) + 1
+            K.repack_owner(opt.module)
 
     def _dis(self):
         return [m for m in (self.dis1, self.dis2, self.dis4) if m is not None]
@@ -130,7 +150,20 @@ class AdversarialTrainer:
         o_s, _, vert_s = self.gen(img_a)
         l_main, l_jac = L.seg_loss(o_s, mask_a_u8, mode)
         seeds_t, seeds_g = [l_main, l_jac], [one, one]
-        if c.d4:
+        aux = c.d4aux and not ms
+        pre_s = None
+        if not ms:
+            # entropy map / probabilities of the source batch (train_mmwhs.py:223-226): the map's mean is a per-step
+            # metric, and with -d2 -etpls a term of the supervised loss (:227-230); the maps themselves are the
+            # discriminators' source inputs of phases 3-4 (taken detached)
+            with_grad = c.d2 and c.etpls
+            ent_s, pred_s, m_s = L.entropy_map(o_s if with_grad else o_s.detach(), mode, True, want_prob=True, want_mean=True)
+            out["entropy_loss"] = m_s.detach()
+            if with_grad:
+                seeds_t.append(m_s)
+                seeds_g.append(one)
+            pre_s = (ent_s.detach(), pred_s.detach())
+        if c.d4 or aux:
             l_pt = L.batch_NN_loss(vert_s, vert_a)
             out["ver_s_loss"] = l_pt.detach()
             seeds_t.append(l_pt)
@@ -143,14 +176,14 @@ class AdversarialTrainer:
         # segmenter's work -- run on their streams UNDER the source batch's backward pass.
         early = self.early_fwd2
         if early:
-            o_t, vert_t, prep, ev, adv_t, adv_g = self._phase2_forward(img_b, vert_b, drop_mask, out, o_s)
+            o_t, vert_t, prep, ev, adv_t, adv_g = self._phase2_forward(img_b, vert_b, drop_mask, out, o_s, pre_s)
         torch.autograd.backward(seeds_t, seeds_g)
         out["seg_dice"] = K.dice_metric(o_s.detach(), mask_a_u8)      # :215-216, on the device
         if keep:
             self.last = {"oS": o_s.detach(), "vertS": None if vert_s is None else vert_s.detach(),
                          "grad_seg": self.opt_gen.g.clone()}
         if not early:
-            o_t, vert_t, prep, ev, adv_t, adv_g = self._phase2_forward(img_b, vert_b, drop_mask, out, o_s)
+            o_t, vert_t, prep, ev, adv_t, adv_g = self._phase2_forward(img_b, vert_b, drop_mask, out, o_s, pre_s)
         # 2. (backward half, :242-247).  Data-parallel: the all-reduce of every segmenter gradient except the encoder's
         # (92 % of the 76 MB) starts from inside the backward pass, as soon as those kernels are launched, and runs on
         # RCCL's stream under the encoder's backward kernels; the encoder's slice follows after the pass.
@@ -175,7 +208,7 @@ class AdversarialTrainer:
         self._phase345(o_s, vert_s, vert_t, prep, ev, drop_mask, out, keep, g_works, split)
         return out
 
-    def _phase2_forward(self, img_b, vert_b, drop_mask, out, o_s):
+    def _phase2_forward(self, img_b, vert_b, drop_mask, out, o_s, pre_s=None):
         c = self.cfg
         ms = c.variant == "mscmrseg"
         mode = "sigmoid" if (ms or not c.softmax) else "softmax"
@@ -191,8 +224,11 @@ class AdversarialTrainer:
             else:
                 tap_t = o_t
         else:
-            ent_t, pred_t = L.entropy_map(o_t, mode, True, want_prob=True)
+            ent_t, pred_t, m_t = L.entropy_map(o_t, mode, True, want_prob=True, want_mean=True)
+            out["entropy_loss_T"] = m_t.detach()                    # train_mmwhs.py:243-244
         adv_t, adv_g = [], []
+        if not ms and c.Tetpls:                                     # :245-247 (weight 1, not dr-scaled)
+            adv_t.append(m_t); adv_g.append(one)
         # the frozen discriminators' forward passes (and, through autograd's per-node streams, their input-gradient
         # passes) run next to each other like phases 3-4 below
         heads = []
@@ -200,8 +236,9 @@ class AdversarialTrainer:
         run_d = lambda m, x: m.forward_cached(x, room=1 if self.d_joint else 0) if self._replays(m) else m(x)
         if c.d2:
             heads.append(("adv2", lambda: run_d(self.dis2, ent_t), c.dr * (1.0 if ms else c.w2)))
-        if c.d4:
+        if c.d4 or (c.d4aux and not ms):
             out["ver_t_loss"] = L.batch_NN_loss(vert_t.detach(), vert_b)
+        if c.d4:
             heads.append(("adv4", lambda: self.dis4(vert_t.transpose(2, 1), drop_mask)[0], c.dr * (1.0 if ms else c.w4)))
         if c.d1:
             heads.append(("adv1", lambda: run_d(self.dis1, tap_t if ms else pred_t), c.dr * (1.0 if ms else c.w1)))
@@ -227,7 +264,7 @@ class AdversarialTrainer:
                 ent_s = L.entropy_map(o_s_d, "sigmoid", False) if c.d2 else None
                 in1_s, in1_t = o_s_d, o_t_d
             else:
-                ent_s, pred_s = L.entropy_map(o_s_d, mode, True, want_prob=True)
+                ent_s, pred_s = pre_s if pre_s is not None else L.entropy_map(o_s_d, mode, True, want_prob=True)
                 in1_s, in1_t = pred_s, (None if pred_t is None else pred_t.detach())
             prep = (ent_s, None if ent_t is None else ent_t.detach(), in1_s, in1_t)
             if self.d_overlap and self.d_streams:
@@ -390,6 +427,8 @@ class AdversarialTrainer:
         for k, w in (("adv2", 1.0 if ms else cfg.w2), ("adv4", 1.0 if ms else cfg.w4), ("adv1", 1.0 if ms else cfg.w1)):
             if k in h:
                 adv += cfg.dr * w * h[k]
+        if not ms and cfg.Tetpls and "entropy_loss_T" in h:
+            adv += h["entropy_loss_T"]
         h["adv_loss"] = adv
         for d in ("dis1", "dis2", "dis4"):
             if d + "_hit_src" in h:

@@ -83,26 +83,36 @@ def jaccard_loss(true, logits, eps=1e-7, activation=True):
 
 class _EntropyFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, mode, norm, want_prob):
+    def forward(ctx, logits, mode, norm, want_prob, want_mean):
         logits = logits.contiguous()
         ent, prob = K.entropy_fwd(logits, mode, norm, want_prob)
         ctx.logits, ctx.mode, ctx.norm = logits, mode, norm
         ctx.set_materialize_grads(False)
+        outs = [ent]
         if want_prob:
-            return ent, prob
-        return ent
+            outs.append(prob)
+        if want_mean:     # torch.mean(torch.sum(map, dim=1)): train_mmwhs.py:225,243
+            outs.append(K.sum_all(ent, 1.0 / (logits.shape[0] * (logits.numel() // (logits.shape[0] * logits.shape[1])))))
+        ctx.layout = (want_prob, want_mean)
+        return outs[0] if len(outs) == 1 else tuple(outs)
 
     @staticmethod
-    def backward(ctx, dent, dprob=None):
-        if dent is None and dprob is None:
-            return None, None, None, None
-        d = K.entropy_bwd(ctx.logits, ctx.mode, ctx.norm, dent, dprob)
-        return d, None, None, None
+    def backward(ctx, dent, *rest):
+        want_prob, want_mean = ctx.layout
+        rest = list(rest)
+        dprob = rest.pop(0) if want_prob else None
+        dmean = rest.pop(0) if want_mean else None
+        if dent is None and dprob is None and dmean is None:
+            return None, None, None, None, None
+        d = K.entropy_bwd(ctx.logits, ctx.mode, ctx.norm, dent, dprob, dmean=dmean)
+        return d, None, None, None, None
 
 
-def entropy_map(logits, mode="sigmoid", normalise=False, want_prob=False):
+def entropy_map(logits, mode="sigmoid", normalise=False, want_prob=False, want_mean=False):
+    """-> ent [, prob] [, mean]: ``mean`` = torch.mean(torch.sum(ent, dim=1)), the entropy loss term of the MM-WHS loop
+    (train_mmwhs.py:225-230,243-247), differentiable like the map itself"""
     norm = 1.0 / math.log(logits.shape[1]) if normalise else 1.0
-    return _EntropyFn.apply(logits, mode, norm, want_prob)
+    return _EntropyFn.apply(logits, mode, norm, want_prob, want_mean)
 
 
 class _EntropyTapFn(torch.autograd.Function):

@@ -3,7 +3,7 @@
 # no trace domains; summary -> gpurun_out/<TAG>_pmc_traffic.csv (copy to profiles/)
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-TAG=${TAG:-r02}
+TAG=${TAG:-r03}
 rm -rf gpurun_out/pmc; mkdir -p gpurun_out/pmc
 for c in FETCH_SIZE WRITE_SIZE; do
   PCUDA_DSTREAMS=0 timeout ${PMC_TIMEOUT:-500} rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc/$c -o $TAG -- python3 bench.py --steps 2 --warmup 1 --settle 2 --no-cpu-baseline --no-roofline > gpurun_out/pmc_${c}_$TAG.log 2>&1
@@ -23,7 +23,11 @@ for k, d in agg.items():
     f_, w_ = d.get("FETCH_SIZE", [0.0, 0]), d.get("WRITE_SIZE", [0.0, 0])
     rows.append((k, max(f_[1], w_[1]), f_[0], w_[0]))
 rows.sort(key=lambda r: -(r[2] + r[3]))
+import sys
+sys.path.insert(0, ".")
+from pointcloududa_amd._lib import csrc_hash
 with open("gpurun_out/%s_pmc_traffic.csv" % tag, "w") as o:
+    o.write("# csrc_sha256=%s\n" % csrc_hash())
     o.write("kernel,launches,FETCH_SIZE_KB_sum_raw,WRITE_SIZE_KB_sum,FETCH_SIZE_KB_per_launch_raw,WRITE_SIZE_KB_per_launch\n")
     for k, n, f_, w_ in rows:
         o.write('"%s",%d,%.0f,%.0f,%.1f,%.1f\n' % (k, n, f_, w_, f_ / max(n, 1), w_ / max(n, 1)))

@@ -152,6 +152,13 @@ def test_bench_launcher_spawns_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--dry-run",
                         "--workload", "nope"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0 and '"metric"' not in r.stdout
+    # a rank >= 1 that dies during start-up: rank 0 is then stuck in the rendezvous / a collective; the launcher polls
+    # every child, ends the survivors and exits with the failed rank's status instead of waiting for rank 0's stdout
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--dry-run"],
+                       capture_output=True, text=True, timeout=120, env=dict(env, PCUDA_DRYRUN_FAIL_RANK="1"))
+    assert r.returncode == 3 and '"metric"' not in r.stdout and time.time() - t0 < 60, (r.returncode, time.time() - t0)
 
 
 def test_single_process_allreduce_is_identity():

@@ -65,6 +65,8 @@ def _check_grads(mod, g, tol, tol_elem=None):
     ("seg_small", dict(filters=4, in_channels=1, n_class=4, pointnet=True, fc_inch=9), False),
     ("seg_small_3ch_nopoint", dict(filters=8, in_channels=3, n_class=5, pointnet=False), True),
     ("seg_full256", dict(filters=32, in_channels=1, n_class=4, pointnet=True, fc_inch=121), False),
+    # stand-in for BASELINE config 5's input size (no DeepLab exists in the reference): the reference's segmenter at 512x512
+    ("seg_full512", dict(filters=32, in_channels=1, n_class=4, pointnet=True, fc_inch=729), False),
     # extpn=True: two extra 3x3 convolutions in front of the point head (unet.py:81-83,90-92)
     ("seg_small_extpn", dict(filters=4, in_channels=1, n_class=4, pointnet=True, fc_inch=9, extpn=True), False),
 ])
