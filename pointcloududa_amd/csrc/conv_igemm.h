@@ -79,6 +79,7 @@ struct WgradParams {
   int tw16;                // TW % 16 == 0 and TW*TH == 128: a k-step's 16 pixel slots share one tile row
   int xq;                  // 1: quad (float4) staging of the input tile (in_w % 4 == 0, no upsampling fold)
   int dbg;                 // PCUDA_DBG bits (timing experiments only): 16 no X staging, 32 no dZ staging, 64 no MFMA
+  int xcd_items;           // > 0: XCD-aware block mapping, work items per XCD (= blocks / 8)
 };
 
 #define WG_ZROW 272   // wgrad: bytes per dZ row in LDS, 128 px bf16 + 16 pad (17*16: conflict-free b128)

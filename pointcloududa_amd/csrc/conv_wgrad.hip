@@ -50,15 +50,19 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
 
 // the split-K reduce for other translation units (the direct kernels' block partials): partial = [ksplit][numel],
 // dw[i] (+)= sum over k in a fixed order; db_partial = [ksplit][nb] or NULL
-int launch_wgrad_reduce(const float* partial, long long numel, int ksplit, float* dw, int accumulate, const float* db_partial,
-                        long long nb, float* db, hipStream_t s) {
+int launch_wgrad_reduce_taps(const float* partial, long long numel, int ksplit, float* dw, int accumulate, int ntaps,
+                             const float* db_partial, long long nb, float* db, hipStream_t s) {
   int nkg = 1;
   while (nkg < 16 && nkg * 2 <= ksplit) nkg <<= 1;
   const unsigned nblk = (unsigned)cdiv(numel, 64) + (db ? (unsigned)cdiv(nb, 64) : 0u);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk), dim3(64 * nkg), 0, s, partial, numel, ksplit, dw, accumulate, 1,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk), dim3(64 * nkg), 0, s, partial, numel, ksplit, dw, accumulate, ntaps,
                      db_partial, db ? nb : 0, db);
   PCUDA_CHECK_LAUNCH("wgrad_reduce_kernel");
   return PCUDA_OK;
+}
+int launch_wgrad_reduce(const float* partial, long long numel, int ksplit, float* dw, int accumulate, const float* db_partial,
+                        long long nb, float* db, hipStream_t s) {
+  return launch_wgrad_reduce_taps(partial, numel, ksplit, dw, accumulate, 1, db_partial, nb, db, s);
 }
 
 // ---- the split-K reduces of MANY weight gradients in one launch (a backward pass issues one per layer: 80 launches of
@@ -209,6 +213,8 @@ extern "C" size_t pcuda_conv2d_wgrad_workspace_size(const pcuda_conv_geom* g) {
   size_t dneed = direct_wgrad_workspace(g);
   const size_t d1need = direct_d1_wgrad_workspace(g);
   if (d1need > dneed) dneed = d1need;
+  const size_t w3need = wgrad3_workspace(g);
+  if (w3need > dneed) dneed = w3need;
   return need > dneed ? need : dneed;
 }
 
@@ -249,6 +255,8 @@ static int wgrad_impl(const pcuda_conv_geom* g, int prec, const pcuda_src* x, co
     int rc;
     if (direct_wgrad(g, x, dy, dy_sn, dy_sc, dw, db, accumulate, workspace, s, &rc)) return rc;
     if (direct_d1_wgrad(g, x, dy, dy_sn, dy_sc, dw, db, accumulate, workspace, s, &rc)) return rc;
+    // aligned 3x3 / stride-1 layers: the fixed-geometry kernel (conv_wgrad3.hip)
+    if (wgrad3_try(g, prec, x, dy, dy_sn, dy_sc, dw, db, accumulate, workspace, s, defer, &rc)) return rc;
   }
   const bool x3 = prec == PCUDA_PREC_BF16X3;
   WgradPlan w = plan_wgrad(g);
@@ -289,6 +297,12 @@ static int wgrad_impl(const pcuda_conv_geom* g, int prec, const pcuda_src* x, co
   const size_t lds = (size_t)x_cap * IG_REC_BYTES * mul + zb;
   if (lds > (size_t)LDS_HARD) PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv2d_wgrad: tile %dx%d does not fit LDS", w.ih_t, w.iw_t);
   const dim3 grid(w.n_co_tiles * w.n_chunks * w.tap_groups, w.ksplit);
+  {
+    static int noxcd = -1;
+    if (noxcd < 0) { const char* e = getenv("PCUDA_WG_NOXCD"); noxcd = (e && atoi(e)) ? 1 : 0; }
+    const long long nblk = (long long)grid.x * grid.y;
+    p.xcd_items = (!noxcd && nblk >= 16 && (nblk & 7) == 0) ? (int)(nblk / 8) : 0;
+  }
   {
     const double flops = 2.0 * g->n * (double)g->out_h * g->out_w * g->cout * (double)g->cin * t.n;
     char tag[160];

@@ -267,11 +267,20 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (TAPS_MAX <= 9 && PF <= 1)) ? 
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tap ranges and tap offsets stay in SGPRs
 
-  const int bx = blockIdx.x;
+  // XCD-aware block -> work mapping (round 3).  Workgroups are dealt round-robin over the 8 XCDs (ids b and b + 8 share
+  // one; each XCD has its own L2).  The workgroups of one split-K slice walk the SAME pixel tiles -- X is re-read once per
+  // co-tile, dZ once per chunk -- so the work items, ordered slice-major, are cut into 8 contiguous ranges, one per XCD:
+  // whole slices (or a contiguous range of one slice's co-tiles) then share an L2 instead of each XCD fetching all of it.
+  int bx = blockIdx.x, kslice = blockIdx.y;
+  if (p.xcd_items) {
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int item = (lin & 7) * p.xcd_items + (lin >> 3);
+    kslice = item / (int)gridDim.x;
+    bx = item - kslice * (int)gridDim.x;
+  }
   const int tgidx = bx % p.tap_groups;
   const int chunk = (bx / p.tap_groups) % p.n_chunks;
   const int cot = bx / (p.tap_groups * p.n_chunks);
-  const int kslice = blockIdx.y;
   const int t_begin = tgidx * p.ntaps;
   const int tcount = min(p.ntaps, p.ntaps_total - t_begin);
   const int cb = w % CO_BLKS, wsub = w / CO_BLKS;
