@@ -319,8 +319,8 @@ int direct_d1_wgrad(const pcuda_conv_geom* g, const pcuda_src* x, const float* d
   const int numel = g->cout * g->cin * 16;
 #define D1_WG_LAUNCH(C_)                                                                                              \
   {                                                                                                                   \
-    static bool set_ = false;                                                                                         \
-    if (!set_) { (void)hipFuncSetAttribute((const void*)d1_wgrad_kernel<C_>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); set_ = true; } \
+    /* (the attribute is per DEVICE: set on every launch rather than once per process -- the call is cheap) */          \
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)d1_wgrad_kernel<C_>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); \
     hipLaunchKernelGGL(d1_wgrad_kernel<C_>, dim3(blocks), dim3(256), lds, s, p, items);                               \
   }
   switch (g->cin) {
@@ -340,17 +340,14 @@ int direct_d1_wgrad(const pcuda_conv_geom* g, const pcuda_src* x, const float* d
 
 // ------------------------------------------------------------------------------------------
 // The discriminators' LAST layer: cin (256 / 512) -> 1 channel, 4x4, stride 2, pad 2, on a 17x17 (or smaller) map
-// (GAN.py:101).  One output row of a 32-row MFMA tile carried data: 0.4-0.7 TFLOP/s, 120 us per launch.  Here: one
-// 1024-thread workgroup per image; 64-channel chunks of the input staged in LDS one chunk ahead (registers: 18 loads
-// per lane in flight), every thread one output pixel and a twelfth of a chunk's channels, fixed-order combine.
-// (With 16-channel chunks and 256 threads the kernel ran at one memory round trip per chunk: 135 us.)
+// (GAN.py:101).  One output row of a 32-row MFMA tile carried data: 0.4-0.7 TFLOP/s, 120 us per launch.  Round 2 ran
+// one 1024-thread workgroup per image over 64-channel chunks staged in LDS (131 us: a fraction of the CUs, eight
+// barrier-separated round trips); round 3 below.
 // Packed forward weights: rows = cout = 1 (row 0 of a 32-row tile), element (ci, t) at ((ci / 32) * 16 + t) * 32 * rec + ci % 32.
 // ------------------------------------------------------------------------------------------
 namespace {
 
-#define D5_CH 64
-#define D5_NT 1024
-#define D5_MAXPIX 292     // in_h * in_w of the staged planes (17 x 17 = 289)
+#define D5_MAXPIX 292     // largest input plane taken (17 x 17 = 289)
 struct D5Params {
   const float* x; long long x_sn, x_sc;
   float* y; long long y_sn;
@@ -360,83 +357,61 @@ struct D5Params {
   int h, w, oh, ow, cin;
 };
 
-__global__ __launch_bounds__(D5_NT) void d5_fwd_kernel(const D5Params p) {
+// Round 3: one workgroup per (image, OUTPUT ROW) instead of one per image.  The one-per-image form put 32-64 workgroups
+// on 256 CUs and walked the 512 channels in 8 barrier-separated chunks: 131 us for an 18.9 MB input (3 us of HBM time).
+// Here 9 x n workgroups (288-576) each read the 4 input rows their output row sees, straight from global memory (an
+// element is used by at most two output pixels of the row; the weights -- 32 KB in fp32 -- are staged in LDS once),
+// thread = (output pixel, channel group), fixed-order combine over the channel groups: deterministic.
+#define D5R_NT 512
+__global__ __launch_bounds__(D5R_NT) void d5_fwd_kernel(const D5Params p) {
   extern __shared__ __attribute__((aligned(16))) float d5_smem[];
-  float* sx = d5_smem;                          // [D5_CH][D5_MAXPIX]
-  float* swt = d5_smem + D5_CH * D5_MAXPIX;     // [D5_CH][16]
-  float* spart = swt + D5_CH * 16;              // [D5_NT]
-  const int tid = threadIdx.x, n = blockIdx.x;
-  const int hw = p.h * p.w, op = p.oh * p.ow;
-  const int ng = D5_NT / op;                        // channel groups (threads per output pixel)
-  const int o = tid % op, gsel = tid / op;
+  float* swt = d5_smem;                      // [cin][16]
+  float* spart = d5_smem + p.cin * 16;       // [ng][ow]
+  const int tid = threadIdx.x, n = blockIdx.x, oy = blockIdx.y;
+  for (int i = tid; i < p.cin * 16; i += D5R_NT) {
+    const int ci = i >> 4, t = i & 15;
+    const uint16_t* wq = p.wpack + ((((long long)(ci >> 5)) * 16 + t) * 32 * p.rec + (ci & 31));
+    float wv = bf16_bits_to_float(wq[0]);
+    if (p.rec > IG_REC) wv += bf16_bits_to_float(wq[32]);
+    PCUDA_KEEP(wq);      // (VMEM address rule, common.h)
+    swt[i] = wv;
+  }
+  const int ng = D5R_NT / p.ow;              // channel groups
+  const int ox = tid % p.ow, gsel = tid / p.ow;
   const bool live = gsel < ng;
-  const int oy = o / p.ow, ox = o - oy * p.ow;
   int off[16];
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
     const int iy = 2 * oy + (t >> 2) - 2, ix = 2 * ox + (t & 3) - 2;
     off[t] = ((unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.w) ? iy * p.w + ix : -1;
   }
-  const int per = (D5_CH * hw + D5_NT - 1) / D5_NT;   // staged elements per thread and chunk (<= 19)
-  float rx[19], rw;
-  const uint16_t* wq = p.wpack;
-  auto issue = [&](int c0) {
-    const float* xb = p.x + (long long)n * p.x_sn + (long long)c0 * p.x_sc;
-#pragma unroll
-    for (int u = 0; u < 19; ++u) {
-      const int i = tid + D5_NT * u;
-      const int c = min(i / hw, D5_CH - 1), q = i - (i / hw) * hw;
-      const int cc = min(c, p.cin - 1 - c0);                     // (a ragged last chunk re-reads a valid plane; its weights are 0)
-      rx[u] = (u < per) ? xb[(long long)cc * p.x_sc + min(q, hw - 1)] : 0.f;
-    }
-    {
-      const int c = tid >> 4, t = tid & 15, ci = min(c0 + c, p.cin - 1);
-      const long long idx = (((long long)(ci >> 5)) * 16 + t) * 32 * p.rec + (ci & 31);
-      wq = p.wpack + idx;
-      rw = bf16_bits_to_float(wq[0]);
-      if (p.rec > IG_REC) rw += bf16_bits_to_float(wq[32]);
-      if (c0 + c >= p.cin) rw = 0.f;
-    }
-  };
+  __syncthreads();
   float acc = 0.f;
-  issue(0);
-  for (int c0 = 0; c0 < p.cin; c0 += D5_CH) {
-    __syncthreads();
+  if (live) {
+    const float* xb = p.x + (long long)n * p.x_sn;
+    for (int c = gsel; c < p.cin; c += ng) {
+      const float* xc = xb + (long long)c * p.x_sc;
+      const float* wc = swt + c * 16;
+      float xv[16];
 #pragma unroll
-    for (int u = 0; u < 19; ++u) {
-      const int i = tid + D5_NT * u;
-      if (u < per && i < D5_CH * hw) sx[(i / hw) * D5_MAXPIX + (i - (i / hw) * hw)] = rx[u];
-    }
-    swt[tid] = rw;
-    PCUDA_KEEP(wq);      // (VMEM address rule, common.h: the weight's address outlives its load)
-    __syncthreads();
-    if (c0 + D5_CH < p.cin) issue(c0 + D5_CH);
-    if (live) {
-      for (int c = gsel; c < D5_CH; c += ng) {
-        const float* xc = sx + c * D5_MAXPIX;
-        const float* wc = swt + c * 16;
+      for (int t = 0; t < 16; ++t) xv[t] = xc[off[t] >= 0 ? off[t] : 0];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const float xv = off[t] >= 0 ? xc[off[t]] : 0.f;
-          acc = fmaf(wc[t], xv, acc);
-        }
-      }
+      for (int t = 0; t < 16; ++t) acc = fmaf(wc[t], off[t] >= 0 ? xv[t] : 0.f, acc);
+      PCUDA_KEEP(xc);
     }
+    spart[gsel * p.ow + ox] = acc;
   }
   __syncthreads();
-  spart[tid] = live ? acc : 0.f;
-  __syncthreads();
-  if (tid < op) {
+  if (tid < p.ow) {
     float s = 0.f;
-    for (int k = 0; k < ng; ++k) s += spart[k * op + tid];   // fixed order
-    // (VMEM address rule, common.h: SGPR base + a VGPR offset of its own that outlives the load -- the constant 0 the
-    // compiler would use is a register it hands to the destination)
+    for (int k = 0; k < ng; ++k) s += spart[k * p.ow + tid];   // fixed order
+    // (VMEM address rule, common.h: SGPR base + a VGPR offset of its own that outlives the load)
     int boff = 0;
     asm volatile("" : "+v"(boff));
     s += p.bias ? p.bias[boff] : 0.f;
     PCUDA_KEEP(boff);
     s = s > 0.f ? s : s * p.slope;
-    p.y[(long long)n * p.y_sn + tid] = s;
+    p.y[(long long)n * p.y_sn + oy * p.ow + tid] = s;
   }
 }
 
@@ -461,10 +436,9 @@ int direct_d5_forward(const pcuda_conv_geom* g, int prec, const pcuda_src* x, co
   char tag[96];
   snprintf(tag, sizeof(tag), "direct d5 fwd n%d cin%d %dx%d", g->n, g->cin, g->in_h, g->in_w);
   ProfScope prof(PCUDA_FAM_CONV_FWD, flops, s, tag);
-  const size_t lds = (size_t)(D5_CH * D5_MAXPIX + D5_CH * 16 + D5_NT) * sizeof(float);
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)d5_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-  hipLaunchKernelGGL(d5_fwd_kernel, dim3(g->n), dim3(D5_NT), lds, s, p);
+  const size_t lds = (size_t)(g->cin * 16 + D5R_NT) * sizeof(float);
+  if (lds > 60 * 1024) return 0;      // (cin <= 896; wider layers take the MFMA kernel)
+  hipLaunchKernelGGL(d5_fwd_kernel, dim3(g->n, g->out_h), dim3(D5R_NT), lds, s, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { pcuda_set_error("d5_fwd_kernel: %s", hipGetErrorString(e)); *rc = PCUDA_E_LAUNCH; }
   return 1;

@@ -193,7 +193,9 @@ WgradPlan plan_wgrad(const pcuda_conv_geom* g) {
   // 768 / 1024 blocks are one / two balanced rounds (1024 32-row blocks were one full round plus a third of one)
   static int tgt32 = -1;
   if (tgt32 < 0) { const char* e = getenv("PCUDA_WG_BLOCKS32"); tgt32 = e ? atoi(e) : 768; }
-  long long ks = (w.co_blks == 1 ? tgt32 : 1024) / base;
+  static int tgt64 = -1;
+  if (tgt64 < 0) { const char* e = getenv("PCUDA_WG_BLOCKS64"); tgt64 = e ? atoi(e) : 1024; }
+  long long ks = (w.co_blks == 1 ? tgt32 : tgt64) / base;
   if (ks < 1) ks = 1;
   if (ks > ntiles) ks = ntiles;
   // keep the partial slabs (written once, re-read once by the reduce kernel) below ~64 MB (measured:
