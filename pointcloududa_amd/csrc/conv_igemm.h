@@ -80,6 +80,7 @@ struct WgradParams {
   int xq;                  // 1: quad (float4) staging of the input tile (in_w % 4 == 0, no upsampling fold)
   int dbg;                 // PCUDA_DBG bits (timing experiments only): 16 no X staging, 32 no dZ staging, 64 no MFMA
   int xcd_items;           // > 0: XCD-aware block mapping, work items per XCD (= blocks / 8)
+  int xcd_slices;          // > 0: split-K slices per XCD (ksplit / 8), tiles of an XCD's eighth interleaved over them
 };
 
 #define WG_ZROW 272   // wgrad: bytes per dZ row in LDS, 128 px bf16 + 16 pad (17*16: conflict-free b128)

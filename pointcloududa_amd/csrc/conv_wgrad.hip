@@ -202,6 +202,7 @@ WgradPlan plan_wgrad(const pcuda_conv_geom* g) {
   // 32 MB costs the wgrad kernels more parallelism than the reduce kernel saves)
   const long long welems = (long long)g->cout * g->cin * ntaps;
   while (ks > 1 && ks * welems * 4 > (64ll << 20)) ks >>= 1;
+  if (ks >= 8) ks &= ~7ll;      // multiples of 8: an XCD's slices interleave over its eighth of the tiles (wgrad_kernel)
   w.ksplit = (int)ks;
   return w;
 }
@@ -304,6 +305,9 @@ static int wgrad_impl(const pcuda_conv_geom* g, int prec, const pcuda_src* x, co
     if (noxcd < 0) { const char* e = getenv("PCUDA_WG_NOXCD"); noxcd = (e && atoi(e)) ? 1 : 0; }
     const long long nblk = (long long)grid.x * grid.y;
     p.xcd_items = (!noxcd && nblk >= 16 && (nblk & 7) == 0) ? (int)(nblk / 8) : 0;
+    static int nointer = -1;
+    if (nointer < 0) { const char* e = getenv("PCUDA_WG_NOINTER"); nointer = (e && atoi(e)) ? 1 : 0; }
+    p.xcd_slices = (p.xcd_items && !nointer && (w.ksplit & 7) == 0) ? w.ksplit / 8 : 0;
   }
   {
     const double flops = 2.0 * g->n * (double)g->out_h * g->out_w * g->cout * (double)g->cin * t.n;

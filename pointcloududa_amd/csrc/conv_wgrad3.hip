@@ -104,13 +104,17 @@ __global__ __launch_bounds__(64 * RB * 2 * KH, 2) void wgrad3_kernel(const W3Par
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cb = w % RB, tsub = (w / RB) & 1, khalf = w / (RB * 2);
   // XCD-aware block -> work mapping.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one, each
-  // XCD has its own L2): the `base` = co-tiles x chunks workgroups that walk the SAME pixel tiles (one split-K slice) re-read
-  // each other's X and dZ, so they get block ids that are equal modulo 8 -- the re-reads then hit that XCD's L2 instead of
-  // going to the fabric a second time from another XCD.  (ksplit is a multiple of 8 whenever xcd is set.)
-  int bwork = blockIdx.x, kslice;
+  // XCD has its own L2).  XCD x owns the contiguous eighth [x T / 8, (x + 1) T / 8) of the pixel tiles; its S = ksplit / 8
+  // split-K slices take every S-th tile of it (which tiles a slice sums is free), in block order -- so the workgroups
+  // resident on an XCD at any moment work on ADJACENT tiles and on every (co-tile, chunk) of them: the re-reads of X per
+  // co-tile and of dZ per chunk, the halo rows and the neighbouring 128-byte lines of a tile's input rows (3 lines touched
+  // per 32-pixel row segment: scripts/micro/fetch_calib.hip) hit that XCD's L2 instead of going out to the fabric again.
+  int bwork, kslice, xcd = 0, jloc = 0;
   if (p.xcd) {
-    const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
-    kslice = (i / p.base) * 8 + xcd;
+    xcd = blockIdx.x & 7;
+    const int i = blockIdx.x >> 3;
+    jloc = i / p.base;                       // slice index inside the XCD
+    kslice = xcd * (p.ksplit >> 3) + jloc;
     bwork = i % p.base;
   } else {
     kslice = blockIdx.x / p.base;
@@ -172,12 +176,24 @@ __global__ __launch_bounds__(64 * RB * 2 * KH, 2) void wgrad3_kernel(const W3Par
 #pragma unroll
   for (int j = 0; j < ZJ; ++j) dbacc[j] = 0.f;
 
-  // ---- tile range of this split-K slice, walked incrementally
+  // ---- tiles of this split-K slice: first, step, count; (image, tile row, tile column) advanced without divisions
   const int tiles_img = p.tiles_x * p.tiles_y, ntiles = p.n * tiles_img;
-  const int tile_lo = (int)((long long)kslice * ntiles / p.ksplit);
-  const int tile_hi = (int)((long long)(kslice + 1) * ntiles / p.ksplit);
-  int tn = tile_lo / tiles_img, trem = tile_lo - tn * tiles_img;
+  int tile_first, tile_step, tile_count;
+  if (p.xcd) {
+    const int S = p.ksplit >> 3;
+    const int T_lo = (int)((long long)xcd * ntiles / 8), T_hi = (int)((long long)(xcd + 1) * ntiles / 8);
+    tile_first = T_lo + jloc;
+    tile_step = S;
+    tile_count = tile_first < T_hi ? (T_hi - tile_first + S - 1) / S : 0;
+  } else {
+    tile_first = (int)((long long)kslice * ntiles / p.ksplit);
+    tile_step = 1;
+    tile_count = (int)((long long)(kslice + 1) * ntiles / p.ksplit) - tile_first;
+  }
+  int tn = tile_first / tiles_img, trem = tile_first - tn * tiles_img;
   int tyi = trem / p.tiles_x, txi = trem - tyi * p.tiles_x;
+  const int step_n = tile_step / tiles_img, step_rem = tile_step - step_n * tiles_img;
+  const int step_y = step_rem / p.tiles_x, step_x = step_rem - step_y * p.tiles_x;
 
   f32x4 xv[8];
   f32x4 zv[ZJ][2];
@@ -211,12 +227,14 @@ __global__ __launch_bounds__(64 * RB * 2 * KH, 2) void wgrad3_kernel(const W3Par
       }
     }
   };
-  auto advance = [&]() {
-    if (++txi == p.tiles_x) { txi = 0; if (++tyi == p.tiles_y) { tyi = 0; ++tn; } }
+  auto advance = [&]() {      // (n, y, x) += (step_n, step_y, step_x) with carries
+    txi += step_x; tyi += step_y; tn += step_n;
+    if (txi >= p.tiles_x) { txi -= p.tiles_x; ++tyi; }
+    if (tyi >= p.tiles_y) { tyi -= p.tiles_y; ++tn; }
   };
 
-  if (tile_lo < tile_hi) issue();
-  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+  if (tile_count > 0) issue();
+  for (int it = 0; it < tile_count; ++it) {
     __syncthreads();        // the previous tile's MFMA phase is done with the LDS tiles
     // ---- commit X: affine, zero padding, bf16 hi / lo split, one 16-byte record slice per pixel and plane
     if (!(p.dbg & 8)) {
@@ -267,7 +285,7 @@ __global__ __launch_bounds__(64 * RB * 2 * KH, 2) void wgrad3_kernel(const W3Par
       *(uint4*)(Zs + zw + j * (NT / 16) * WG_ZROW) = hi;
     }
     __syncthreads();
-    if (tile + 1 < tile_hi) { advance(); issue(); }      // the next tile's loads stay in flight during the MFMA phase
+    if (it + 1 < tile_count) { advance(); issue(); }      // the next tile's loads stay in flight during the MFMA phase
     if (p.dbg & 4) continue;
     if (KH == 1) {
       if (tsub == 0) w3_mfma<X3, 5, 0, 8, CO_T>(acc, Xs, Zs, xa, za);
@@ -322,7 +340,9 @@ bool w3_eligible(const pcuda_conv_geom* g, const pcuda_src* x, const float* dy, 
   if (off < 0) { const char* e = getenv("PCUDA_NO_WGRAD3"); off = (e && atoi(e)) ? 1 : 0; }
   if (off) return false;
   if (g->k != 3 || g->stride != 1 || g->dil != 1 || g->pad != 1 || g->in_up) return false;
-  if ((g->out_w % W3_TW) || (g->out_h % W3_TH) || (g->cout & 63) || g->cout < 128) return false;
+  static int mincout = -1;
+  if (mincout < 0) { const char* e = getenv("PCUDA_W3_MINCOUT"); mincout = e ? atoi(e) : 128; }
+  if ((g->out_w % W3_TW) || (g->out_h % W3_TH) || (g->cout & 63) || g->cout < mincout) return false;
   const int c1 = x->c1 < g->cin ? x->c1 : g->cin;
   if ((c1 & 31) || ((g->cin - c1) & 31)) return false;
   if (!fast_src_ok(x, g->cin)) return false;
@@ -365,7 +385,7 @@ W3Plan w3_plan(const pcuda_conv_geom* g) {
 
 size_t wgrad3_workspace(const pcuda_conv_geom* g) {
   if (g->k != 3 || g->stride != 1 || g->dil != 1 || g->pad != 1 || g->in_up || (g->out_w % W3_TW) || (g->out_h % W3_TH) ||
-      (g->cout & 63) || g->cout < 128 || (g->cin & 31))
+      (g->cout & 63) || (g->cin & 31))
     return 0;
   const W3Plan w = w3_plan(g);
   return ((size_t)w.ksplit * w.kh * g->cout * g->cin * 9 + (size_t)w.ksplit * w.kh * g->cout) * sizeof(float) + 256;

@@ -294,8 +294,23 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (TAPS_MAX <= 9 && PF <= 1)) ? 
   unsigned char* Zlo = Zhi + (size_t)CO_TILE * WG_ZROW;
 
   const int ntiles = p.n * p.tiles_y * p.tiles_x;
-  const int tile_lo = (int)((long long)kslice * ntiles / p.ksplit);
-  const int tile_hi = (int)((long long)(kslice + 1) * ntiles / p.ksplit);
+  // Which tiles a slice sums is free (split-K partial sums).  Plain: a contiguous range.  With the XCD-aware mapping and
+  // ksplit a multiple of 8 (round 3): XCD x owns the contiguous eighth [x T / 8, (x + 1) T / 8) of the tiles and its
+  // S = ksplit / 8 slices take every S-th tile of it, so that the workgroups resident on the XCD at any moment work
+  // on ADJACENT tiles: the halo rows and the neighbouring 128-byte lines of a tile's input rows -- 3 lines touched per
+  // 32-pixel row segment, 6 rows per 4 -- are then in that XCD's L2 when the neighbour asks for them.  (Walking a
+  // contiguous range per workgroup, 64 workgroups x 63 KB per tile step turned the 4 MB L2 over between two
+  // consecutive tiles of one workgroup: the weight gradient of 32->32 at 256x256 fetched 2.5x its algorithmic bytes.)
+  int tile_lo = (int)((long long)kslice * ntiles / p.ksplit);
+  int tile_hi = (int)((long long)(kslice + 1) * ntiles / p.ksplit);
+  int tile_step = 1;
+  if (p.xcd_items && p.xcd_slices) {
+    const int xcd = (blockIdx.y * gridDim.x + blockIdx.x) & 7, S = p.xcd_slices;
+    const int T_lo = (int)((long long)xcd * ntiles / 8), T_hi = (int)((long long)(xcd + 1) * ntiles / 8);
+    tile_lo = T_lo + (kslice - xcd * S);
+    tile_step = S;
+    tile_hi = tile_lo < T_hi ? tile_lo + ((T_hi - tile_lo + S - 1) / S) * S : tile_lo;    // tile_lo + count * S
+  }
   const bool do_db = (db_partial != nullptr) && chunk == 0 && tgidx == 0;
 
   f32x16 acc[MAXT];
@@ -341,7 +356,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (TAPS_MAX <= 9 && PF <= 1)) ? 
     }
   }
 
-  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+  for (int tile = tile_lo; tile < tile_hi; tile += tile_step) {
     if (PF == 0) cur = wtile_decode<CLAMP>(p, tile);
     const int oy0 = cur.oy0, ox0 = cur.ox0, tw = cur.tw, npix = cur.npix;
     __syncthreads();   // the previous tile's MFMA phase is done with the LDS tiles
@@ -364,8 +379,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (TAPS_MAX <= 9 && PF <= 1)) ? 
     zpre_commit<X3, CO_TILE, NT>(zv, p, cur, cot, tid, Zhi, Zlo, do_db, dbacc, false);
     __syncthreads();
     WTile nxt = cur;
-    if (PF > 0 && tile + 1 < tile_hi) {   // (the block's last tile skips the loads altogether)
-      nxt = wtile_decode<CLAMP>(p, tile + 1);
+    if (PF > 0 && tile + tile_step < tile_hi) {   // (the block's last tile skips the loads altogether)
+      nxt = wtile_decode<CLAMP>(p, tile + tile_step);
       if (XQ) xq_issue<XPF, NT>(xpre, p.x, nxt.n, p.cin, chunk, p.in_h, p.in_w, nxt.oy0, nxt.ox0, nxt.th, nxt.tw, tid);
       else xfast_issue<XPF, NT>(xpre, p.x, nxt.n, p.cin, chunk, p.in_h, p.in_w, p.in_shift, p.in_row, nxt.oy0, nxt.ox0, nxt.tw,
                                 nxt.npix, ngroups, tid);
