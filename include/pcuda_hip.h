@@ -192,6 +192,8 @@ int pcuda_bn_bwd_reduce(const float* dy, long long dy_sn, long long dy_sc, const
                         long long dy2_sc, const float* a, long long a_sn, long long a_sc, const float* mean,
                         const float* invstd, const float* scale, const float* shift, int post_relu, int n, int c,
                         long long hw, float* red, int* ntiles, pcuda_stream_t s);
+/* count < 0: the statistics were FROZEN (eval-mode BatchNorm, nn.BatchNorm2d.eval() in a fine-tuning run: mean / invstd
+ * from the running buffers): coef then describes the fixed affine (dz = m * c0 * dy), dgamma / dbeta are unchanged */
 int pcuda_bn_bwd_finalize(const float* red, int ntiles, int c, long long count, const float* gamma,
                           const float* invstd, const float* mean, float* dgamma, float* dbeta, int accumulate,
                           float* coef /* [c][3]: dz = m*(c0*dy + c1*a + c2) */, pcuda_stream_t s);

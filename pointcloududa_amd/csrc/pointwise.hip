@@ -188,8 +188,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     const double g = gamma ? (double)gamma[ch] : 1.0, is = invstd[ch], m = mean[ch];
     const double sc = g * is;
     coef[ch * 3 + 0] = (float)sc;
-    coef[ch * 3 + 1] = (float)(-sc * is * S2 / count);
-    coef[ch * 3 + 2] = (float)(-sc * S1 / count + sc * is * (S2 / count) * m);
+    // count < 0: FROZEN statistics (eval-mode BatchNorm, mean / invstd from the running buffers): the layer is a fixed
+    // per-channel affine, the batch-mean terms of the training formula vanish; dgamma / dbeta are the same sums
+    coef[ch * 3 + 1] = count < 0 ? 0.f : (float)(-sc * is * S2 / count);
+    coef[ch * 3 + 2] = count < 0 ? 0.f : (float)(-sc * S1 / count + sc * is * (S2 / count) * m);
   }
 }
 
@@ -547,7 +549,7 @@ extern "C" int pcuda_bn_bwd_reduce(const float* dy, long long dy_sn, long long d
 extern "C" int pcuda_bn_bwd_finalize(const float* red, int ntiles, int c, long long count, const float* gamma,
                                      const float* invstd, const float* mean, float* dgamma, float* dbeta,
                                      int accumulate, float* coef, pcuda_stream_t s) {
-  if (!red || ntiles <= 0 || c <= 0 || count <= 0 || !invstd || !mean || !coef)
+  if (!red || ntiles <= 0 || c <= 0 || count == 0 || !invstd || !mean || !coef)
     PCUDA_FAIL(PCUDA_E_BADARG, "bn_bwd_finalize: bad arguments");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(256), 0, (hipStream_t)s, red, ntiles, c, (double)count,
                      gamma, invstd, mean, dgamma, dbeta, accumulate, coef);

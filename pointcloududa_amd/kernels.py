@@ -372,9 +372,10 @@ def bn_apply(a: torch.Tensor, st: BNState, relu=False, out=None):
 
 
 def bn_backward(dy, a, st: BNState, gamma, dgamma, dbeta, dy2=None, post_relu=False, act_slope=1.0,
-                accumulate=True, red=None):
+                accumulate=True, red=None, frozen=False):
     """Backward of [a = lrelu(z, act_slope)] -> BN (post_relu=False) or a -> BN -> ReLU (post_relu=True).
-    Returns dz (gradient w.r.t. the pre-activation conv output, or w.r.t. a when post_relu)."""
+    Returns dz (gradient w.r.t. the pre-activation conv output, or w.r.t. a when post_relu).
+    ``frozen``: ``st`` holds the running statistics (eval-mode BatchNorm): the layer is a fixed affine."""
     n, c, hw, asn, asc = _planes(a)
     _, _, _, dsn, dsc = _planes(dy)
     d2p, d2sn, d2sc = None, 0, 0
@@ -396,7 +397,7 @@ def bn_backward(dy, a, st: BNState, gamma, dgamma, dbeta, dy2=None, post_relu=Fa
                                       pr, n, c, hw, red.data_ptr(), C.byref(nt), _stream()), "bn_bwd_reduce")
         ntv = nt.value
     coef = torch.empty((c, 3), dtype=torch.float32, device=a.device)
-    check(lib.pcuda_bn_bwd_finalize(red.data_ptr(), ntv, c, n * hw, _ptr(gamma), st.invstd.data_ptr(),
+    check(lib.pcuda_bn_bwd_finalize(red.data_ptr(), ntv, c, -(n * hw) if frozen else n * hw, _ptr(gamma), st.invstd.data_ptr(),
                                     st.mean.data_ptr(), _ptr(dgamma), _ptr(dbeta), 1 if accumulate else 0,
                                     coef.data_ptr(), _stream()), "bn_bwd_finalize")
     dz = torch.empty(a.shape, dtype=torch.float32, device=a.device)

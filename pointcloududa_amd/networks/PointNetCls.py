@@ -101,10 +101,8 @@ class _Tape:
         def bwd():
             if y.g is None:
                 return
-            if not self.training:
-                raise NotImplementedError("backward through eval-mode BatchNorm is not built")
             a.acc(K.bn_backward(y.g, a.t, st, P[bn + ".weight"], self.G(bn + ".weight"), self.G(bn + ".bias"),
-                                post_relu=relu, act_slope=1.0))
+                                post_relu=relu, act_slope=1.0, frozen=not self.training))
         self.steps.append(bwd)
         return y
 

@@ -92,15 +92,16 @@ class _SegEngine:
         """``red``: the second BatchNorm's backward-reduce partials where the kernel that produced ``dy`` already
         computed them (decoder blocks: the classifier's dgrad, the 2x2 fold behind an up-convolution)"""
         x, x2, a0, st0, a1, st1 = S[blk]
+        frozen = not S["training"]      # eval-mode BatchNorm (running statistics): a fixed affine in the backward pass
         dz1 = K.bn_backward(dy, a1, st1, P[blk + ".5.weight"], G(blk + ".5.weight"), G(blk + ".5.bias"), dy2=dy2,
-                            act_slope=SLOPE, red=red if dy2 is None else None)
+                            act_slope=SLOPE, red=red if dy2 is None else None, frozen=frozen)
         if G(blk + ".3.weight") is not None:
             self.ops[blk + ".3"].wgrad(TA(a0, st0.scale, st0.shift), dz1, G(blk + ".3.weight"), G(blk + ".3.bias"), h, w)
         # the second convolution's data gradient IS the first BatchNorm's incoming gradient: its reduce (sum g,
         # sum g * a_hat) rides in the dgrad kernel's epilogue where the geometry allows
         d_y0, red = self.ops[blk + ".3"].dgrad(dz1, P[blk + ".3.weight"], h, w, bnred=(a0, st0))
         dz0 = K.bn_backward(d_y0, a0, st0, P[blk + ".2.weight"], G(blk + ".2.weight"), G(blk + ".2.bias"),
-                            act_slope=SLOPE, red=red)
+                            act_slope=SLOPE, red=red, frozen=frozen)
         if G(blk + ".0.weight") is not None:
             self.ops[blk + ".0"].wgrad(x, dz0, G(blk + ".0.weight"), G(blk + ".0.bias"), h, w, x2=x2)
         if not need_dx:
@@ -177,10 +178,6 @@ class _SegEngine:
 
     # ---------------------------------------------------------------- backward
     def backward(self, P, S, d_logits, d_verts, need_dx):
-        if not S["training"]:
-            # the BatchNorm backward kernels implement the batch-statistics formula; a pass through running statistics
-            # (frozen-BN fine-tuning, input gradients in eval mode) would be silently wrong
-            raise NotImplementedError("backward through Segmentation_model_Point in eval mode is not built")
         wants = S["wants"]       # parameters that required a gradient when the forward pass ran (autograd's rule)
 
         def G(name):

@@ -83,6 +83,17 @@ def _compare_grads(named_hip, grads_ref, tol=TOL, parts=None):
     return worst
 
 
+def _random_running_stats(params, seed):
+    rng = np.random.default_rng(seed + 7)
+    for k in params:
+        if ".in" in k or k.startswith("in"):
+            continue
+        if k.endswith("running_mean"):
+            params[k] = torch.from_numpy(rng.normal(0, 0.2, tuple(params[k].shape)).astype(np.float32))
+        if k.endswith("running_var"):
+            params[k] = torch.from_numpy(rng.uniform(0.5, 1.5, tuple(params[k].shape)).astype(np.float32))
+
+
 def _seg_table(S, cfg, logits, verts):
     """anchor table of one segmenter forward pass: pre-activation outputs of every convolution the HIP engine kept"""
     table = {"classifier": logits.detach().float().cpu()}
@@ -123,10 +134,14 @@ def _pn_table(trace):
     (dict(filters=8, in_channels=3, n_class=5, pointnet=False), True, 2, 64, 1110),
     (dict(filters=16, in_channels=1, n_class=4, pointnet=True, fc_inch=9), False, 3, 128, 1120),
     (dict(filters=4, in_channels=1, n_class=4, pointnet=True, fc_inch=9, extpn=True), False, 2, 128, 1130),
+    # eval mode (negative seed): BatchNorm on its running statistics -- frozen-BatchNorm fine-tuning, unet.py:26,30 under
+    # model.eval() -- is a fixed affine in the backward pass
+    (dict(filters=8, in_channels=3, n_class=5, pointnet=True, fc_inch=9), True, 2, 128, -1140),
 ])
 def test_segmenter_backward_shared_routing(dev, cfg_kw, softmax, b, hw, seed):
     """encoder blocks + max-pool + dense-skip 1x1 convs, the dilated bottleneck and its running sum, the point head,
     the decoder (upsampling fold, zero-copy concat) and the classifier, under the reference's supervised loss"""
+    training, seed = seed > 0, abs(seed)
     from oracle import losses as OL
     from oracle import nets as ON
     from oracle.synth import synth_batch
@@ -134,7 +149,9 @@ def test_segmenter_backward_shared_routing(dev, cfg_kw, softmax, b, hw, seed):
     from pointcloududa_amd.utils import loss as L
     cfg = ON.SegCfg(**cfg_kw)
     params = ON.make_params(ON.seg_param_shapes(cfg), seed)
-    model = _load(Segmentation_model_Point(**cfg_kw), params, dev)
+    if not training:
+        _random_running_stats(params, seed)
+    model = _load(Segmentation_model_Point(**cfg_kw), params, dev).train(training)
     model._keep_state = True
     img, mask, vert, _, _ = synth_batch(b, cfg.in_channels, cfg.n_class, hw, seed=seed + 1)
     x = torch.from_numpy(img).to(dev).requires_grad_(True)
@@ -152,7 +169,7 @@ def test_segmenter_backward_shared_routing(dev, cfg_kw, softmax, b, hw, seed):
     xo = torch.from_numpy(img).requires_grad_(True)
     used, pre = set(), {}
     with ON.anchored(_anchor_from(table, used, pre)):
-        lo2, ve2 = ON.seg_forward(p2, xo, cfg, training=True)
+        lo2, ve2 = ON.seg_forward(p2, xo, cfg, training=training)
     assert used == set(table), set(table) - used
     m2, j2 = (OL.seg_loss_softmax if softmax else OL.seg_loss_sigmoid)(lo2, torch.from_numpy(mask))
     loss2 = m2 + j2 + (OL.batch_nn_loss(ve2, torch.from_numpy(vert)) if cfg.pointnet else 0.0)
@@ -196,16 +213,20 @@ def test_discriminator_backward_shared_routing(dev, inch, ext, hw, seed):
           % (worst[0], worst[1], e_dx, pre.get("tag"), pre.get("e", 0.0)))
 
 
-@pytest.mark.parametrize("ft,ext,b,seed", [(False, False, 16, 1300), (True, True, 12, 1310), (False, False, 4, 1320)])
+@pytest.mark.parametrize("ft,ext,b,seed", [(False, False, 16, 1300), (True, True, 12, 1310), (False, False, 4, 1320),
+                                            (True, True, 6, -1330)])      # negative seed: eval mode (running statistics)
 def test_pointnet_cls_backward_shared_routing(dev, ft, ext, b, seed):
     """PointNetCls (T-Nets, k=1 convolutions + BatchNorm1d + ReLU, max over points, FC + BatchNorm1d) with the ReLU
     masks and the max-over-points argmax shared"""
+    training, seed = seed > 0, abs(seed)
     from oracle import losses as OL
     from oracle import nets as ON
     from pointcloududa_amd.networks import PointNetCls
     from pointcloududa_amd.utils import loss as L
     params = ON.make_params(ON.pointnet_cls_param_shapes(ft, ext=ext), seed)
-    model = _load(PointNetCls(feature_transform=ft, ext=ext, drop=0.0), params, dev)
+    if not training:
+        _random_running_stats(params, seed)
+    model = _load(PointNetCls(feature_transform=ft, ext=ext, drop=0.0), params, dev).train(training)
     model._keep_trace = True
     rng = np.random.default_rng(seed + 1)
     xn = rng.random((b, 3, 300), dtype=np.float32)
@@ -217,7 +238,7 @@ def test_pointnet_cls_backward_shared_routing(dev, ft, ext, b, seed):
     xo = torch.from_numpy(xn).requires_grad_(True)
     used, pre = set(), {}
     with ON.anchored(_anchor_from(table, used, pre)):
-        y2, _, _ = ON.pointnet_cls_forward(p2, xo, feature_transform=ft, ext=ext, drop=0.0, training=True)
+        y2, _, _ = ON.pointnet_cls_forward(p2, xo, feature_transform=ft, ext=ext, drop=0.0, training=training)
     assert used == set(table), set(table) - used
     OL.bce_logits_const(y2, 0.0).backward()
     ref = {k: v.grad for k, v in p2.items() if ON.is_trainable(k)}
