@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out/prof gpurun_out/pmc
-TAG=${TAG:-r02}
+TAG=${TAG:-r03}
 # (kernel durations with the discriminator streams serialised, as in bench.py's roofline pass: concurrent kernels are each billed the shared time)
 PCUDA_DSTREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o $TAG -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/prof_bench_$TAG.log 2>&1
 tail -1 gpurun_out/prof_bench_$TAG.log | cut -c1-300

@@ -3,7 +3,7 @@
 # no trace domains; aggregates per kernel into gpurun_out/${TAG}_pmc_conv.csv.   usage: CASES="g32" TAG=r02 bash scripts/pmc_conv.sh
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-TAG=${TAG:-r02}
+TAG=${TAG:-r03}
 rm -rf gpurun_out/pmcc; mkdir -p gpurun_out/pmcc
 SETS=(
  "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_VALU_MFMA_BUSY_CYCLES"

@@ -4,7 +4,7 @@
 # (case, op) by their order.  Writes gpurun_out/${TAG}_pmc_layers.csv.   usage: TAG=r02 bash scripts/pmc_layers.sh
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-TAG=${TAG:-r02}
+TAG=${TAG:-r03}
 CASES=${CASES:-"g32 g64 g128 g256 b512 d2 d4"}
 rm -rf gpurun_out/pmcl; mkdir -p gpurun_out/pmcl
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -23,7 +23,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     fs = glob.glob("gpurun_out/pmcl/%s/**/*counter_collection.csv" % ctr, recursive=True)
     if not fs: continue
     recs = sorted(csv.DictReader(open(fs[0])), key=lambda r: int(r["Dispatch_Id"]))
-    recs = [r for r in recs if r["Counter_Name"] == ctr and ("igemm" in r["Kernel_Name"] or "wgrad_kernel" in r["Kernel_Name"])]
+    recs = [r for r in recs if r["Counter_Name"] == ctr and ("igemm" in r["Kernel_Name"] or "wgrad_kernel" in r["Kernel_Name"] or "wgrad3_kernel" in r["Kernel_Name"])]
     # conv dispatches arrive in a fixed order: per case 11 forward launches, 11 x stride^2 dgrad launches (one per
     # stride-parity class), 11 weight-gradient launches (their reduce kernels are filtered out above)
     pos = 0
@@ -31,11 +31,12 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         st = GEOM[cs][6]
         for op, cnt in enumerate((11, 11 * st * st, 11)):
             for r in recs[pos:pos + cnt]:
-                assert ("wgrad_kernel" in r["Kernel_Name"]) == (op == 2), (cs, op, r["Kernel_Name"])
+                assert ("wgrad_kernel" in r["Kernel_Name"] or "wgrad3_kernel" in r["Kernel_Name"]) == (op == 2), (cs, op, r["Kernel_Name"])
                 rows[(ci, op)][ctr].append(float(r["Counter_Value"]))
             pos += cnt
     assert pos == len(recs), (pos, len(recs))
 with open("gpurun_out/%s_pmc_layers.csv" % tag, "w") as o:
+    o.write("# FETCH_SIZE counts 64 B per 128-byte line touched, for every load form of these kernels (dwordx4, dword, buffer dword: profiles/r03_fetch_calib.txt): fabric bytes = 2 x FETCH_SIZE + WRITE_SIZE\n")
     o.write("case,op,n,cin,cout,h,w,k,stride,launches,FETCH_SIZE_KB_raw_per_launch,WRITE_SIZE_KB_per_launch,hbm_MB_per_launch(2xFETCH+WRITE),algorithmic_MB\n")
     for (ci, op), d in sorted(rows.items()):
         n, cin, cout, h, w, k, s = GEOM[cases[ci]]

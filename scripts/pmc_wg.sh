@@ -19,7 +19,7 @@ for f in glob.glob('gpurun_out/pmc/p*/**/*counter_collection.csv', recursive=Tru
         k = r['Kernel_Name'][:60]
         agg[k][r['Counter_Name']] += float(r['Counter_Value'])
 for k, d in agg.items():
-    if 'wgrad_kernel' not in k and 'igemm' not in k: continue
+    if 'wgrad' not in k and 'igemm' not in k: continue
     print(k)
     for c, v in sorted(d.items()): print('   %-34s %.4g' % (c, v))
 PY
