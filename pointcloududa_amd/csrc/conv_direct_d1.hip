@@ -393,11 +393,13 @@ __global__ __launch_bounds__(D5R_NT) void d5_fwd_kernel(const D5Params p) {
       const float* xc = xb + (long long)c * p.x_sc;
       const float* wc = swt + c * 16;
       float xv[16];
+      const float* xa[16];
 #pragma unroll
-      for (int t = 0; t < 16; ++t) xv[t] = xc[off[t] >= 0 ? off[t] : 0];
+      for (int t = 0; t < 16; ++t) { xa[t] = xc + (off[t] >= 0 ? off[t] : 0); xv[t] = *xa[t]; }
 #pragma unroll
       for (int t = 0; t < 16; ++t) acc = fmaf(wc[t], off[t] >= 0 ? xv[t] : 0.f, acc);
-      PCUDA_KEEP(xc);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) PCUDA_KEEP(xa[t]);      // (VMEM address rule, common.h: every address outlives its load)
     }
     spart[gsel * p.ow + ox] = acc;
   }

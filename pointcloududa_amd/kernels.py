@@ -602,7 +602,7 @@ def jaccard_fwd(probs, truth, eps):
     """probs fp32 [n,c,...]; truth one-hot, fp32 or uint8, same shape -> (loss scalar, workspace)"""
     _req(probs)
     if truth.dtype not in (torch.float32, torch.uint8):
-        raise TypeError("jaccard: `true` must be a float32 or uint8 one-hot tensor")
+        truth = truth.float()      # the reference casts any dtype: ``true.type(probas.type())`` (loss.py:27)
     _req(truth, truth.dtype)
     if truth.shape != probs.shape:
         raise ValueError("jaccard: `true` %r and probabilities %r differ in shape" % (tuple(truth.shape), tuple(probs.shape)))

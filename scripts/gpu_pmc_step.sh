@@ -15,8 +15,8 @@ tag = os.environ.get("TAG", "r01")
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob("gpurun_out/pmc/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        name = name.split("<")[0] if not name.startswith(("igemm", "wgrad_kernel", "(anonymous namespace)::wgrad3")) else name
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+        name = name.split("<")[0] if not name.startswith(("igemm", "wgrad_kernel", "wgrad3_kernel")) else name
         a = agg[name[:80]][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
 rows = []
 for k, d in agg.items():

@@ -25,6 +25,27 @@ def test_direct_kernels_keep_load_addresses_alive():
     assert not bad, "loads whose destination overlaps their address: %s" % bad[:4]
 
 
+# loads of that form the compiler still emits in the LDS-free kernel families (one process per GPU never showed a wrong
+# result from them; a GPU shared by two processes is an unsupported deployment: INTEGRATION.md section 4).  The counts
+# are an allow-list: a compiler upgrade or a new kernel that ADDS such loads fails this test instead of going unnoticed.
+ALLOWED = {"pointwise.s": 11, "losses.s": 15, "dense.s": 20, "sampler.s": 56, "conv1d_f32.s": 10, "optim.s": 0}
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc (cross-compiles without a GPU)")
+def test_lds_free_kernel_families_do_not_grow_the_pattern():
+    srcs = " ".join(k[:-2] + ".hip" for k in ALLOWED)
+    r = subprocess.run(["make", "-C", CSRC, "isa", "ISA_SRCS=" + srcs], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import vmem_overlap_scan as V
+    got = {}
+    for f, _, n, _ in V.scan(os.path.join(CSRC, "build", "isa")):
+        got[f] = got.get(f, 0) + n
+    for f, lim in ALLOWED.items():
+        assert f in got, "no assembly for " + f
+        assert got[f] <= lim, "%s: %d loads whose destination overlaps their address (allow-list: %d)" % (f, got[f], lim)
+
+
 def test_scanner_sees_the_pattern(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import vmem_overlap_scan as V

@@ -47,8 +47,10 @@ def _check_grads(mod, g, tol, tol_elem=None):
             continue
         ref_norm = float(g["gnorm/" + k])
         got_norm = float(p.grad.double().norm())
-        tn = max(2e-2, 3.0 * float(g["gnspread/" + k])) if "gnspread/" + k in g else tol
-        te = max(2e-2, 3.0 * float(g["gspread/" + k])) if "gspread/" + k in g else tol_elem
+        # (capped: a parameter whose reference spread is 20 % is not excused beyond 25 % -- a real backward bug confined to
+        # such a layer must not pass; the shared-routing twins of test_backward_exact_gpu.py hold every one of them to 1e-4)
+        tn = max(2e-2, min(3.0 * float(g["gnspread/" + k]), 0.25)) if "gnspread/" + k in g else tol
+        te = max(2e-2, min(3.0 * float(g["gspread/" + k]), 0.25)) if "gspread/" + k in g else tol_elem
         assert abs(got_norm - ref_norm) <= tn * ref_norm + floor, (k, got_norm, ref_norm, tn)
         if ref_norm < 10 * floor:
             continue
