@@ -818,6 +818,45 @@ def gold_seg_full512():
              seed=510, full_tensors=False)
 
 
+def gold_seg_variants():
+    """Constructor variants the reference offers and its scripts never use (unet.py:25,29 batchnorm=False; :139-162
+    Segmentation_model(feature_dis=True)): forward + backward of the REFERENCE modules."""
+    gold_seg("seg_small_nobn", ON.SegCfg(filters=4, in_channels=1, n_class=4, pointnet=True, fc_inch=9, batchnorm=False), b=2,
+             hw=128, seed=130, full_tensors=True)
+    # feature_dis: classifier2 takes 512 channels, i.e. filters = 32; a 64x64 input keeps the fixture small
+    from networks.unet import Segmentation_model
+    cfg = ON.SegCfg(filters=32, in_channels=1, n_class=4, pointnet=False, feature_dis=True)
+    params = ON.make_params(ON.seg_param_shapes(cfg), 140)
+    img, mask, _, _, _ = synth_batch(2, 1, 4, 64, seed=141)
+    ya = torch.tensor(mask, dtype=torch.float32)
+
+    def total(lo, o2):      # the supervised loss on the logits + a smooth loss on the second head (it has no loss in the reference)
+        pr = torch.sigmoid(lo)
+        return torch.nn.BCELoss()(pr, ya) + ref_loss.jaccard_loss(logits=pr, true=ya, activation=False) + 0.5 * (o2 * o2).mean()
+    ref = load_into(Segmentation_model(filters=32, in_channels=1, n_class=4, feature_dis=True), params).train()
+    xr = torch.from_numpy(img).clone().requires_grad_(True)
+    lo, o2, none = ref(xr)
+    assert none is None
+    loss = total(lo, o2)
+    loss.backward()
+    p2 = {k: (v.clone().requires_grad_(True) if ON.is_trainable(k) else v.clone()) for k, v in params.items()}
+    xo = torch.from_numpy(img).clone().requires_grad_(True)
+    lo2, o22 = ON.seg_forward(p2, xo, cfg, training=True)
+    total(lo2, o22).backward()
+    close(lo2, lo, 1e-5, "featdis logits"); close(o22, o2, 1e-5, "featdis output2"); close(xo.grad, xr.grad, 1e-4, "featdis dx")
+    out = {"seed": np.int64(140), "b": np.int64(2), "hw": np.int64(64), "loss": np.float64(loss.item()),
+           "logits": lo.detach().numpy(), "out2": o2.detach().numpy(), "dx": xr.grad.numpy()}
+    for k, pp in ref.named_parameters():
+        if pp.grad is None:
+            out["gnone/" + k] = np.int64(1)
+            continue
+        close(p2[k].grad, pp.grad, 2e-4, "featdis grad " + k)
+        out["gnorm/" + k] = np.float64(pp.grad.double().norm().item())
+        out["gs/" + k] = sample(pp.grad, 512)
+    np.savez_compressed(os.path.join(GOLD, "seg_featdis.npz"), **out)
+    print("seg_featdis ok  loss", loss.item())
+
+
 def gold_mmwhs_flags():
     """The optional branches of the MM-WHS loop, two fixtures: (a) -d1 -d2 -d4 -etpls -Tetpls (both entropy terms in the
     losses), (b) -d2 -d4aux -sgd (point head trained without d4; SGD on the segmenter)."""
@@ -887,6 +926,7 @@ def main():
     gold_step_mmwhs("step_segonly_small", ON.SegCfg(filters=4, in_channels=3, n_class=5, pointnet=False), b=4, hw=128,
                     seed=950, d1=False, d2=False, d4=False)
     gold_mmwhs_flags()
+    gold_seg_variants()
     if os.environ.get("GOLDEN_FULL", "1") == "1":
         full = ON.SegCfg(filters=32, in_channels=1, n_class=4, pointnet=True, fc_inch=121)
         gold_seg("seg_full256", full, b=2, hw=256, seed=500, full_tensors=False)
@@ -898,6 +938,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "pncls":    # only the PointNetCls fixtures
         gold_pncls("pncls", False, False, b=16, seed=300)
         gold_pncls("pncls_ft_ext", True, True, b=12, seed=310)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "variants":
+        gold_seg_variants()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "full512":
         gold_seg_full512()

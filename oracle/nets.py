@@ -75,6 +75,7 @@ class SegCfg:
     fc_inch: int = 81
     extpn: bool = False
     batchnorm: bool = True
+    feature_dis: bool = False      # Segmentation_model(feature_dis=True): classifier2 on the bottleneck output (unet.py:147-158)
 
 
 def seg_param_shapes(cfg: SegCfg) -> Dict[str, Tuple[int, ...]]:
@@ -129,6 +130,8 @@ def seg_param_shapes(cfg: SegCfg) -> Dict[str, Tuple[int, ...]]:
         else:
             conv(blk + ".2", co, co, 3)
     conv("classifier", cfg.n_class, f, 1)
+    if cfg.feature_dis:
+        conv("classifier2", cfg.n_class, 512, 1)
     return shapes
 
 
@@ -321,6 +324,8 @@ def seg_forward(p: Params, x, cfg: SegCfg, training: bool = True):
     verts = _point_head(p, bott, cfg) if cfg.pointnet else None
     out = _decoder(p, bott, skips, cfg, training)
     logits = _conv(p, "classifier", out)
+    if cfg.feature_dis:      # Segmentation_model.forward (unet.py:152-162) -> (logits, output2)
+        return logits, _conv(p, "classifier2", bott)
     return logits, verts
 
 

@@ -27,11 +27,15 @@ SLOPE = 0.01   # nn.LeakyReLU() default used throughout unet.py
 class _SegEngine:
     """forward / hand-written backward of Segmentation_model_Point over a name->tensor dict"""
 
-    def __init__(self, filters, in_channels, n_block, depth, n_class, pointnet, fc_inch, extpn=False):
+    def __init__(self, filters, in_channels, n_block, depth, n_class, pointnet, fc_inch, extpn=False, batchnorm=True,
+                 feature_dis=False):
         f = filters
         self.f, self.cin, self.nb, self.depth, self.ncls, self.pointnet, self.fc_inch = \
             f, in_channels, n_block, depth, n_class, pointnet, fc_inch
         self.extpn = bool(extpn and pointnet)
+        self.bn = bool(batchnorm)
+        self.c2 = ".3" if self.bn else ".2"      # index of a block's second convolution inside its nn.Sequential (unet.py:23-30)
+        self.feature_dis = bool(feature_dis)
         self.after_deep_grads = None      # optional hook of the backward pass (see ``backward``)
         ops = {}
         for i in range(n_block):
@@ -39,7 +43,7 @@ class _SegEngine:
             ci = in_channels if i == 0 else f * 2 ** (i - 1)
             blk = "encoder.encoder%d" % (i + 1)
             ops[blk + ".0"] = ConvOp(ci, co, 3, pad=1)
-            ops[blk + ".3"] = ConvOp(co, co, 3, pad=1)
+            ops[blk + self.c2] = ConvOp(co, co, 3, pad=1)
             if i > 0:
                 ops["encoder.conv1_%d.0" % (i + 1)] = ConvOp(ci * 3, co, 1)
         co, ci = f * 2 ** n_block, f * 2 ** (n_block - 1)
@@ -58,8 +62,10 @@ class _SegEngine:
             ops["decoder.decoder1_%d.1" % (i + 1)] = ConvOp(2 * co, co, 3, pad=1, in_up=True)
             blk = "decoder.decoder2_%d" % (i + 1)
             ops[blk + ".0"] = ConvOp(2 * co, co, 3, pad=1)
-            ops[blk + ".3"] = ConvOp(co, co, 3, pad=1)
+            ops[blk + self.c2] = ConvOp(co, co, 3, pad=1)
         ops["classifier"] = ConvOp(f, n_class, 1)
+        if self.feature_dis:                                          # unet.py:147-148: hard-wired 512 input channels
+            ops["classifier2"] = ConvOp(512, n_class, 1)
         self.ops = ops
 
     # ---------------------------------------------------------------- helpers
@@ -79,6 +85,11 @@ class _SegEngine:
     def _dc_fwd(self, P, blk, x, x2, h, w, training, S):
         """conv3x3 -> LeakyReLU -> BN -> conv3x3 -> LeakyReLU -> BN (unet.py:23-30,116-125)."""
         n = (x.t if isinstance(x, TA) else x).shape[0]
+        if not self.bn:      # batchnorm=False (unet.py:25,29): conv -> LeakyReLU -> conv -> LeakyReLU
+            a0, _, _ = self.ops[blk + ".0"].forward(x, P[blk + ".0.weight"], P[blk + ".0.bias"], SLOPE, h, w, x2=x2)
+            a1, _, _ = self.ops[blk + ".2"].forward(a0, P[blk + ".2.weight"], P[blk + ".2.bias"], SLOPE, h, w)
+            S[blk] = (x, x2, a0, None, a1, None)
+            return a1
         a0, part, nt = self.ops[blk + ".0"].forward(x, P[blk + ".0.weight"], P[blk + ".0.bias"], SLOPE, h, w, x2=x2,
                                                     want_stats=training)
         st0 = self._bn(P, blk + ".2", part, nt, n * h * w, training, a0.device)
@@ -92,6 +103,12 @@ class _SegEngine:
         """``red``: the second BatchNorm's backward-reduce partials where the kernel that produced ``dy`` already
         computed them (decoder blocks: the classifier's dgrad, the 2x2 fold behind an up-convolution)"""
         x, x2, a0, st0, a1, st1 = S[blk]
+        if not self.bn:
+            dz1 = K.lrelu_bwd(dy, a1, SLOPE, dy2=dy2)
+            if G(blk + ".2.weight") is not None:
+                self.ops[blk + ".2"].wgrad(a0, dz1, G(blk + ".2.weight"), G(blk + ".2.bias"), h, w)
+            dz0 = K.lrelu_bwd(self.ops[blk + ".2"].dgrad(dz1, P[blk + ".2.weight"], h, w), a0, SLOPE)
+            return self._dc_bwd_first(P, G, blk, x, x2, dz0, h, w, need_dx)
         frozen = not S["training"]      # eval-mode BatchNorm (running statistics): a fixed affine in the backward pass
         dz1 = K.bn_backward(dy, a1, st1, P[blk + ".5.weight"], G(blk + ".5.weight"), G(blk + ".5.bias"), dy2=dy2,
                             act_slope=SLOPE, red=red if dy2 is None else None, frozen=frozen)
@@ -102,6 +119,10 @@ class _SegEngine:
         d_y0, red = self.ops[blk + ".3"].dgrad(dz1, P[blk + ".3.weight"], h, w, bnred=(a0, st0))
         dz0 = K.bn_backward(d_y0, a0, st0, P[blk + ".2.weight"], G(blk + ".2.weight"), G(blk + ".2.bias"),
                             act_slope=SLOPE, red=red, frozen=frozen)
+        return self._dc_bwd_first(P, G, blk, x, x2, dz0, h, w, need_dx)
+
+    def _dc_bwd_first(self, P, G, blk, x, x2, dz0, h, w, need_dx):
+        """weight and input gradients of a block's first convolution"""
         if G(blk + ".0.weight") is not None:
             self.ops[blk + ".0"].wgrad(x, dz0, G(blk + ".0.weight"), G(blk + ".0.bias"), h, w, x2=x2)
         if not need_dx:
@@ -164,6 +185,11 @@ class _SegEngine:
                 raise ValueError("fc_inch=%d does not match the %dx%d head output" % (self.fc_inch, h - 5, w - 5))
             verts = K.linear_fwd(flat, P["pointNet.final_fc.weight"], P["pointNet.final_fc.bias"]).view(n, 300, 3)
             S["head"] = (hin, hc, flat)
+        out2 = None
+        if self.feature_dis:                                          # unet.py:157-158: classifier2(output_bottleneck)
+            S["bsum"] = bsum
+            out2, _, _ = self.ops["classifier2"].forward(bsum, P["classifier2.weight"], P["classifier2.bias"], 1.0, h, w)
+        S["out2"] = out2
         prev, ph, pw = bsum, h, w
         for i in reversed(range(nb)):                                 # unet.py:128-136
             up = "decoder.decoder1_%d.1" % (i + 1)
@@ -177,7 +203,7 @@ class _SegEngine:
         return logits, verts, S
 
     # ---------------------------------------------------------------- backward
-    def backward(self, P, S, d_logits, d_verts, need_dx):
+    def backward(self, P, S, d_logits, d_verts, need_dx, d_out2=None):
         wants = S["wants"]       # parameters that required a gradient when the forward pass ran (autograd's rule)
 
         def G(name):
@@ -193,7 +219,10 @@ class _SegEngine:
             # every decoder block's incoming gradient has ONE producer (the classifier's dgrad, then the 2x2 fold behind
             # each up-convolution): that kernel also computes the block's second BatchNorm's backward-reduce partials
             bn_of = lambda i: (S["decoder.decoder2_%d" % (i + 1)][4], S["decoder.decoder2_%d" % (i + 1)][5])
-            d_cur, red = self.ops["classifier"].dgrad(d_logits, P["classifier.weight"], H, W, bnred=bn_of(0))
+            if self.bn:
+                d_cur, red = self.ops["classifier"].dgrad(d_logits, P["classifier.weight"], H, W, bnred=bn_of(0))
+            else:
+                d_cur, red = self.ops["classifier"].dgrad(d_logits, P["classifier.weight"], H, W), None
             for i in range(nb):
                 oh, ow = H >> i, W >> i
                 d_skips[i], d_u = self._dc_bwd(P, G, "decoder.decoder2_%d" % (i + 1), d_cur, None, oh, ow, S, True, red=red)
@@ -201,12 +230,21 @@ class _SegEngine:
                 if G(up + ".weight") is not None:
                     self.ops[up].wgrad(S[up], d_u, G(up + ".weight"), G(up + ".bias"), oh, ow)
                 d_up = self.ops[up].dgrad(d_u, P[up + ".weight"], oh, ow)
-                if i + 1 < nb:
+                if i + 1 < nb and self.bn:
                     d_cur, red = K.upsample2_bwd(d_up, bnred=bn_of(i + 1))
                 else:
                     d_cur, red = K.upsample2_bwd(d_up), None
             d_bsum = d_cur
         h, w = H >> nb, W >> nb
+        if self.feature_dis and d_out2 is not None:
+            d_out2 = d_out2.contiguous()
+            op2 = self.ops["classifier2"]
+            if G("classifier2.weight") is not None:
+                op2.wgrad(S["bsum"], d_out2, G("classifier2.weight"), G("classifier2.bias"), h, w)
+            if d_bsum is None:
+                d_bsum = op2.dgrad(d_out2, P["classifier2.weight"], h, w)
+            else:
+                op2.dgrad(d_out2, P["classifier2.weight"], h, w, dx=d_bsum, accumulate=True)
         if self.pointnet and d_verts is not None:
             hin, hc, flat = S["head"]
             d_v = d_verts.contiguous().view(n * 300, 3)
@@ -253,7 +291,7 @@ class _SegEngine:
                 dzc = K.lrelu_bwd(d_t, t, SLOPE)
                 if G(c1 + ".weight") is not None:
                     self.ops[c1].wgrad(y, dzc, G(c1 + ".weight"), G(c1 + ".bias"), hi, wi, x2=res_prev)
-                d_y = torch.empty(y.t.shape, dtype=torch.float32, device=dzc.device)
+                d_y = torch.empty((y.t if isinstance(y, TA) else y).shape, dtype=torch.float32, device=dzc.device)
                 dB = torch.empty(res_prev.shape, dtype=torch.float32, device=dzc.device)
                 self.ops[c1].dgrad(dzc, P[c1 + ".weight"], hi, wi, dx=d_y, dx2=dB)
             else:
@@ -277,14 +315,18 @@ class _SegFn(torch.autograd.Function):
         if getattr(module, "_keep_state", False):     # tests (shared-routing backward checks)
             module._last_S = S
         ctx.set_materialize_grads(False)
-        if verts is None:
-            return logits
-        return logits, verts
+        out2 = S.get("out2")
+        ctx.layout = (verts is not None, out2 is not None)
+        outs = [logits] + ([verts] if verts is not None else []) + ([out2] if out2 is not None else [])
+        return outs[0] if len(outs) == 1 else tuple(outs)
 
     @staticmethod
-    def backward(ctx, d_logits, d_verts=None):
+    def backward(ctx, d_logits, *rest):
+        rest = list(rest)
+        d_verts = rest.pop(0) if ctx.layout[0] else None
+        d_out2 = rest.pop(0) if ctx.layout[1] else None
         with K.deferred_wgrad_reduces():      # (PCUDA_BATCH_REDUCE=1: the layers' split-K reduces in two launches instead of 43)
-            dx = ctx.module._engine.backward(ctx.P, ctx.S, d_logits, d_verts, ctx.needs_input_grad[1])
+            dx = ctx.module._engine.backward(ctx.P, ctx.S, d_logits, d_verts, ctx.needs_input_grad[1], d_out2=d_out2)
         ctx.S = None
         return (None, dx) + (None,) * (len(ctx.needs_input_grad) - 2)
 
@@ -364,8 +406,6 @@ class Segmentation_model_Point(nn.Module):
         if multicuda:
             raise NotImplementedError("multicuda (2-GPU model split, unet.py:180-192) is replaced by data "
                                       "parallelism: see pointcloududa_amd.parallel")
-        if not batchnorm:
-            raise NotImplementedError("batchnorm=False is never used by the reference scripts")
         self._pointnet = pointnet
         self.encoder = Encoder(filters=filters, in_channels=in_channels, n_block=n_block, batch_norm=batchnorm)
         self.bottleneck = Bottleneck(filters=filters, n_block=n_block, depth=bottleneck_depth)
@@ -375,7 +415,12 @@ class Segmentation_model_Point(nn.Module):
         self.classifier = Conv2d(filters, n_class, kernel_size=(1, 1))
         self._initialize_weights(heinit=heinit)
         self._multicuda = False
-        self._engine = _SegEngine(filters, in_channels, n_block, bottleneck_depth, n_class, pointnet, fc_inch, extpn)
+        self._build_engine(filters, in_channels, n_block, bottleneck_depth, n_class, pointnet, fc_inch, extpn, batchnorm)
+
+    def _build_engine(self, filters, in_channels, n_block, bottleneck_depth, n_class, pointnet, fc_inch, extpn, batchnorm,
+                      feature_dis=False):
+        self._engine = _SegEngine(filters, in_channels, n_block, bottleneck_depth, n_class, pointnet, fc_inch, extpn,
+                                  batchnorm=batchnorm, feature_dis=feature_dis)
         for op in self._engine.ops.values():
             op.owner = self
 
@@ -408,7 +453,10 @@ class Segmentation_model_Point(nn.Module):
     def forward(self, x, features_out=True, print_shape=False):
         params = [p for p in self.parameters()]
         out = _SegFn.apply(self, x, *params)
-        logits, verts = (out if isinstance(out, tuple) else (out, None))
+        out = list(out) if isinstance(out, tuple) else [out]
+        logits = out.pop(0)
+        verts = out.pop(0) if self._pointnet else None
+        self._out2 = out.pop(0) if out else None
         if print_shape:
             print("output: {}".format(logits.size()))
             if verts is not None:
@@ -419,10 +467,28 @@ class Segmentation_model_Point(nn.Module):
 
 
 class Segmentation_model(Segmentation_model_Point):
-    """unet.py:139-162 (not used by the reference scripts): the same network without the point head."""
+    """unet.py:139-162 (not used by the reference scripts): the same network without the point head.
+    ``feature_dis=True`` adds ``classifier2`` -- a 1x1 convolution with 512 input channels, as hard-wired in the reference
+    (:147-148; i.e. filters = 32, n_block = 4) -- on the bottleneck output; forward then returns (logits, output2, None)."""
 
     def __init__(self, filters=32, in_channels=3, n_block=4, bottleneck_depth=4, n_class=4, feature_dis=False):
-        if feature_dis:
-            raise NotImplementedError("feature_dis (a second classifier on the bottleneck) is not built")
         super().__init__(filters=filters, in_channels=in_channels, n_block=n_block,
                          bottleneck_depth=bottleneck_depth, n_class=n_class, pointnet=False)
+        self._feature_dis = bool(feature_dis)
+        for m in self.modules():      # the reference's Segmentation_model has no init pass (unet.py:140-150): torch's defaults
+            if isinstance(m, nn.Conv2d):
+                m.reset_parameters()
+        if feature_dis:
+            if filters * 2 ** n_block != 512:
+                raise ValueError("feature_dis: classifier2 takes 512 channels (unet.py:148); the bottleneck has %d"
+                                 % (filters * 2 ** n_block))
+            self.classifier2 = Conv2d(512, n_class, kernel_size=(1, 1))
+            # (the reference builds classifier2 AFTER its constructor has no init pass: default nn.Conv2d init stays)
+            self._build_engine(filters, in_channels, n_block, bottleneck_depth, n_class, False, 81, False, True,
+                               feature_dis=True)
+
+    def forward(self, x, features_out=True):
+        logits, _, _ = super().forward(x, features_out=True)
+        if features_out:
+            return logits, (self._out2 if self._feature_dis else None), None
+        return logits

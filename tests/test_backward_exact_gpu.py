@@ -100,7 +100,7 @@ def _seg_table(S, cfg, logits, verts):
     for blk in ["encoder.encoder%d" % (i + 1) for i in range(cfg.n_block)] + \
                ["decoder.decoder2_%d" % (i + 1) for i in range(cfg.n_block)]:
         _, _, a0, _, a1, _ = S[blk]
-        table[blk + ".0"], table[blk + ".3"] = _unlrelu(a0, 0.01), _unlrelu(a1, 0.01)
+        table[blk + ".0"], table[blk + (".3" if cfg.batchnorm else ".2")] = _unlrelu(a0, 0.01), _unlrelu(a1, 0.01)
     for i in range(1, cfg.n_block):
         c1 = "encoder.conv1_%d.0" % (i + 1)
         table[c1] = _unlrelu(S[c1][2], 0.01)
@@ -137,6 +137,7 @@ def _pn_table(trace):
     # eval mode (negative seed): BatchNorm on its running statistics -- frozen-BatchNorm fine-tuning, unet.py:26,30 under
     # model.eval() -- is a fixed affine in the backward pass
     (dict(filters=8, in_channels=3, n_class=5, pointnet=True, fc_inch=9), True, 2, 128, -1140),
+    (dict(filters=4, in_channels=1, n_class=4, pointnet=True, fc_inch=9, batchnorm=False), False, 2, 128, 1150),
 ])
 def test_segmenter_backward_shared_routing(dev, cfg_kw, softmax, b, hw, seed):
     """encoder blocks + max-pool + dense-skip 1x1 convs, the dilated bottleneck and its running sum, the point head,
@@ -175,9 +176,12 @@ def test_segmenter_backward_shared_routing(dev, cfg_kw, softmax, b, hw, seed):
     loss2 = m2 + j2 + (OL.batch_nn_loss(ve2, torch.from_numpy(vert)) if cfg.pointnet else 0.0)
     loss2.backward()
     ref = {k: v.grad for k, v in p2.items() if ON.is_trainable(k)}
-    worst = _compare_grads(model.named_parameters(), ref)
+    # (batchnorm=False: nothing normalises the activations, the logits saturate the sigmoid and the classifier's bias gradient
+    # is a sum of 32k terms that cancel to a hundredth of their magnitude: 3e-4 there)
+    tol = TOL if cfg.batchnorm else 3e-4
+    worst = _compare_grads(model.named_parameters(), ref, tol=tol)
     e_dx = rel_err(x.grad, xo.grad)
-    assert e_dx < TOL, e_dx
+    assert e_dx < tol, e_dx
     print("worst parameter gradient error %s %.2e, dx %.2e; worst layer-local forward error %s %.2e"
           % (worst[0], worst[1], e_dx, pre.get("tag"), pre.get("e", 0.0)))
 

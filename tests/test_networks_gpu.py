@@ -71,6 +71,9 @@ def _check_grads(mod, g, tol, tol_elem=None):
     ("seg_full512", dict(filters=32, in_channels=1, n_class=4, pointnet=True, fc_inch=729), False),
     # extpn=True: two extra 3x3 convolutions in front of the point head (unet.py:81-83,90-92)
     ("seg_small_extpn", dict(filters=4, in_channels=1, n_class=4, pointnet=True, fc_inch=9, extpn=True), False),
+    # batchnorm=False (unet.py:25,29): conv -> LeakyReLU -> conv -> LeakyReLU blocks; a constructor variant the reference
+    # offers and its scripts never use
+    ("seg_small_nobn", dict(filters=4, in_channels=1, n_class=4, pointnet=True, fc_inch=9, batchnorm=False), False),
 ])
 def test_segmenter_vs_reference_golden(dev, tag, cfg_kw, softmax):
     """forward + backward under the reference's own supervised loss (train_mscmrseg.py:202-209 /
@@ -185,6 +188,33 @@ def test_pointnet_cls_vs_reference_golden(dev, tag, ft, ext):
     for k in params:
         if "bn/" + k in g:
             assert rel_err(sd[k], g["bn/" + k]) < 1e-3, k
+
+
+def test_segmentation_model_feature_dis_vs_reference_golden(dev):
+    """Segmentation_model(feature_dis=True) (unet.py:139-162): a second 1x1 classifier on the bottleneck output, returned
+    as the second element of forward's tuple; golden from the reference module (filters = 32: classifier2 is hard-wired to
+    512 input channels), loss = the supervised loss on the logits + 0.5 mean(output2^2)."""
+    from oracle import nets as ON
+    from oracle.synth import synth_batch
+    from pointcloududa_amd.networks.unet import Segmentation_model
+    from pointcloududa_amd.utils import loss as L
+    g = np.load(os.path.join(GOLD, "seg_featdis.npz"))
+    cfg = ON.SegCfg(filters=32, in_channels=1, n_class=4, pointnet=False, feature_dis=True)
+    params = ON.make_params(ON.seg_param_shapes(cfg), int(g["seed"]))
+    model = _load(Segmentation_model(filters=32, in_channels=1, n_class=4, feature_dis=True), params, dev)
+    assert list(model.state_dict().keys()) == list(params.keys())
+    img, mask, _, _, _ = synth_batch(int(g["b"]), 1, 4, int(g["hw"]), seed=int(g["seed"]) + 1)
+    x = torch.from_numpy(img).to(dev).requires_grad_(True)
+    logits, out2, none = model(x)
+    assert none is None and model(x, features_out=False).shape == logits.shape
+    l_main, l_jac = L.seg_loss(logits, torch.from_numpy(mask).to(dev), "sigmoid")
+    l2 = 0.5 * (out2 * out2).mean()      # (test-side loss on the second head: plain torch ops feeding the HIP node's backward)
+    (l_main + l_jac + l2).backward()
+    assert rel_err(logits, g["logits"]) < 1e-3 and rel_err(out2, g["out2"]) < 1e-3
+    assert abs(float((l_main + l_jac + l2).detach()) - float(g["loss"])) < 1e-4 * max(1.0, abs(float(g["loss"])))
+    _check_grads(model, g, 5e-2, 1e-1)
+    for k in ("classifier2.weight", "classifier2.bias"):
+        assert rel_err(_strided(dict(model.named_parameters())[k].grad, 512), g["gs/" + k]) < 2e-2, k
 
 
 def test_backward_through_eval_mode_batchnorm(dev):
