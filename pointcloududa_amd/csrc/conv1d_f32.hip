@@ -31,33 +31,61 @@ struct GemmP {
   int M, K, L, ncols, cin;
 };
 
-// C[i][j] = sum_k A[i][k] B[k][j];  TA = false: A[i][k] = w[i*cin + k] (forward), true: A[i][k] = w[k*cin + i] (dgrad)
-template <int MB, bool TA>
+// C[i][j] = sum_k A[i][k] B[k][j];  TA = false: A[i][k] = w[i*cin + k] (forward), true: A[i][k] = w[k*cin + i] (dgrad).
+// VEC: 16-byte global loads (L, K and M multiples of 4, 16-byte aligned tensors: every PointNetCls layer but the 3- and
+// 8-channel ones) and a 32-deep stage; otherwise dword loads with bounds checks and a 16-deep stage.
+template <int MB, bool TA, bool VEC>
 __global__ __launch_bounds__(256) void c1d_gemm_kernel(const GemmP p) {
   constexpr int BM = 64 * MB;       // rows per workgroup: wave (w >> 1) owns MB row blocks of 32, wave (w & 1) a column half
-  constexpr int PA = BM + 1, PB = BN + 1;
-  __shared__ float As[BK][PA];
-  __shared__ float Bs[BK][PB];
+  constexpr int KS = VEC ? 32 : BK; // reduction depth per stage
+  constexpr int PA = (VEC && TA) ? BM + 4 : BM + 1, PB = VEC ? BN + 4 : BN + 1;
+  __shared__ __attribute__((aligned(16))) float As[KS][PA];
+  __shared__ __attribute__((aligned(16))) float Bs[KS][PB];
   __shared__ float red[2][BM][2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int j0 = blockIdx.x * BN, i0 = blockIdx.y * BM;
   const int ch = w & 1, rp = w >> 1;
   const int r = lane & 31, h = lane >> 5;
 
-  // B-tile loader: lane column jj, k rows kb + 4q
+  // ---- scalar loaders (VEC = false): B lane column jj, k rows kb + 4q; A see below
   const int jj = tid & 63, kb = tid >> 6;
   const int jcol = j0 + jj;
   const bool jok = jcol < p.ncols;
   const int jb = jok ? jcol / p.L : 0, jl = jok ? jcol - jb * p.L : 0;
   const float* xcol = p.x + ((long long)jb * p.K * p.L + jl);
-  // A-tile loader
-  //   TA = false: lane k index tid & 15, rows (tid >> 4) + 16q      (k contiguous in memory)
-  //   TA = true : lane row index tid & 63 (+ 64q), k rows (tid >> 6) + 4q'   (rows contiguous in memory)
-  constexpr int AL = BM * BK / 256;
-  float av[AL], bv[4];
+  // ---- vector loaders (VEC = true): B lane = 4 columns (tid & 15), k rows (tid >> 4) + 16q;
+  //      A, TA = false: 4 k's (tid & 7), rows (tid >> 3) + 32q (transposed scalar LDS stores);
+  //      A, TA = true : 4 rows (tid % (BM / 4)), k rows tid / (BM / 4) + (1024 / BM) q (16-byte LDS stores)
+  const int vj = (tid & 15) * 4, vk = tid >> 4;
+  const int vcol = j0 + vj;
+  const bool vok = vcol < p.ncols;          // (ncols % 4 == 0: a quad is inside or outside as a whole, and inside one batch row)
+  const int vb = vok ? vcol / p.L : 0, vl = vok ? vcol - vb * p.L : 0;
+  const float* xq = p.x + ((long long)vb * p.K * p.L + vl);
+  constexpr int AL = VEC ? BM * 32 / 1024 : BM * BK / 256;      // A loads per thread and stage (float4 / float)
+  constexpr int BL = VEC ? 2 : 4;
+  float av[VEC ? 1 : AL], bv[VEC ? 1 : BL];
+  f32x4 av4[VEC ? AL : 1], bv4[VEC ? BL : 1];
   auto load = [&](int k0) {
+    if (VEC) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < BL; ++q) {
+        const int k = k0 + vk + 16 * q;
+        bv4[q] = (vok && k < p.K) ? *(const f32x4*)(xq + (long long)k * p.L) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int q = 0; q < AL; ++q) {
+        if (!TA) {
+          const int k = k0 + (tid & 7) * 4, gi = i0 + (tid >> 3) + 32 * q;
+          av4[q] = (gi < p.M && k < p.K) ? *(const f32x4*)(p.w + (long long)gi * p.cin + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+          const int gi = i0 + (tid % (BM / 4)) * 4, k = k0 + tid / (BM / 4) + (1024 / BM) * q;
+          av4[q] = (gi < p.M && k < p.K) ? *(const f32x4*)(p.w + (long long)k * p.cin + gi) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      return;
+    }
+#pragma unroll
+    for (int q = 0; q < BL; ++q) {
       const int k = k0 + kb + 4 * q;
       bv[q] = (jok && k < p.K) ? xcol[(long long)k * p.L] : 0.f;
     }
@@ -72,8 +100,23 @@ __global__ __launch_bounds__(256) void c1d_gemm_kernel(const GemmP p) {
     }
   };
   auto commit = [&]() {
+    if (VEC) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) Bs[kb + 4 * q][jj] = bv[q];
+      for (int q = 0; q < BL; ++q) *(f32x4*)&Bs[vk + 16 * q][vj] = bv4[q];
+#pragma unroll
+      for (int q = 0; q < AL; ++q) {
+        if (!TA) {
+          const int k = (tid & 7) * 4, i = (tid >> 3) + 32 * q;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) As[k + e][i] = av4[q][e];
+        } else {
+          *(f32x4*)&As[tid / (BM / 4) + (1024 / BM) * q][(tid % (BM / 4)) * 4] = av4[q];
+        }
+      }
+      return;
+    }
+#pragma unroll
+    for (int q = 0; q < BL; ++q) Bs[kb + 4 * q][jj] = bv[q];
 #pragma unroll
     for (int q = 0; q < AL; ++q) {
       int i, k;
@@ -90,12 +133,12 @@ __global__ __launch_bounds__(256) void c1d_gemm_kernel(const GemmP p) {
     for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
 
   load(0);
-  for (int k0 = 0; k0 < p.K; k0 += BK) {
+  for (int k0 = 0; k0 < p.K; k0 += KS) {
     __syncthreads();          // the previous stage's MFMAs are done with the tiles
     commit();
     __syncthreads();
-    if (k0 + BK < p.K) load(k0 + BK);      // in flight during this stage's MFMAs
-    const int npair = min(BK, p.K - k0 + 1) >> 1;      // k pairs that hold data (the rest of the tile is zero)
+    if (k0 + KS < p.K) load(k0 + KS);      // in flight during this stage's MFMAs
+    const int npair = min(KS, p.K - k0 + 1) >> 1;      // k pairs that hold data (the rest of the tile is zero)
     for (int s = 0; s < npair; ++s) {
       const float b = Bs[2 * s + h][ch * 32 + r];
 #pragma unroll
@@ -224,6 +267,12 @@ __global__ __launch_bounds__(256) void c1d_wgrad_kernel(const WgradP p) {
   }
 }
 
+// 16-byte loads: K (reduction rows of the B operand), M (output rows) and L multiples of 4, weight rows of 4k floats,
+// 16-byte aligned tensors
+bool vec_ok(const float* xb, const float* w, const float* y, int K, int M, int l, int wrow) {
+  return (K & 3) == 0 && (M & 3) == 0 && (l & 3) == 0 && (wrow & 3) == 0 && (((uintptr_t)xb | (uintptr_t)w | (uintptr_t)y) & 15) == 0;
+}
+
 bool dims_ok(int b, int cin, int cout, int l) {
   return b > 0 && cin > 0 && cout > 0 && l > 0 && (long long)b * l < (1ll << 30) &&
          (long long)b * (cin > cout ? cin : cout) * l < (1ll << 40);
@@ -255,10 +304,14 @@ extern "C" int pcuda_conv1d_k1_fwd(const float* x, const float* w, const float* 
   char tag[96];
   snprintf(tag, sizeof(tag), "conv1d f32 fwd n%d cin%d cout%d l%d", b, cin, cout, l);
   ProfScope prof(PCUDA_FAM_DENSE_F32, 2.0 * b * l * (double)cin * cout, s, tag);
-  if (cout > 64) {
-    hipLaunchKernelGGL((c1d_gemm_kernel<2, false>), dim3(cdiv(p.ncols, BN), cdiv(cout, 128)), dim3(256), 0, s, p);
+  const bool vec = vec_ok(x, w, y, cin, cout, l, cin);
+  const dim3 g2(cdiv(p.ncols, BN), cdiv(cout, 128)), g1(cdiv(p.ncols, BN), cdiv(cout, 64));
+  if (cout > 64 && (long long)g2.x * g2.y >= 512) {
+    if (vec) hipLaunchKernelGGL((c1d_gemm_kernel<2, false, true>), g2, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((c1d_gemm_kernel<2, false, false>), g2, dim3(256), 0, s, p);
   } else {
-    hipLaunchKernelGGL((c1d_gemm_kernel<1, false>), dim3(cdiv(p.ncols, BN), cdiv(cout, 64)), dim3(256), 0, s, p);
+    if (vec) hipLaunchKernelGGL((c1d_gemm_kernel<1, false, true>), g1, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((c1d_gemm_kernel<1, false, false>), g1, dim3(256), 0, s, p);
   }
   PCUDA_CHECK_LAUNCH("c1d_gemm_kernel(fwd)");
   return PCUDA_OK;
@@ -272,10 +325,15 @@ extern "C" int pcuda_conv1d_k1_dgrad(const float* dy, const float* w, float* dx,
   char tag[96];
   snprintf(tag, sizeof(tag), "conv1d f32 dgrad n%d cin%d cout%d l%d", b, cin, cout, l);
   ProfScope prof(PCUDA_FAM_DENSE_F32, 2.0 * b * l * (double)cin * cout, s, tag);
-  if (cin > 64) {
-    hipLaunchKernelGGL((c1d_gemm_kernel<2, true>), dim3(cdiv(p.ncols, BN), cdiv(cin, 128)), dim3(256), 0, s, p);
+  const bool vec = vec_ok(dy, w, dx, cout, cin, l, cin);
+  const dim3 g2(cdiv(p.ncols, BN), cdiv(cin, 128)), g1(cdiv(p.ncols, BN), cdiv(cin, 64));
+  // (128-row tiles only where they still fill the chip twice: 1024 -> 128 channels on 9600 points is 150 of them)
+  if (cin > 64 && (long long)g2.x * g2.y >= 512) {
+    if (vec) hipLaunchKernelGGL((c1d_gemm_kernel<2, true, true>), g2, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((c1d_gemm_kernel<2, true, false>), g2, dim3(256), 0, s, p);
   } else {
-    hipLaunchKernelGGL((c1d_gemm_kernel<1, true>), dim3(cdiv(p.ncols, BN), cdiv(cin, 64)), dim3(256), 0, s, p);
+    if (vec) hipLaunchKernelGGL((c1d_gemm_kernel<1, true, true>), g1, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((c1d_gemm_kernel<1, true, false>), g1, dim3(256), 0, s, p);
   }
   PCUDA_CHECK_LAUNCH("c1d_gemm_kernel(dgrad)");
   return PCUDA_OK;
