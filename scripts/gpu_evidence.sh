@@ -6,6 +6,9 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 TAG=${TAG:-r03}
 python3 -c "import sys; sys.path.insert(0, '.'); from pointcloududa_amd._lib import csrc_hash; print('csrc_sha256', csrc_hash())" | tee gpurun_out/${TAG}_build_hash.txt
+# (the whole-step traffic first: bench.py quotes roofline.traffic from profiles/rNN_pmc_traffic.csv of THIS build's hash)
+TAG=$TAG bash scripts/gpu_pmc_step.sh > gpurun_out/${TAG}_pmc_step.log 2>&1; echo "pmc_step rc=$?"
+cp gpurun_out/${TAG}_pmc_traffic.csv profiles/${TAG}_pmc_traffic.csv
 TAG=$TAG bash scripts/gpu_profile.sh > gpurun_out/${TAG}_profile.log 2>&1; echo "profile rc=$?"
 for wl in unet_d2 mmwhs_uda uda_512; do
   python3 bench.py --workload $wl --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_$wl.json; echo "$wl: $(cut -c1-160 gpurun_out/${TAG}_bench_$wl.json)"
@@ -14,6 +17,5 @@ python3 bench.py --precision bf16 --no-cpu-baseline 2>/dev/null | tail -1 > gpur
 CASES="g32 g64 g128 g256 b512 d2 d4" TAG=$TAG NSETS=2 bash scripts/pmc_conv.sh > gpurun_out/${TAG}_pmc_conv.log 2>&1; echo "pmc_conv rc=$?"
 python3 scripts/mfma_table.py gpurun_out/${TAG}_pmc_conv.csv gpurun_out/${TAG}_mfma_counters.csv > /dev/null; echo "mfma table rc=$?"
 TAG=$TAG bash scripts/pmc_layers.sh > gpurun_out/${TAG}_pmc_layers.log 2>&1; echo "pmc_layers rc=$?"
-TAG=$TAG bash scripts/gpu_pmc_step.sh > gpurun_out/${TAG}_pmc_step.log 2>&1; echo "pmc_step rc=$?"
 TAG=$TAG bash scripts/micro/fetch_calib.sh > gpurun_out/${TAG}_fetch_calib.log 2>&1; echo "fetch_calib rc=$?"
 ls gpurun_out/${TAG}_*
