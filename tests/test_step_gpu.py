@@ -132,7 +132,7 @@ def _check_updates(tr, g, pre):
     # (independent forward passes: a few LeakyReLU(0.2) routing flips in the 129^2 ... 9^2 maps; observed <= 3.8e-2; the
     # 1e-4 check with the routing shared is test_discriminator_backward_shared_routing).  d4 sits behind
     # BatchNorm1d over the batch of 4-8 (see _check_losses): its buffer is held to 0.35 in norm per tensor and to a
-    # cosine of 0.9 with the reference's over all sampled elements.
+    # cosine of 0.95 with the reference's over all sampled elements (observed 0.980-0.998 since PointNetCls runs in exact fp32).
     for nm, mod, opt in (("d1", tr.dis1, tr.opt_d1), ("d2", tr.dis2, tr.opt_d2), ("d4", tr.dis4, tr.opt_d4)):
         if mod is None:
             continue
@@ -155,7 +155,7 @@ def _check_updates(tr, g, pre):
             assert np.all(np.abs(p1 - p1_ref) <= opt.lr * np.abs(got - ref) + 2.01 * ulp), (nm, k)
         if nm == "d4":
             cos = dot / max((n_got * n_ref) ** 0.5, 1e-30)
-            assert cos >= 0.9 and abs(n_got ** 0.5 - n_ref ** 0.5) <= 0.35 * n_ref ** 0.5, (cos, n_got, n_ref)
+            assert cos >= 0.95 and abs(n_got ** 0.5 - n_ref ** 0.5) <= 0.35 * n_ref ** 0.5, (cos, n_got, n_ref)
             rates["sgd_d4_cos"] = cos
         else:
             rates["sgd_" + nm] = worst
