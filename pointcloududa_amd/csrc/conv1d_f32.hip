@@ -52,7 +52,6 @@ __global__ __launch_bounds__(256) void c1d_gemm_kernel(const GemmP p) {
   const int jcol = j0 + jj;
   const bool jok = jcol < p.ncols;
   const int jb = jok ? jcol / p.L : 0, jl = jok ? jcol - jb * p.L : 0;
-  const float* xcol = p.x + ((long long)jb * p.K * p.L + jl);
   // ---- vector loaders (VEC = true): B lane = 4 columns (tid & 15), k rows (tid >> 4) + 16q;
   //      A, TA = false: 4 k's (tid & 7), rows (tid >> 3) + 32q (transposed scalar LDS stores);
   //      A, TA = true : 4 rows (tid % (BM / 4)), k rows tid / (BM / 4) + (1024 / BM) q (16-byte LDS stores)
@@ -60,34 +59,48 @@ __global__ __launch_bounds__(256) void c1d_gemm_kernel(const GemmP p) {
   const int vcol = j0 + vj;
   const bool vok = vcol < p.ncols;          // (ncols % 4 == 0: a quad is inside or outside as a whole, and inside one batch row)
   const int vb = vok ? vcol / p.L : 0, vl = vok ? vcol - vb * p.L : 0;
-  const float* xq = p.x + ((long long)vb * p.K * p.L + vl);
   constexpr int AL = VEC ? BM * 32 / 1024 : BM * BK / 256;      // A loads per thread and stage (float4 / float)
   constexpr int BL = VEC ? 2 : 4;
   float av[VEC ? 1 : AL], bv[VEC ? 1 : BL];
   f32x4 av4[VEC ? AL : 1], bv4[VEC ? BL : 1];
+  // VMEM address rule (common.h): every load goes through a wave-uniform base + a 32-bit byte offset of its own that
+  // stays alive (PCUDA_KEEP behind the commit that consumes the data); lanes outside the problem read offset 0 and are
+  // zeroed afterwards -- no load sits under a per-lane branch
+  unsigned aoff[AL], boff[BL];
+  bool aok[AL], bok[BL];
+  const char* const wb = (const char*)p.w;
+  const char* const xb = (const char*)p.x;
+  const unsigned xq_off = (unsigned)(((long long)vb * p.K * p.L + vl) * 4), xc_off = (unsigned)(((long long)jb * p.K * p.L + jl) * 4);
   auto load = [&](int k0) {
     if (VEC) {
 #pragma unroll
       for (int q = 0; q < BL; ++q) {
         const int k = k0 + vk + 16 * q;
-        bv4[q] = (vok && k < p.K) ? *(const f32x4*)(xq + (long long)k * p.L) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bok[q] = vok && k < p.K;
+        boff[q] = bok[q] ? xq_off + (unsigned)(k * p.L) * 4u : 0u;
+        bv4[q] = *(const f32x4*)(xb + boff[q]);
       }
 #pragma unroll
       for (int q = 0; q < AL; ++q) {
         if (!TA) {
           const int k = k0 + (tid & 7) * 4, gi = i0 + (tid >> 3) + 32 * q;
-          av4[q] = (gi < p.M && k < p.K) ? *(const f32x4*)(p.w + (long long)gi * p.cin + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+          aok[q] = gi < p.M && k < p.K;
+          aoff[q] = aok[q] ? (unsigned)(gi * p.cin + k) * 4u : 0u;
         } else {
           const int gi = i0 + (tid % (BM / 4)) * 4, k = k0 + tid / (BM / 4) + (1024 / BM) * q;
-          av4[q] = (gi < p.M && k < p.K) ? *(const f32x4*)(p.w + (long long)k * p.cin + gi) : f32x4{0.f, 0.f, 0.f, 0.f};
+          aok[q] = gi < p.M && k < p.K;
+          aoff[q] = aok[q] ? (unsigned)(k * p.cin + gi) * 4u : 0u;
         }
+        av4[q] = *(const f32x4*)(wb + aoff[q]);
       }
       return;
     }
 #pragma unroll
     for (int q = 0; q < BL; ++q) {
       const int k = k0 + kb + 4 * q;
-      bv[q] = (jok && k < p.K) ? xcol[(long long)k * p.L] : 0.f;
+      bok[q] = jok && k < p.K;
+      boff[q] = bok[q] ? xc_off + (unsigned)(k * p.L) * 4u : 0u;
+      bv[q] = *(const float*)(xb + boff[q]);
     }
 #pragma unroll
     for (int q = 0; q < AL; ++q) {
@@ -95,35 +108,42 @@ __global__ __launch_bounds__(256) void c1d_gemm_kernel(const GemmP p) {
       if (!TA) { k = tid & 15; i = (tid >> 4) + 16 * q; }
       else { i = (tid & 63) + 64 * (q / 4); k = (tid >> 6) + 4 * (q & 3); }
       const int gi = i0 + i, gk = k0 + k;
-      const bool ok = gi < p.M && gk < p.K;
-      av[q] = ok ? (TA ? p.w[(long long)gk * p.cin + gi] : p.w[(long long)gi * p.cin + gk]) : 0.f;
+      aok[q] = gi < p.M && gk < p.K;
+      aoff[q] = aok[q] ? (unsigned)(TA ? gk * p.cin + gi : gi * p.cin + gk) * 4u : 0u;
+      av[q] = *(const float*)(wb + aoff[q]);
     }
   };
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto commit = [&]() {
     if (VEC) {
 #pragma unroll
-      for (int q = 0; q < BL; ++q) *(f32x4*)&Bs[vk + 16 * q][vj] = bv4[q];
+      for (int q = 0; q < BL; ++q) *(f32x4*)&Bs[vk + 16 * q][vj] = bok[q] ? bv4[q] : zero4;
 #pragma unroll
       for (int q = 0; q < AL; ++q) {
+        const f32x4 a4 = aok[q] ? av4[q] : zero4;
         if (!TA) {
           const int k = (tid & 7) * 4, i = (tid >> 3) + 32 * q;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) As[k + e][i] = av4[q][e];
+          for (int e = 0; e < 4; ++e) As[k + e][i] = a4[e];
         } else {
-          *(f32x4*)&As[tid / (BM / 4) + (1024 / BM) * q][(tid % (BM / 4)) * 4] = av4[q];
+          *(f32x4*)&As[tid / (BM / 4) + (1024 / BM) * q][(tid % (BM / 4)) * 4] = a4;
         }
       }
-      return;
+    } else {
+#pragma unroll
+      for (int q = 0; q < BL; ++q) Bs[kb + 4 * q][jj] = bok[q] ? bv[q] : 0.f;
+#pragma unroll
+      for (int q = 0; q < AL; ++q) {
+        int i, k;
+        if (!TA) { k = tid & 15; i = (tid >> 4) + 16 * q; }
+        else { i = (tid & 63) + 64 * (q / 4); k = (tid >> 6) + 4 * (q & 3); }
+        As[k][i] = aok[q] ? av[q] : 0.f;
+      }
     }
 #pragma unroll
-    for (int q = 0; q < BL; ++q) Bs[kb + 4 * q][jj] = bv[q];
+    for (int q = 0; q < BL; ++q) PCUDA_KEEP(boff[q]);
 #pragma unroll
-    for (int q = 0; q < AL; ++q) {
-      int i, k;
-      if (!TA) { k = tid & 15; i = (tid >> 4) + 16 * q; }
-      else { i = (tid & 63) + 64 * (q / 4); k = (tid >> 6) + 4 * (q & 3); }
-      As[k][i] = av[q];
-    }
+    for (int q = 0; q < AL; ++q) PCUDA_KEEP(aoff[q]);
   };
 
   f32x16 acc[MB];
@@ -207,21 +227,29 @@ __global__ __launch_bounds__(256) void c1d_wgrad_kernel(const WgradP p) {
   for (int q = 0; q < AL; ++q) dbacc[q] = 0.f;
   const int step_lo = ks * p.steps_per_slice;
   const int step_hi = min(step_lo + p.steps_per_slice, (p.ncols + WK - 1) / WK);
+  // (VMEM address rule, common.h: uniform base + a kept 32-bit offset per load, unconditional loads, zeros selected after)
+  unsigned aoff[AL], boff[8];
+  bool aok[AL], bok[8];
+  const char* const ab = (const char*)p.dy;
+  const char* const bb = (const char*)p.x;
   auto load = [&](int step) {
     const int j = step * WK + kk;
     const bool jok = j < p.ncols;
     const int b = jok ? j / p.L : 0, l = jok ? j - b * p.L : 0;
-    const float* ac = p.dy + ((long long)b * p.M * p.L + l);
-    const float* bc = p.x + ((long long)b * p.N * p.L + l);
+    const unsigned ac = (unsigned)(((long long)b * p.M * p.L + l) * 4), bc = (unsigned)(((long long)b * p.N * p.L + l) * 4);
 #pragma unroll
     for (int q = 0; q < AL; ++q) {
       const int gi = i0 + r0 + 8 * q;
-      av[q] = (jok && gi < p.M) ? ac[(long long)gi * p.L] : 0.f;
+      aok[q] = jok && gi < p.M;
+      aoff[q] = aok[q] ? ac + (unsigned)(gi * p.L) * 4u : 0u;
+      av[q] = *(const float*)(ab + aoff[q]);
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int gn = n0 + r0 + 8 * q;
-      bv[q] = (jok && gn < p.N) ? bc[(long long)gn * p.L] : 0.f;
+      bok[q] = jok && gn < p.N;
+      boff[q] = bok[q] ? bc + (unsigned)(gn * p.L) * 4u : 0u;
+      bv[q] = *(const float*)(bb + boff[q]);
     }
   };
   f32x16 acc[MB];
@@ -233,9 +261,14 @@ __global__ __launch_bounds__(256) void c1d_wgrad_kernel(const WgradP p) {
   for (int step = step_lo; step < step_hi; ++step) {
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < AL; ++q) { As[kk][r0 + 8 * q] = av[q]; if (do_db) dbacc[q] += av[q]; }
+    for (int q = 0; q < AL; ++q) {
+      const float a = aok[q] ? av[q] : 0.f;
+      As[kk][r0 + 8 * q] = a;
+      if (do_db) dbacc[q] += a;
+      PCUDA_KEEP(aoff[q]);
+    }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) Bs[kk][r0 + 8 * q] = bv[q];
+    for (int q = 0; q < 8; ++q) { Bs[kk][r0 + 8 * q] = bok[q] ? bv[q] : 0.f; PCUDA_KEEP(boff[q]); }
     __syncthreads();
     if (step + 1 < step_hi) load(step + 1);
 #pragma unroll 4
@@ -274,8 +307,9 @@ bool vec_ok(const float* xb, const float* w, const float* y, int K, int M, int l
 }
 
 bool dims_ok(int b, int cin, int cout, int l) {
+  // (32-bit byte offsets inside every tensor)
   return b > 0 && cin > 0 && cout > 0 && l > 0 && (long long)b * l < (1ll << 30) &&
-         (long long)b * (cin > cout ? cin : cout) * l < (1ll << 40);
+         (long long)b * (cin > cout ? cin : cout) * l < (1ll << 29) && (long long)cin * cout < (1ll << 29);
 }
 
 int wgrad_ksplit(int b, int cin, int cout, int l, int mb) {
