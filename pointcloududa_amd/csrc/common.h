@@ -47,6 +47,21 @@ struct ProfScope {
   hipStream_t stream;
 };
 
+// hipFuncSetAttribute (the dynamic-LDS opt-in) is per DEVICE while a launcher's guard is per kernel: one bit per device
+// ordinal, so a process that drives a second GPU sets it there too (a process-wide flag did not; setting it twice from
+// two threads is harmless, hence relaxed atomics).
+struct DeviceOnce {
+  unsigned long long done = 0;
+  // the current device's bit if the attribute still has to be set there, 0 otherwise
+  unsigned long long pending() const {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) d = 0;
+    const unsigned long long b = 1ull << (d & 63);
+    return (__atomic_load_n(&done, __ATOMIC_RELAXED) & b) ? 0ull : b;
+  }
+  void mark(unsigned long long b) { __atomic_fetch_or(&done, b, __ATOMIC_RELAXED); }
+};
+
 // ---------------------------------------------------------------- bf16 split helpers
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
   bf16x2 p = {(__bf16)a, (__bf16)b};  // v_cvt_pk_bf16_f32 (round to nearest even, NaN preserving)

@@ -977,11 +977,11 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
 template <bool X3, int CO_BLKS, bool CLAMP, int NPBT, int PF, bool XQ, bool STATS>
 static int launch_igemm8_s(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
   auto kern = igemm8_kernel<X3, CO_BLKS, CLAMP, NPBT, PF, XQ, STATS>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce lds_opt;
+  if (const unsigned long long devbit = lds_opt.pending()) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HARD);
     if (e != hipSuccess) PCUDA_FAIL(PCUDA_E_LAUNCH, "igemm8: cannot raise dynamic LDS: %s", hipGetErrorString(e));
-    attr_set = true;
+    lds_opt.mark(devbit);
   }
   const int total = p.n_co_tiles * p.n * p.tiles_x * p.tiles_y;
   int grid = 256;
@@ -1015,11 +1015,11 @@ static int igemm8_dispatch(const IgemmParams& p, const IgemmPlan& pl, int co_blk
 template <bool X3, int CO_BLKS, bool CLAMP, int NPB>
 static int launch_igemm_t(const IgemmParams& p, int x_cap, size_t lds, hipStream_t s) {
   auto kern = igemm_kernel<X3, CO_BLKS, CLAMP, NPB>;
-  static size_t lds_set = 0;
-  if (lds > 32 * 1024 && lds > lds_set) {
+  static DeviceOnce lds_opt;
+  if (const unsigned long long devbit = lds > 32 * 1024 ? lds_opt.pending() : 0ull) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HARD);
     if (e != hipSuccess) PCUDA_FAIL(PCUDA_E_LAUNCH, "igemm: cannot raise dynamic LDS to %d: %s", LDS_HARD, hipGetErrorString(e));
-    lds_set = LDS_HARD;
+    lds_opt.mark(devbit);
   }
   const int grid = p.n_co_tiles * p.n * p.tiles_x * p.tiles_y;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, p, x_cap);
@@ -1038,11 +1038,11 @@ static int launch_igemm_c(const IgemmParams& p, const IgemmPlan& pl, hipStream_t
 template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ, int STATS, bool TE>
 static int launch_pipe_s(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
   auto kern = igemm_pipe_kernel<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, STATS, TE>;
-  static size_t lds_set = 0;
-  if (pl.lds > 32 * 1024 && pl.lds > lds_set) {
+  static DeviceOnce lds_opt;
+  if (const unsigned long long devbit = pl.lds > 32 * 1024 ? lds_opt.pending() : 0ull) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HARD);
     if (e != hipSuccess) PCUDA_FAIL(PCUDA_E_LAUNCH, "igemm_pipe: cannot raise dynamic LDS: %s", hipGetErrorString(e));
-    lds_set = LDS_HARD;
+    lds_opt.mark(devbit);
   }
   const int total = p.n_co_tiles * p.n * p.tiles_x * p.tiles_y;
   // persistent grid = what is resident at once (registers and LDS both limit it)

@@ -96,7 +96,6 @@ __global__ __launch_bounds__(64 * RB * 2 * KH, 2) void wgrad3_kernel(const W3Par
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CO_T = 32 * RB;
   constexpr int ZJ = CO_T * 16 / NT;             // dZ octets per thread
-  constexpr int NKS = 8 / KH;
   unsigned char* Xs = smem;                                            // hi plane, lo plane at + W3_XPLANE
   unsigned char* Zs = smem + (X3 ? 2 : 1) * W3_XPLANE;                 // hi rows, lo rows at + CO_T * WG_ZROW
 

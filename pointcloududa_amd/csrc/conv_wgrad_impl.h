@@ -430,11 +430,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (TAPS_MAX <= 9 && PF <= 1)) ? 
 template <bool X3, int CO_BLKS, int MODE, int TAPS_MAX, int PF, int NW, bool XQ>
 static int launch_wgrad_q(const WgradParams& p, int x_cap, size_t lds, float* dbp, dim3 grid, hipStream_t s) {
   auto kern = wgrad_kernel<X3, CO_BLKS, MODE, TAPS_MAX, PF, NW, XQ>;
-  static size_t lds_set = 0;
-  if (lds > 32 * 1024 && lds > lds_set) {
+  static DeviceOnce lds_opt;
+  if (const unsigned long long devbit = lds > 32 * 1024 ? lds_opt.pending() : 0ull) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HARD);
     if (e != hipSuccess) PCUDA_FAIL(PCUDA_E_LAUNCH, "wgrad: cannot raise dynamic LDS: %s", hipGetErrorString(e));
-    lds_set = LDS_HARD;
+    lds_opt.mark(devbit);
   }
   hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, s, p, x_cap, dbp);
   PCUDA_CHECK_LAUNCH("wgrad_kernel");

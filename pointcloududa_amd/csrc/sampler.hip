@@ -179,11 +179,11 @@ extern "C" int pcuda_fps(const double* pts, const int* counts, const int* first,
     PCUDA_FAIL(PCUDA_E_BADARG, "fps: bad arguments");
   const size_t lds = (size_t)npts_max * sizeof(double);
   if (lds > 150 * 1024) PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "fps: at most %d points per cloud", (int)(150 * 1024 / 8));
-  static bool attr_set = false;
-  if (lds > 32 * 1024 && !attr_set) {
+  static DeviceOnce lds_opt;
+  if (const unsigned long long devbit = lds > 32 * 1024 ? lds_opt.pending() : 0ull) {
     if (hipFuncSetAttribute((const void*)fps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       PCUDA_FAIL(PCUDA_E_LAUNCH, "fps: cannot raise dynamic LDS");
-    attr_set = true;
+    lds_opt.mark(devbit);
   }
   hipLaunchKernelGGL(fps_kernel, dim3(b), dim3(256), lds, (hipStream_t)s, pts, counts, first, npts_max, k, idx);
   PCUDA_CHECK_LAUNCH("fps_kernel");
