@@ -103,7 +103,9 @@ size_t pcuda_conv2d_packed_dgrad_bytes(const pcuda_conv_geom* g, int prec);
  * Opaque to the caller (sizes from the two queries above); call once per optimiser step */
 int pcuda_conv2d_pack_fwd(const pcuda_conv_geom* g, int prec, const float* w, void* packed, pcuda_stream_t s);
 int pcuda_conv2d_pack_dgrad(const pcuda_conv_geom* g, int prec, const float* w, void* packed, pcuda_stream_t s);
-/* both repacks in ONE launch (forward layout + every dgrad parity class); packed_dgrad may be NULL */
+/* both repacks in ONE launch (forward layout + every dgrad parity class -- for k = 4 / stride 2 / pad 2 one image per ROW
+ * parity with the two column classes interleaved row by row; the layout is the library's business: size it with
+ * pcuda_conv2d_packed_dgrad_bytes and hand it back to pcuda_conv2d_dgrad); packed_dgrad may be NULL */
 int pcuda_conv2d_pack_all(const pcuda_conv_geom* g, int prec, const float* w, void* packed_fwd, void* packed_dgrad,
                           pcuda_stream_t s);
 /* Batched repack (one launch for all layers of a network after an optimiser step): fill the job records of a layer

@@ -79,6 +79,35 @@ static inline TapSet dgrad_taps(const pcuda_conv_geom* g, int ry, int rx) {
   return t;
 }
 
+// Stride-2 layers whose two COLUMN parity classes reach the same gradient pixels (k = 4, pad = 2, the discriminators'
+// layers, GAN.py:97-105: both classes have the tap offsets {0,1} x {0,1}): the two classes run as ONE launch with rows
+// (channel, column parity), so that a wave writes both halves of every 8 bytes of a destination line (a class on its own
+// stores every other dword: the lines reach HBM half-written twice, WRITE_SIZE 2x the tensor) and the gradient tile is
+// staged twice per layer instead of four times.  A property of (k, stride, pad, dil, cin) only: the packed image of a
+// layer and its launches agree.  (cin <= 5 stays on the four-class image: the direct kernels of the first layer read it.)
+static inline bool dgrad_pair_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("PCUDA_DGRAD_PAIR"); on = (e && !atoi(e)) ? 0 : 1; }
+  return on != 0;
+}
+static inline bool dgrad_pair_ok(const pcuda_conv_geom* g) {
+  if (g->stride != 2 || g->in_up || g->cin <= 5 || !dgrad_pair_enabled()) return false;
+  for (int ry = 0; ry < 2; ++ry) {
+    const TapSet a = dgrad_taps(g, ry, 0), b = dgrad_taps(g, ry, 1);
+    if (a.n < 1 || a.n != b.n || 2 * a.n > IG_MAX_TAPS) return false;
+    for (int i = 0; i < a.n; ++i)
+      if (a.dy[i] != b.dy[i] || a.dx[i] != b.dx[i]) return false;
+  }
+  return true;
+}
+// taps of row class ry for both column classes: offsets once, src[0..n) for rx = 0 and src[n..2n) for rx = 1
+static inline TapSet dgrad_pair_taps(const pcuda_conv_geom* g, int ry) {
+  TapSet t = dgrad_taps(g, ry, 0);
+  const TapSet b = dgrad_taps(g, ry, 1);
+  for (int i = 0; i < b.n; ++i) t.src[t.n + i] = b.src[i];
+  return t;
+}
+
 // candidate output-tile widths: powers of two plus even splits of the row (so a 17- or 33-wide map is
 // not padded to 32 / 64)
 static inline int tile_width_candidates(int lw, int tile_px, int* out) {

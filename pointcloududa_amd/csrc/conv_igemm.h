@@ -55,6 +55,10 @@ struct IgemmParams {
   int dbg;                 // PCUDA_DBG bits (timing experiments only): 1 no X loads, 2 no MFMA, 4 no epilogue, 8 no W copy
   unsigned long long* dbg_clk;   // PCUDA_DBG bit 128: 8 per-phase cycle sums
   int xq;                  // 1: quad (float4) input staging (in_w % 4 == 0, no upsampling fold)
+  // paired column classes of a stride-2 data gradient (dword-store epilogues): row 2c + rx of the launch is channel c,
+  // column parity rx -- one wave stores both halves of every 8 bytes of a destination line back to back.  lw = columns
+  // of the even class, lw2 = of the odd one; ox_off = 0, ox_mul = 2.
+  int pair, lw2;
 };
 
 // wgrad: dW[r][c][tap] = sum_{n,oy,ox} dZ[r][oy,ox] * X[c][oy*stride + dy[t]][ox*stride + dx[t]]
@@ -93,6 +97,7 @@ struct PackParams {
   long long s_row, s_red;  // element strides in w for row / reduction index (tap stride is 1)
   int ntaps;
   signed char tap_src[IG_MAX_TAPS];
+  int pair;                // 1: row r reads source row r >> 1 through tap_src[(r & 1) * ntaps + t] (paired column classes)
   int co_tile;             // 32 or 64
   int nchunks, n_co_tiles;
 };

@@ -33,7 +33,8 @@ __global__ void pack_kernel(const PackParams p) {
     const int cc = is_lo ? col - 32 : col;
     int r = cot * p.co_tile + row, c = ch * 32 + cc;
     float v = 0.f;
-    if (cc < 32 && r < p.rows && c < p.red) v = p.w[r * p.s_row + c * p.s_red + p.tap_src[t]];
+    if (cc < 32 && r < p.rows && c < p.red)
+      v = p.w[(p.pair ? r >> 1 : r) * p.s_row + c * p.s_red + p.tap_src[p.pair ? (r & 1) * p.ntaps + t : t]];
     __bf16 hi = (__bf16)v;
     if (is_lo) hi = (__bf16)(v - (float)hi);
     p.out[idx] = __builtin_bit_cast(uint16_t, hi);
@@ -63,7 +64,8 @@ __global__ void pack_multi_kernel(const PackJobs jobs) {
     const int cc = is_lo ? col - 32 : col;
     int r = cot * p.co_tile + row, c = ch * 32 + cc;
     float v = 0.f;
-    if (cc < 32 && r < p.rows && c < p.red) v = p.w[r * p.s_row + c * p.s_red + p.tap_src[t]];
+    if (cc < 32 && r < p.rows && c < p.red)
+      v = p.w[(p.pair ? r >> 1 : r) * p.s_row + c * p.s_red + p.tap_src[p.pair ? (r & 1) * p.ntaps + t : t]];
     __bf16 hi = (__bf16)v;
     if (is_lo) hi = (__bf16)(v - (float)hi);
     p.out[idx] = __builtin_bit_cast(uint16_t, hi);
@@ -98,7 +100,8 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const PackParams* __res
     const int cc = is_lo ? col - 32 : col;
     int r = cot * p.co_tile + row, c = ch * 32 + cc;
     float v = 0.f;
-    if (cc < 32 && r < p.rows && c < p.red) v = p.w[r * p.s_row + c * p.s_red + p.tap_src[t]];
+    if (cc < 32 && r < p.rows && c < p.red)
+      v = p.w[(p.pair ? r >> 1 : r) * p.s_row + c * p.s_red + p.tap_src[p.pair ? (r & 1) * p.ntaps + t : t]];
     __bf16 hi16 = (__bf16)v;
     if (is_lo) hi16 = (__bf16)(v - (float)hi16);
     p.out[idx] = __builtin_bit_cast(uint16_t, hi16);
@@ -140,11 +143,13 @@ size_t packed_elems(int rows, int red, int ntaps, int prec) {   // bf16 elements
   return (size_t)n_co_tiles * nchunks * ntaps * co_tile * (ig_rec_bytes(prec == PCUDA_PREC_BF16X3) / 2);
 }
 
+// pair: rows = 2 x the source rows, (source row, column class) interleaved; taps.src holds both classes' sources
 size_t fill_pack(PackParams& p, const float* w, uint16_t* out, int prec, int rows, int red, long long s_row,
-                 long long s_red, const TapSet& taps) {
+                 long long s_red, const TapSet& taps, bool pair = false) {
   p.w = w; p.out = out;
   p.rows = rows; p.red = red; p.s_row = s_row; p.s_red = s_red;
   p.ntaps = taps.n;
+  p.pair = pair ? 1 : 0;
   memcpy(p.tap_src, taps.src, sizeof(p.tap_src));
   p.co_tile = 32 * ig_co_blks(rows);
   p.n_co_tiles = cdiv(rows, p.co_tile);
@@ -155,10 +160,10 @@ size_t fill_pack(PackParams& p, const float* w, uint16_t* out, int prec, int row
 }
 
 int launch_pack(const float* w, uint16_t* out, int prec, int rows, int red, long long s_row, long long s_red,
-                const TapSet& taps, hipStream_t s) {
+                const TapSet& taps, hipStream_t s, bool pair = false) {
   if (taps.n == 0) return PCUDA_OK;
   PackParams p;
-  const size_t plane = fill_pack(p, w, out, prec, rows, red, s_row, s_red, taps);
+  const size_t plane = fill_pack(p, w, out, prec, rows, red, s_row, s_red, taps, pair);
   const int blocks = (int)((plane + 255) / 256 > 4096 ? 4096 : (plane + 255) / 256);
   hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, s, p);
   PCUDA_CHECK_LAUNCH("pack_kernel");
@@ -353,6 +358,10 @@ extern "C" size_t pcuda_conv2d_packed_fwd_bytes(const pcuda_conv_geom* g, int pr
 extern "C" size_t pcuda_conv2d_packed_dgrad_bytes(const pcuda_conv_geom* g, int prec) {
   if (!geom_ok(g)) return 0;
   size_t tot = 0;
+  if (dgrad_pair_ok(g)) {
+    for (int ry = 0; ry < 2; ++ry) tot += packed_elems(2 * g->cin, g->cout, dgrad_taps(g, ry, 0).n, prec) * 2;
+    return tot;
+  }
   for (int ry = 0; ry < g->stride; ++ry)
     for (int rx = 0; rx < g->stride; ++rx) {
       TapSet t = dgrad_taps(g, ry, rx);
@@ -374,6 +383,15 @@ extern "C" int pcuda_conv2d_pack_dgrad(const pcuda_conv_geom* g, int prec, const
   if (!geom_ok(g) || !w || !packed) PCUDA_FAIL(PCUDA_E_BADARG, "pack_dgrad: bad geometry or null pointer");
   const int kk = g->k * g->k;
   uint16_t* out = (uint16_t*)packed;
+  if (dgrad_pair_ok(g)) {
+    for (int ry = 0; ry < 2; ++ry) {
+      TapSet t = dgrad_pair_taps(g, ry);
+      int rc = launch_pack(w, out, prec, 2 * g->cin, g->cout, kk, (long long)g->cin * kk, t, (hipStream_t)s, true);
+      if (rc) return rc;
+      out += packed_elems(2 * g->cin, g->cout, t.n, prec);
+    }
+    return PCUDA_OK;
+  }
   for (int ry = 0; ry < g->stride; ++ry)
     for (int rx = 0; rx < g->stride; ++rx) {
       TapSet t = dgrad_taps(g, ry, rx);
@@ -397,7 +415,15 @@ extern "C" int pcuda_conv2d_pack_all(const pcuda_conv_geom* g, int prec, const f
   jobs.n = 0;
   size_t maxplane = fill_pack(jobs.p[jobs.n++], w, (uint16_t*)packed_fwd, prec, g->cout, g->cin, (long long)g->cin * kk,
                               kk, fwd_taps(g));
-  if (packed_dgrad) {
+  if (packed_dgrad && dgrad_pair_ok(g)) {
+    uint16_t* out = (uint16_t*)packed_dgrad;
+    for (int ry = 0; ry < 2; ++ry) {
+      const size_t plane = fill_pack(jobs.p[jobs.n++], w, out, prec, 2 * g->cin, g->cout, kk, (long long)g->cin * kk,
+                                     dgrad_pair_taps(g, ry), true);
+      if (plane > maxplane) maxplane = plane;
+      out += plane;
+    }
+  } else if (packed_dgrad) {
     uint16_t* out = (uint16_t*)packed_dgrad;
     for (int ry = 0; ry < g->stride; ++ry)
       for (int rx = 0; rx < g->stride; ++rx) {
@@ -466,6 +492,29 @@ extern "C" int pcuda_conv2d_dgrad(const pcuda_conv_geom* g, int prec, const pcud
   }
   const uint16_t* wp = (const uint16_t*)packed_w_dgrad;
   const int st = g->stride;
+  if (dgrad_pair_ok(g)) {   // (conv_host.h: one launch per row class, rows = (channel, column class))
+    for (int ry = 0; ry < 2; ++ry) {
+      TapSet t = dgrad_pair_taps(g, ry);
+      const int lh = (g->in_h - ry + 1) / 2, lw = (g->in_w + 1) / 2;
+      if (lh > 0) {
+        IgemmParams p;
+        memset(&p, 0, sizeof(p));
+        p.x = *dy; p.cin = g->cout;
+        p.in_h = g->out_h; p.in_w = g->out_w; p.in_shift = 0; p.in_row = g->out_w;
+        p.y = *dx; p.cout = 2 * g->cin; p.out_w = g->in_w;
+        p.lh = lh; p.lw = lw; p.pair = 1; p.lw2 = g->in_w / 2;
+        p.oy_mul = p.ox_mul = 2; p.oy_off = ry; p.ox_off = 0;
+        p.in_step = 1;
+        p.wpack = wp; p.w_lo_off = 0;
+        p.bias = nullptr; p.slope = 1.f; p.accumulate = accumulate; p.stats = nullptr;
+        p.n = g->n;
+        int rc = launch_igemm(p, prec, t, (hipStream_t)s);
+        if (rc) return rc;
+      }
+      wp += packed_elems(2 * g->cin, g->cout, t.n, prec);
+    }
+    return PCUDA_OK;
+  }
   for (int ry = 0; ry < st; ++ry)
     for (int rx = 0; rx < st; ++rx) {
       TapSet t = dgrad_taps(g, ry, rx);
@@ -563,7 +612,15 @@ extern "C" int pcuda_conv2d_pack_jobs_fill(const pcuda_conv_geom* g, int prec, c
   int nj = 0;
   size_t plane = fill_pack(jobs[nj], w, (uint16_t*)packed_fwd, prec, g->cout, g->cin, (long long)g->cin * kk, kk, fwd_taps(g));
   job_blocks[nj++] = (int)((plane + PACK_TABLE_ELEMS - 1) / PACK_TABLE_ELEMS);
-  if (packed_dgrad) {
+  if (packed_dgrad && dgrad_pair_ok(g)) {
+    uint16_t* out = (uint16_t*)packed_dgrad;
+    for (int ry = 0; ry < 2; ++ry) {
+      if (nj >= max_jobs) PCUDA_FAIL(PCUDA_E_BADARG, "pack_jobs_fill: more layouts than job slots");
+      plane = fill_pack(jobs[nj], w, out, prec, 2 * g->cin, g->cout, kk, (long long)g->cin * kk, dgrad_pair_taps(g, ry), true);
+      job_blocks[nj++] = (int)((plane + PACK_TABLE_ELEMS - 1) / PACK_TABLE_ELEMS);
+      out += plane;
+    }
+  } else if (packed_dgrad) {
     uint16_t* out = (uint16_t*)packed_dgrad;
     for (int ry = 0; ry < g->stride; ++ry)
       for (int rx = 0; rx < g->stride; ++rx) {

@@ -143,17 +143,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p, const i
   float* sred = (float*)smem;   // [4 waves][CO_TILE][2]
   // per-lane output pixel offsets (elements within a plane), computed once
   int poff[NPB];
-  bool pok[NPB];
+  bool pok[NPB], pok1[NPB];
 #pragma unroll
   for (int pb = 0; pb < NPB; ++pb) {
     const int ly = y0 + pty[pb], lx = x0 + ptx[pb];
     pok[pb] = pvalid[pb] & (ly < p.lh) & (lx < p.lw);
+    pok1[pb] = pok[pb] & (lx < p.lw2);   // (paired column classes: see igemm_pipe_kernel)
     poff[pb] = (ly * p.oy_mul + p.oy_off) * p.out_w + (lx * p.ox_mul + p.ox_off);
   }
   const int co0 = cot * CO_TILE;
   // fast path: the two half-waves (rows r0 and r0+4) of every register land in the same destination
   // tensor -> the plane base of row r0 is wave-uniform (SGPR) and lanes add a 32-bit offset
-  const bool uni = (p.y.c1 >= p.cout) | ((p.y.c1 & 7) == 0);
+  const bool uni = !p.pair & ((p.y.c1 >= p.cout) | ((p.y.c1 & 7) == 0));
   float* const yb1 = p.y.p1 + (long long)n * p.y.sn1;
   float* const yb2 = p.y.p2 + (long long)n * p.y.sn2;
 #pragma unroll
@@ -172,16 +173,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p, const i
         const long long hs = (cu < p.y.c1) ? p.y.sc1 : p.y.sc2;
         plane = base + (h ? 4 * hs : 0);
       } else {
-        const int cc = min(co, p.cout - 1);
+        const int cc = min(co, p.cout - 1) >> p.pair;
         plane = (cc < p.y.c1) ? yb1 + (long long)cc * p.y.sc1 : yb2 + (long long)(cc - p.y.c1) * p.y.sc2;
       }
+      const bool odd = (i & 1) & p.pair;
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int pb = 0; pb < NPB; ++pb) {
         float v = acc[cb][pb][i] + b;
         v = v > 0.f ? v : v * p.slope;
-        float* dst = plane + poff[pb];
-        if (cok & pok[pb]) {
+        float* dst = plane + poff[pb] + (odd ? 1 : 0);
+        if (cok & (odd ? pok1[pb] : pok[pb])) {
           if (p.accumulate) v += *dst;
           *dst = v;
           s1 += v;
@@ -679,15 +681,19 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
           }
         }
       } else {
-      unsigned pixo[NPB];
+      // (paired column classes, IgemmParams::pair: row 2c + rx is channel c, pixel 2 lx + rx -- registers i and i + 1 of
+      // a lane are the two halves of 8 consecutive bytes; pair = 0 leaves every index below as it was)
+      unsigned pixo[NPB], pixo1[NPB];
       bool pok[NPB];
 #pragma unroll
       for (int pb = 0; pb < NPB; ++pb) {
         const int ly = g.y0 + pty[pb], lx = g.x0 + ptx[pb];
         pok[pb] = pvalid[pb] & (ly < p.lh) & (lx < p.lw);
         pixo[pb] = pok[pb] ? (unsigned)((ly * p.oy_mul + p.oy_off) * p.out_w + (lx * p.ox_mul + p.ox_off)) * 4u : IG_OOB;
+        pixo1[pb] = (pok[pb] & (lx < p.lw2)) ? pixo[pb] + 4u : IG_OOB;
       }
-      const int c1 = min(p.y.c1, p.cout);
+      const int nch = p.cout >> p.pair;                         // channels of the destination(s)
+      const int c1 = min(p.y.c1, nch);
       float* const yb1 = p.y.p1 + (long long)g.n * p.y.sn1;
       float* const yb2 = p.y.p2 + (long long)g.n * p.y.sn2;
       const unsigned pl1 = (unsigned)p.y.sc1 * 4u, pl2 = (unsigned)p.y.sc2 * 4u;
@@ -697,20 +703,21 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
         for (int i = 0; i < 16; ++i) {
           const int row0 = cb * 32 + (i & 3) + 8 * (i >> 2);   // this register's row for h = 0; h = 1 is 4 rows on
           const int row = row0 + 4 * h;
-          const int cu = co0 + row0;                            // uniform; rows cu and cu + 4 lie in one destination
+          const int cu = (co0 + row0) >> p.pair;                // uniform; rows cu and cu + 4 lie in one destination
           const bool first = cu < c1;
           const unsigned plane = first ? pl1 : pl2;
           const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-              (void*)(first ? yb1 : yb2), 0, (int)((first ? c1 : p.cout - c1) * plane), 0x00020000);
+              (void*)(first ? yb1 : yb2), 0, (int)((first ? c1 : nch - c1) * plane), 0x00020000);
           const unsigned soff = (unsigned)(first ? cu : cu - c1) * plane;
-          const unsigned hoff = h ? 4u * plane : 0u;
+          const unsigned hoff = h ? (4u >> p.pair) * plane : 0u;
+          const bool odd = (i & 1) & p.pair;                    // uniform: the odd column class
           const float b = sbias[row];
           float s1 = 0.f, s2 = 0.f;
 #pragma unroll
           for (int pb = 0; pb < NPB; ++pb) {
             float v = acc[cb][pb][i] + b;
             v = v > 0.f ? v : v * p.slope;
-            const unsigned vo = pixo[pb] + hoff;
+            const unsigned vo = (odd ? pixo1[pb] : pixo[pb]) + hoff;
             if (p.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, soff, 0));
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, vo, soff, 0);
             if (STATS) {
@@ -920,7 +927,9 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
       const int ly = g.y0 + pty, lx = g.x0 + ptx;
       const bool pok = pvalid & (ly < p.lh) & (lx < p.lw);
       const unsigned pixo = pok ? (unsigned)((ly * p.oy_mul + p.oy_off) * p.out_w + (lx * p.ox_mul + p.ox_off)) * 4u : IG_OOB;
-      const int c1 = min(p.y.c1, p.cout);
+      const unsigned pixo1 = (pok & (lx < p.lw2)) ? pixo + 4u : IG_OOB;   // (paired column classes: see igemm_pipe_kernel)
+      const int nch = p.cout >> p.pair;
+      const int c1 = min(p.y.c1, nch);
       float* const yb1 = p.y.p1 + (long long)g.n * p.y.sn1;
       float* const yb2 = p.y.p2 + (long long)g.n * p.y.sn2;
       const unsigned pl1 = (unsigned)p.y.sc1 * 4u, pl2 = (unsigned)p.y.sc2 * 4u;
@@ -930,13 +939,13 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
         for (int i = 0; i < 16; ++i) {
           const int row0 = (cb0 + cb) * 32 + (i & 3) + 8 * (i >> 2);
           const int row = row0 + 4 * h;
-          const int cu = co0 + row0;
+          const int cu = (co0 + row0) >> p.pair;
           const bool first = cu < c1;
           const unsigned plane = first ? pl1 : pl2;
           const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-              (void*)(first ? yb1 : yb2), 0, (int)((first ? c1 : p.cout - c1) * plane), 0x00020000);
+              (void*)(first ? yb1 : yb2), 0, (int)((first ? c1 : nch - c1) * plane), 0x00020000);
           const unsigned soff = (unsigned)(first ? cu : cu - c1) * plane;
-          const unsigned vo = pixo + (h ? 4u * plane : 0u);
+          const unsigned vo = (((i & 1) & p.pair) ? pixo1 : pixo) + (h ? (4u >> p.pair) * plane : 0u);
           float v = acc[cb][i] + sbias[row];
           v = v > 0.f ? v : v * p.slope;
           if (p.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, soff, 0));

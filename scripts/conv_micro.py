@@ -13,6 +13,7 @@ CASES = {  # name: (n, cin, cout, h, w, k, s, p, d, up)
     "g256": (32, 256, 256, 32, 32, 3, 1, 1, 1, False),
     "b512": (32, 512, 512, 16, 16, 3, 1, 1, 1, False),
     "d2": (32, 64, 128, 129, 129, 4, 2, 2, 1, False),
+    "d3": (32, 128, 256, 65, 65, 4, 2, 2, 1, False),
     "d4": (32, 256, 512, 33, 33, 4, 2, 2, 1, False),
 }
 which = sys.argv[1:] or list(CASES)

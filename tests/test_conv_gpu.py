@@ -200,3 +200,42 @@ def test_deferred_split_k_reduces_are_bit_identical(dev, monkeypatch):
     op.wgrad(x, dy, ref[0][0], ref[0][1], hw, hw, accumulate=True)
     for (a, b), (c, d) in zip(ref, got):
         assert torch.equal(a, c) and torch.equal(b, d)
+
+
+# (n, cin, cout, h, w): k = 4, stride 2, pad 2 (GAN.py:97-105).  The data gradient of these layers runs one launch per
+# ROW parity with rows (channel, column parity) -- csrc/conv_host.h, dgrad_pair_ok -- so every shape of the pairing is
+# exercised here: odd and even maps (the odd class one column short), a single output column of the odd class missing
+# altogether (w = 1), ragged channel counts (the last co-tile half empty), cout = 1 (one reduction channel), the
+# benchmark's discriminator sizes.
+PAIR_CASES = [(2, 64, 128, 129, 129), (2, 128, 256, 65, 65), (2, 256, 512, 33, 33), (2, 512, 1, 17, 17), (3, 8, 16, 16, 16),
+              (2, 24, 40, 11, 14), (2, 96, 32, 20, 37), (1, 16, 8, 5, 1), (2, 40, 24, 2, 2), (2, 72, 64, 31, 64)]
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("case", PAIR_CASES)
+def test_stride2_dgrad_paired_column_classes(dev, case, prec):
+    from pointcloududa_amd import kernels as K
+    n, cin, cout, h, w_ = case
+    K.set_precision(prec)
+    try:
+        g = torch.Generator().manual_seed(hash(case) & 0xffff)
+        oh, ow = h // 2 + 1, w_ // 2 + 1
+        w = 0.1 * torch.randn(cout, cin, 4, 4, generator=g)
+        dy = torch.randn(n, cout, oh, ow, generator=g)
+        ref = F.grad.conv2d_input((n, cin, h, w_), w, dy, stride=2, padding=2)
+        op = K.ConvOp(cin, cout, 4, stride=2, pad=2)
+        dx = torch.full((n, cin, h, w_), float("nan"), device=dev)          # every element must be written
+        op.dgrad(dy.to(dev), w.to(dev), h, w_, dx=dx)
+        assert rel_err(dx, ref) < TOL[prec]
+        base = torch.randn(n, cin, h, w_, generator=g).to(dev)              # accumulate into an existing gradient
+        acc = base.clone()
+        op.dgrad(dy.to(dev), w.to(dev), h, w_, dx=acc, accumulate=True)
+        assert rel_err(acc - base, ref) < max(TOL[prec], 2e-4)
+        if cin % 16 == 0 and cin >= 16:                                     # the gradient split over two destinations
+            c1 = cin // 2
+            d1 = torch.full((n, c1, h, w_), float("nan"), device=dev)
+            d2 = torch.full((n, cin - c1, h, w_), float("nan"), device=dev)
+            op.dgrad(dy.to(dev), w.to(dev), h, w_, dx=d1, dx2=d2)
+            assert rel_err(torch.cat([d1, d2], 1), ref) < TOL[prec]
+    finally:
+        K.set_precision("bf16x3")
