@@ -24,12 +24,14 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     if not fs: continue
     recs = sorted(csv.DictReader(open(fs[0])), key=lambda r: int(r["Dispatch_Id"]))
     recs = [r for r in recs if r["Counter_Name"] == ctr and ("igemm" in r["Kernel_Name"] or "wgrad_kernel" in r["Kernel_Name"] or "wgrad3_kernel" in r["Kernel_Name"])]
-    # conv dispatches arrive in a fixed order: per case 11 forward launches, 11 x stride^2 dgrad launches (one per
-    # stride-parity class), 11 weight-gradient launches (their reduce kernels are filtered out above)
+    # conv dispatches arrive in a fixed order: per case 11 forward launches, 11 x dgrad launches per call (stride 1: one;
+    # k = 4 / stride 2 / pad 2: one per ROW parity, the column classes paired -- four with PCUDA_DGRAD_PAIR=0), 11
+    # weight-gradient launches (their reduce kernels are filtered out above)
     pos = 0
+    pair = os.environ.get("PCUDA_DGRAD_PAIR", "1") != "0"
     for ci, cs in enumerate(cases):
         st = GEOM[cs][6]
-        for op, cnt in enumerate((11, 11 * st * st, 11)):
+        for op, cnt in enumerate((11, 11 * (st * st if (st == 1 or not pair) else st), 11)):
             for r in recs[pos:pos + cnt]:
                 assert ("wgrad_kernel" in r["Kernel_Name"] or "wgrad3_kernel" in r["Kernel_Name"]) == (op == 2), (cs, op, r["Kernel_Name"])
                 rows[(ci, op)][ctr].append(float(r["Counter_Value"]))
@@ -44,7 +46,7 @@ with open("gpurun_out/%s_pmc_layers.csv" % tag, "w") as o:
         xin, yout = n * cin * h * w * 4 / 1e6, n * cout * oh * ow * 4 / 1e6
         alg = xin + yout
         f, wv = d.get("FETCH_SIZE", [0]), d.get("WRITE_SIZE", [0])
-        # per LAUNCH of the op: conv_micro runs every op 11 times; a dgrad of stride 2 is 4 kernels per op
+        # per CALL of the op: conv_micro runs every op 11 times; a dgrad of stride 2 is 2 (paired) or 4 kernels per call
         per = lambda v: sum(v) / 11.0
         o.write("%s,%s,%d,%d,%d,%d,%d,%d,%d,%d,%.1f,%.1f,%.1f,%.1f\n" % (cases[ci], ("fwd", "dgrad", "wgrad")[op], n, cin, cout, h, w, k, s,
                 len(f), per(f), per(wv), (2 * per(f) + per(wv)) / 1e3, alg))
