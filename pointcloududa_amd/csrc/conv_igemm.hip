@@ -72,11 +72,14 @@ __global__ void pack_multi_kernel(const PackJobs jobs) {
   }
 }
 
-// every repack of a network in ONE launch: the jobs (one per layout: forward + each dgrad parity class of every layer)
-// live in device memory; a workgroup owns PACK_TABLE_ELEMS consecutive elements of one job and finds it in the table of
-// first-block indices behind the jobs.  (Packed lazily, layer by layer, the 43 small launches of the segmenter sat in the
-// dependent chain of the next forward pass.)
-#define PACK_TABLE_ELEMS 2048
+// every repack of a network in ONE launch: the jobs (one per layout: forward + each dgrad image of every layer) live in
+// device memory; a workgroup finds its job in the table of first-block indices behind the jobs.  (Packed lazily, layer by
+// layer, the 43 small launches of the segmenter sat in the dependent chain of the next forward pass.)
+// A workgroup owns PACK_ROWS rows of one (co-tile, chunk) for EVERY tap: the fp32 source of those rows x 32 reduction
+// indices x all taps is a few whole lines, read once by the workgroup that needs all of it (round 3: with one tap per
+// workgroup the nine workgroups sharing a source line sat on different XCDs and FETCH_SIZE was 9x the weights, 673 MB per
+// launch for 76 MB), and each tap's PACK_ROWS records are whole lines of the packed image (8 x 144 B = 9 lines, 8 x 80 = 5).
+#define PACK_ROWS 8
 __global__ __launch_bounds__(256) void pack_table_kernel(const PackParams* __restrict__ jobs, const int* __restrict__ first_block,
                                                          int njobs) {
   int lo = 0, hi = njobs - 1;          // last job whose first block is <= blockIdx.x
@@ -85,28 +88,73 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const PackParams* __res
     if (first_block[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const PackParams& p = jobs[lo];
-  const long long total = (long long)p.n_co_tiles * p.nchunks * p.ntaps * p.co_tile * p.rec;
-  const long long base = (long long)((int)blockIdx.x - first_block[lo]) * PACK_TABLE_ELEMS;
-  for (int e = threadIdx.x; e < PACK_TABLE_ELEMS; e += 256) {
-    const long long idx = base + e;
-    if (idx >= total) break;
-    int col = (int)(idx % p.rec);
-    long long rest = idx / p.rec;
-    int row = (int)(rest % p.co_tile); rest /= p.co_tile;
-    int t = (int)(rest % p.ntaps); rest /= p.ntaps;
-    int ch = (int)(rest % p.nchunks);
-    int cot = (int)(rest / p.nchunks);
-    const bool is_lo = p.rec > IG_REC && col >= 32;
-    const int cc = is_lo ? col - 32 : col;
-    int r = cot * p.co_tile + row, c = ch * 32 + cc;
-    float v = 0.f;
-    if (cc < 32 && r < p.rows && c < p.red)
-      v = p.w[(p.pair ? r >> 1 : r) * p.s_row + c * p.s_red + p.tap_src[p.pair ? (r & 1) * p.ntaps + t : t]];
-    __bf16 hi16 = (__bf16)v;
-    if (is_lo) hi16 = (__bf16)(v - (float)hi16);
-    p.out[idx] = __builtin_bit_cast(uint16_t, hi16);
+  const int blk = (int)blockIdx.x - first_block[lo];
+  const int rgs = p.co_tile / PACK_ROWS;                      // row groups per co-tile (4 or 8)
+  const int rg = blk % rgs, ch = (blk / rgs) % p.nchunks, cot = blk / (rgs * p.nchunks);
+  if (cot >= p.n_co_tiles) return;
+  // the source of this group: (source row, reduction index) -> kk = k x k contiguous taps; a source row's reduction
+  // indices are contiguous for the forward image (s_red = kk), a reduction index's rows for the data gradient's
+  // (s_row = kk).  Copied run by run, in memory order, into LDS ([row][c][tap] resp. [c][row][tap]) and packed from there
+  // 8 values = one 16-byte vector per item: per ELEMENT index arithmetic (two divisions for two bytes) made the first
+  // form of this kernel instruction-bound at 0.2 TB/s.
+  __shared__ float sw[PACK_ROWS * 32 * IG_MAX_TAPS];
+  const int kk = (int)(p.s_row < p.s_red ? p.s_row : p.s_red);
+  const int nsr = PACK_ROWS >> p.pair, r0s = (cot * p.co_tile + rg * PACK_ROWS) >> p.pair, rows_src = p.rows >> p.pair;
+  const int c0 = ch * 32;
+  const int nr = min(nsr, rows_src - r0s), nc = min(32, p.red - c0);     // valid source rows / reduction indices
+  const bool by_row = p.s_red <= p.s_row;
+  for (int f = threadIdx.x; f < PACK_ROWS * 32 * kk; f += 256) sw[f] = 0.f;
+  __syncthreads();
+  {   // eight loads in flight per lane (one load per loop trip waited for each one: the kernel was latency-bound at 0.3 TB/s)
+    const int nseg = by_row ? nr : nc, runlen = (by_row ? nc : nr) * kk;
+    const long long seg_src = by_row ? p.s_row : p.s_red;
+    const int seg_lds = (by_row ? 32 : nsr) * kk;
+    const float* src0 = p.w + (by_row ? (long long)r0s * p.s_row + (long long)c0 * kk : (long long)r0s * kk + (long long)c0 * p.s_red);
+    const int total = nseg * runlen;
+    for (int base = 0; base < total; base += 256 * 8) {
+      float v[8];
+      int dst[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int idx = base + j * 256 + (int)threadIdx.x;
+        const int seg = idx / runlen, f = idx - seg * runlen;
+        dst[j] = idx < total ? seg * seg_lds + f : -1;
+        v[j] = idx < total ? src0[seg * seg_src + f] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (dst[j] >= 0) sw[dst[j]] = v[j];
+    }
+  }
+  __syncthreads();
+  const bool x3 = p.rec > IG_REC;
+  const int nvec = p.rec >> 3;                                // 16-byte vectors per record: 4 hi (+ 4 lo) + 1 pad
+  const int per_t = PACK_ROWS * nvec;
+  const long long tile0 = (long long)(cot * p.nchunks + ch) * p.ntaps;
+  for (int it = threadIdx.x; it < p.ntaps * per_t; it += 256) {
+    const int t = it / per_t, rem = it - t * per_t;
+    const int rowi = rem / nvec, vec = rem - rowi * nvec;
+    const bool pad = vec == nvec - 1, is_lo = x3 && vec >= 4;
+    const int cb = (vec & 3) * 8, ri = rowi >> p.pair;
+    const int ts = p.tap_src[p.pair ? (rowi & 1) * p.ntaps + t : t];
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v0 = 0.f, v1 = 0.f;
+      if (!pad) {
+        const int cc = cb + 2 * j;
+        v0 = sw[(by_row ? ri * 32 + cc : cc * nsr + ri) * kk + ts];
+        v1 = sw[(by_row ? ri * 32 + cc + 1 : (cc + 1) * nsr + ri) * kk + ts];
+      }
+      uint32_t hi, lo;
+      split2(v0, v1, hi, lo);
+      o[j] = is_lo ? lo : hi;
+    }
+    const int row = rg * PACK_ROWS + rowi;
+    *(uint4*)(p.out + ((tile0 + t) * p.co_tile + row) * p.rec + vec * 8) = make_uint4(o[0], o[1], o[2], o[3]);
   }
 }
+static inline int pack_table_blocks(const PackParams& p) { return p.n_co_tiles * p.nchunks * (p.co_tile / PACK_ROWS); }
 
 // ==========================================================================================
 // host side
@@ -611,13 +659,13 @@ extern "C" int pcuda_conv2d_pack_jobs_fill(const pcuda_conv_geom* g, int prec, c
   const int kk = g->k * g->k;
   int nj = 0;
   size_t plane = fill_pack(jobs[nj], w, (uint16_t*)packed_fwd, prec, g->cout, g->cin, (long long)g->cin * kk, kk, fwd_taps(g));
-  job_blocks[nj++] = (int)((plane + PACK_TABLE_ELEMS - 1) / PACK_TABLE_ELEMS);
+  job_blocks[nj] = pack_table_blocks(jobs[nj]); ++nj;
   if (packed_dgrad && dgrad_pair_ok(g)) {
     uint16_t* out = (uint16_t*)packed_dgrad;
     for (int ry = 0; ry < 2; ++ry) {
       if (nj >= max_jobs) PCUDA_FAIL(PCUDA_E_BADARG, "pack_jobs_fill: more layouts than job slots");
       plane = fill_pack(jobs[nj], w, out, prec, 2 * g->cin, g->cout, kk, (long long)g->cin * kk, dgrad_pair_taps(g, ry), true);
-      job_blocks[nj++] = (int)((plane + PACK_TABLE_ELEMS - 1) / PACK_TABLE_ELEMS);
+      job_blocks[nj] = pack_table_blocks(jobs[nj]); ++nj;
       out += plane;
     }
   } else if (packed_dgrad) {
@@ -628,7 +676,7 @@ extern "C" int pcuda_conv2d_pack_jobs_fill(const pcuda_conv_geom* g, int prec, c
         if (t.n == 0) continue;
         if (nj >= max_jobs) PCUDA_FAIL(PCUDA_E_BADARG, "pack_jobs_fill: more layouts than job slots");
         plane = fill_pack(jobs[nj], w, out, prec, g->cin, g->cout, kk, (long long)g->cin * kk, t);
-        job_blocks[nj++] = (int)((plane + PACK_TABLE_ELEMS - 1) / PACK_TABLE_ELEMS);
+        job_blocks[nj] = pack_table_blocks(jobs[nj]); ++nj;
         out += plane;
       }
   }

@@ -135,8 +135,20 @@ class AdversarialTrainer:
             m.train()
 
     # ------------------------------------------------------------------ one loop iteration
+    # PCUDA_TIMELINE=1 (diagnostics, scripts/step_timeline.py): timed events on the streams at the schedule's joints -- where
+    # each stream is when, without a profiler in the host's way.  Off: ``_mark`` returns at once.
+    _timeline = os.environ.get("PCUDA_TIMELINE", "0") == "1"
+
+    def _mark(self, label, stream=None):
+        if not self._timeline:
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream if stream is not None else torch.cuda.current_stream())
+        self.__dict__.setdefault("_marks", []).append((label, ev))
+
     def step(self, img_a, mask_a_u8, vert_a, img_b, vert_b, drop_mask=None, keep=False) -> Dict[str, torch.Tensor]:
         c, out = self.cfg, {}
+        self._mark("step")
         ms = c.variant == "mscmrseg"
         mode = "sigmoid" if (ms or not c.softmax) else "softmax"
         one = self._one
@@ -148,6 +160,7 @@ class AdversarialTrainer:
 
         # 1. supervised pass on the source batch (train_mscmrseg.py:200-213)
         o_s, _, vert_s = self.gen(img_a)
+        self._mark("fwd_src.end")
         l_main, l_jac = L.seg_loss(o_s, mask_a_u8, mode)
         seeds_t, seeds_g = [l_main, l_jac], [one, one]
         aux = c.d4aux and not ms
@@ -178,6 +191,7 @@ class AdversarialTrainer:
         if early:
             o_t, vert_t, prep, ev, adv_t, adv_g = self._phase2_forward(img_b, vert_b, drop_mask, out, o_s, pre_s)
         torch.autograd.backward(seeds_t, seeds_g)
+        self._mark("bwd_src.end")
         out["seg_dice"] = K.dice_metric(o_s.detach(), mask_a_u8)      # :215-216, on the device
         if keep:
             self.last = {"oS": o_s.detach(), "vertS": None if vert_s is None else vert_s.detach(),
@@ -197,6 +211,7 @@ class AdversarialTrainer:
                         self.opt_gen.all_reduce_grads_async(self.group, lo=split)[0])
             try:
                 torch.autograd.backward(adv_t, adv_g)
+                self._mark("bwd_adv.end")
             finally:
                 if eng is not None:
                     eng.after_deep_grads = None
@@ -214,6 +229,7 @@ class AdversarialTrainer:
         mode = "sigmoid" if (ms or not c.softmax) else "softmax"
         one = self._one
         o_t, _, vert_t = self.gen(img_b)
+        self._mark("fwd_tgt.end")
         norm = not ms
         pred_t = ent_t = tap_t = None
         if ms:
@@ -249,7 +265,9 @@ class AdversarialTrainer:
             if st is not None:
                 st.wait_stream(cur)
             with torch.cuda.stream(st if st is not None else cur):
+                self._mark(nm + ".fwd.start")
                 l = L.bce_logits_const(fwd(), 1.0, weight=wgt)
+                self._mark(nm + ".fwd.end")
             adv_t.append(l); adv_g.append(one); out[nm] = l.detach()
         # (no join here: autograd orders the backward nodes across streams, and the caller's stream waits for the
         # discriminator streams at the end of phase 4)
@@ -312,6 +330,7 @@ class AdversarialTrainer:
                     else:
                         st.wait_stream(main)
                 with torch.cuda.stream(st if st is not None else main):
+                    self._mark(nm + ".update.start")
                     dnet = getattr(self, "dis" + nm[1])
                     if nm != "d4" and self._replays(dnet) and getattr(dnet, "_cache", None) is not None:
                         # source batch: a forward pass; target batch: the activations of phase 2's frozen pass (the
@@ -355,6 +374,7 @@ class AdversarialTrainer:
                     # data-parallel: this network's all-reduce starts behind its own passes (on its stream), under the
                     # other discriminators' kernels
                     d_works[nm] = getattr(self, "opt_" + nm).all_reduce_grads_async(self.group)
+                    self._mark(nm + ".update.end")
             for st in side:
                 if st is not None:
                     main.wait_stream(st)
@@ -376,6 +396,7 @@ class AdversarialTrainer:
                     work, scale = d_works[nm]
                     o.finish_all_reduce(work)
                     o.step(scale)
+            self._mark("opt_d.end")
         if g_work is not None:      # no discriminator configured
             self.opt_gen.finish_all_reduce(g_work)
             self.opt_gen.step(g_scale)

@@ -239,3 +239,42 @@ def test_stride2_dgrad_paired_column_classes(dev, case, prec):
             assert rel_err(torch.cat([d1, d2], 1), ref) < TOL[prec]
     finally:
         K.set_precision("bf16x3")
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+def test_table_repack_matches_the_per_layer_pack(dev, prec):
+    """The one-launch repack of a network (kernels.repack_owner: what every optimiser step replays) writes the same packed
+    images, byte for byte, as the per-layer pack -- forward layouts, the four-class and the paired dgrad layouts
+    (discriminator: k = 4 / stride 2 / pad 2), 1x1 / 3x3 / dilated / 6x6 layers (segmenter)."""
+    from pointcloududa_amd import kernels as K
+    from pointcloududa_amd.networks import Segmentation_model_Point, UncertaintyDiscriminator
+    K.set_precision(prec)
+    try:
+        torch.manual_seed(3)
+        nets = [(UncertaintyDiscriminator(4).to(dev).train(), torch.randn(2, 4, 64, 64, device=dev)),
+                (Segmentation_model_Point(filters=8, in_channels=1, n_class=4, pointnet=True, fc_inch=1).to(dev).train(),
+                 torch.randn(2, 1, 96, 96, device=dev))]
+        for net, x in nets:
+            out = net(x.requires_grad_(True))
+            (out[0] if isinstance(out, tuple) else out).sum().backward()          # forward + dgrad images exist now
+            ops = [op for op in K._conv_ops if op.owner is net and op._last_fwd is not None]
+            assert len(ops) >= 5
+            with torch.no_grad():
+                for q in net.parameters():
+                    q.mul_(1.25).add_(0.01)                                         # (in place: same storage)
+            net._wgen = getattr(net, "_wgen", 0) + 1
+            assert K.repack_owner(net)
+            torch.cuda.synchronize()
+            got = [(op, {k: v[3].clone() for k, v in op._pk.items() if k[1] == K._precision}) for op in ops]
+            for op, packed in got:
+                w, g = op._last_fwd
+                assert packed, "no packed image"
+                for (kind, _), img in packed.items():
+                    fresh = torch.zeros_like(img)
+                    lib = K.L.lib()
+                    fn = lib.pcuda_conv2d_pack_fwd if kind == "fwd" else lib.pcuda_conv2d_pack_dgrad
+                    K.check(fn(K.C.byref(g), K._precision, w.data_ptr(), fresh.data_ptr(), K._stream()), "pack")
+                    torch.cuda.synchronize()
+                    assert torch.equal(img.view(torch.uint8), fresh.view(torch.uint8)), (kind, op.cin, op.cout, op.k)
+    finally:
+        K.set_precision("bf16x3")
