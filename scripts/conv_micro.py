@@ -14,6 +14,10 @@ CASES = {  # name: (n, cin, cout, h, w, k, s, p, d, up)
     "b512": (32, 512, 512, 16, 16, 3, 1, 1, 1, False),
     "d2": (32, 64, 128, 129, 129, 4, 2, 2, 1, False),
     "d3": (32, 128, 256, 65, 65, 4, 2, 2, 1, False),
+    # even-sized twins of the discriminator layers ("Round 3" item 10: what they measure is tile fit)
+    "d2e": (32, 64, 128, 128, 128, 4, 2, 2, 1, False), "d2f": (32, 64, 128, 126, 126, 4, 2, 2, 1, False),
+    "d3e": (32, 128, 256, 64, 64, 4, 2, 2, 1, False), "d3f": (32, 128, 256, 62, 62, 4, 2, 2, 1, False),
+    "d4e": (32, 256, 512, 32, 32, 4, 2, 2, 1, False), "d4f": (32, 256, 512, 30, 30, 4, 2, 2, 1, False),
     "d4": (32, 256, 512, 33, 33, 4, 2, 2, 1, False),
 }
 which = sys.argv[1:] or list(CASES)
