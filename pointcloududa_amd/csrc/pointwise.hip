@@ -57,6 +57,26 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   }
 }
 
+// One thread's share of a channel's per-tile partial pairs [tile][c][2], tiles t, t + 256, ... in that order (the order
+// is part of the result).  Eight 8-byte loads in flight per lane: one load per loop trip made the 8192-tile layers'
+// finalize kernels a chain of memory round trips (33 us for 2 MB).
+__device__ __forceinline__ void tile_pair_sum(const float* __restrict__ part, int ntiles, int c, int ch, double& s1, double& s2) {
+  const float2* p2 = (const float2*)part;
+  s1 = 0; s2 = 0;
+  int t = threadIdx.x;
+  for (; t + 7 * 256 < ntiles; t += 8 * 256) {
+    float2 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = p2[(long long)(t + j * 256) * c + ch];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1 += (double)v[j].x; s2 += (double)v[j].y; }
+  }
+  for (; t < ntiles; t += 256) {
+    const float2 v = p2[(long long)t * c + ch];
+    s1 += (double)v.x; s2 += (double)v.y;
+  }
+}
+
 // one workgroup per channel; fp64 finalisation in a fixed order (deterministic)
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int ntiles, int c,
                                                           double count, const float* __restrict__ gamma,
@@ -65,11 +85,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float* invstd, float* scale, float* shift) {
   __shared__ double sh[2][256];
   const int ch = blockIdx.x;
-  double s1 = 0, s2 = 0;
-  for (int t = threadIdx.x; t < ntiles; t += 256) {
-    s1 += (double)partials[((long long)t * c + ch) * 2 + 0];
-    s2 += (double)partials[((long long)t * c + ch) * 2 + 1];
-  }
+  double s1, s2;
+  tile_pair_sum(partials, ntiles, c, ch, s1, s2);
   sh[0][threadIdx.x] = s1;
   sh[1][threadIdx.x] = s2;
   __syncthreads();
@@ -166,11 +183,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               float* dbeta, int accumulate, float* coef) {
   __shared__ double sh[2][256];
   const int ch = blockIdx.x;
-  double s1 = 0, s2 = 0;
-  for (int t = threadIdx.x; t < ntiles; t += 256) {
-    s1 += (double)red[((long long)t * c + ch) * 2 + 0];
-    s2 += (double)red[((long long)t * c + ch) * 2 + 1];
-  }
+  double s1, s2;
+  tile_pair_sum(red, ntiles, c, ch, s1, s2);
   sh[0][threadIdx.x] = s1;
   sh[1][threadIdx.x] = s2;
   __syncthreads();
