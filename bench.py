@@ -375,7 +375,7 @@ def main():
                    # replayed from the adversarial pass, 7 of them execute for those two networks
                    "executed_gflop_per_pair": round(wl["gflop_per_pair"] - (2 * 3.60 * (wl.get("hw", 256) / 256.0) ** 2
                                                     * (int(wl["d1"]) + int(wl["d2"])) / 2.0 if tr.d_reuse else 0.0), 1),
-                   "box_to_box": "641-687 img/s measured for this command across MI355X boxes in round 3 (boxes of the pool differ by up to 10 % on one binary)",
+                   "box_to_box": "641-688 img/s measured for this command across MI355X boxes in round 3 (boxes of the pool differ by up to 10 % on one binary)",
                    "streams": "discriminators concurrent" if tr.d_streams else "single",
                    # d1 / d2 see the target batch twice per step with the same weights and the same input values
                    # (adversarial pass, then their own update): the second forward is replayed from the first's
