@@ -3,8 +3,9 @@
 ``UncertaintyDiscriminator`` (GAN.py:89-144) is the class both image discriminators of the train
 scripts instantiate (d1 on logits / probabilities, d2 on the entropy map).  Its five 4x4 stride-2
 convolutions run on the MFMA implicit-GEMM kernels; the adversarial gradient that flows back to
-the segmenter is the stride-2 *transposed* convolution (``conv2d_dgrad`` with one launch per
-output-parity class).  The other classes of the file keep their signatures and parameter names.
+the segmenter is the stride-2 *transposed* convolution (``conv2d_dgrad``: one launch per output ROW
+parity, the two column parities paired in one row tile).  The other classes of the file keep their signatures and
+parameter names.
 """
 from __future__ import annotations
 
