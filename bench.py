@@ -52,6 +52,13 @@ WORKLOADS = {
     "uda_512": dict(desc="STAND-IN for config 5 (no DeepLab in the reference): UNet(PointNet head, fc_inch=729) + d1 + d2 + d4, "
                          "512x512x1, 4 classes",
                     batch=8, d1=True, d2=True, d4=True, gflop_per_pair=1166.0, hw=512, fc_inch=729),
+    # The reference's REAL MS-CMRSeg operating point (train_mscmrseg.py:412-425): crop 224, 3-channel PNG slices,
+    # Segmentation_model_Point(filters=32, pointnet=True) with its constructor defaults in_channels=3, fc_inch=81; the
+    # image discriminators end in [B,1,8,8].  Not a BASELINE.json config (those are 256x256); the shape a user of the
+    # reference runs.  Work per pair: 6 x 28.28 + 2 x 8 x 2.78 + 8 x 0.17 GFLOP (SURVEY 8a5 / 8d convention).
+    "mscmrseg_224": dict(desc="MS-CMRSeg as the reference runs it: UNet(PointNet head, fc_inch=81) + d1 + d2 + d4, 224x224x3, 4 classes",
+                         batch=32, d1=True, d2=True, d4=True, gflop_per_pair=215.6, hw=224, fc_inch=81, in_channels=3,
+                         d_gflop=2.783),
 }
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
@@ -373,7 +380,7 @@ def main():
                    "algorithmic_gflop_per_pair": wl["gflop_per_pair"],
                    # the SURVEY 8d convention counts 8 passes per discriminator; with the target forward of d1 / d2
                    # replayed from the adversarial pass, 7 of them execute for those two networks
-                   "executed_gflop_per_pair": round(wl["gflop_per_pair"] - (2 * 3.60 * (wl.get("hw", 256) / 256.0) ** 2
+                   "executed_gflop_per_pair": round(wl["gflop_per_pair"] - (2 * wl.get("d_gflop", 3.60 * (wl.get("hw", 256) / 256.0) ** 2)
                                                     * (int(wl["d1"]) + int(wl["d2"])) / 2.0 if tr.d_reuse else 0.0), 1),
                    "box_to_box": "641-688 img/s measured for this command across MI355X boxes in round 3 (boxes of the pool differ by up to 10 % on one binary)",
                    "streams": "discriminators concurrent" if tr.d_streams else "single",

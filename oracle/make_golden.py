@@ -818,6 +818,16 @@ def gold_seg_full512():
              seed=510, full_tensors=False)
 
 
+def gold_full224():
+    """The reference's REAL MS-CMRSeg operating point (train_mscmrseg.py:412-425): crop_size = 224,
+    Segmentation_model_Point(filters=32, pointnet=args.d4) with the constructor DEFAULTS in_channels = 3, fc_inch = 81
+    (224 / 16 = 14, the 6x6 valid head convolution leaves 9 x 9 = 81 per channel), three discriminators at in_channel = 4
+    (image discriminators' output [B, 1, 8, 8]): forward + backward of the segmenter, and one full 5-phase step."""
+    cfg = ON.SegCfg(filters=32, in_channels=3, n_class=4, pointnet=True, fc_inch=81)
+    gold_seg("seg_full224", cfg, b=2, hw=224, seed=520, full_tensors=False)
+    gold_step("step_full224", cfg, b=4, hw=224, seed=620, n_steps=1, full=False)
+
+
 def gold_seg_variants():
     """Constructor variants the reference offers and its scripts never use (unet.py:25,29 batchnorm=False; :139-162
     Segmentation_model(feature_dis=True)): forward + backward of the REFERENCE modules."""
@@ -932,6 +942,7 @@ def main():
         gold_seg("seg_full256", full, b=2, hw=256, seed=500, full_tensors=False)
         gold_step("step_full256", full, b=4, hw=256, seed=600, n_steps=1, full=False)
         gold_seg_full512()
+        gold_full224()
 
 
 if __name__ == "__main__":
@@ -944,6 +955,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "full512":
         gold_seg_full512()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "full224":
+        gold_full224()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "flags":    # only the MM-WHS optional-branch fixtures
         gold_mmwhs_flags()

@@ -29,25 +29,28 @@ def predict_labels(seg_model, x: torch.Tensor) -> torch.Tensor:
 
 @torch.no_grad()
 def valid_batch(seg_model, x: torch.Tensor, y_onehot_u8: torch.Tensor, z: Optional[torch.Tensor] = None,
-                d4: bool = True) -> Dict[str, torch.Tensor]:
-    """One iteration of the reference's validation loop (``train_mscmrseg.py:67-92``); ``seg_model`` must be in
-    eval mode.  Returns device scalars: loss (l1 + l2 + l3), vert_loss (l3 or -1), dice (mean of classes 1..3),
-    plus the per-class Dice vector."""
+                d4: bool = True, variant: str = "mscmrseg", softmax: bool = True) -> Dict[str, torch.Tensor]:
+    """One iteration of the reference's validation loop; ``seg_model`` must be in eval mode.  Returns device scalars.
+    ``variant="mscmrseg"`` (``train_mscmrseg.py:67-92``): loss = BCE + Jaccard + point NN loss (l1 + l2 + l3), vert_loss
+    (l3 or -1), dice = mean of classes 1..3.  ``variant="mmwhs"`` (``train_mmwhs.py:65-90``): l1 = double-softmax CE
+    (``softmax``) or BCE, loss = l1 + l2 WITHOUT the point term (:82), dice = mean of classes 1..4 (``metrics2``)."""
     prediction, _, vert_s = seg_model(x)
-    l1, l2 = L.seg_loss(prediction, y_onehot_u8, "sigmoid")
+    ms = variant == "mscmrseg"
+    l1, l2 = L.seg_loss(prediction, y_onehot_u8, "sigmoid" if (ms or not softmax) else "softmax")
+    loss = l1 + l2
     if d4 and vert_s is not None and z is not None:
-        l3 = L.batch_NN_loss(vert_s, z)
-        vert = l3
-        loss = l1 + l2 + l3
+        vert = L.batch_NN_loss(vert_s, z)
+        if ms:
+            loss = loss + vert
     else:
         vert = torch.full((), -1.0, dtype=torch.float32, device=x.device)
-        loss = l1 + l2
     c = prediction.shape[1]
     dc = M.label_dice(M.argmax_labels(prediction), M.argmax_labels(y_onehot_u8), c)
-    return {"loss": loss, "vert_loss": vert, "dice": dc[1:4].mean(), "dice_per_class": dc}
+    return {"loss": loss, "vert_loss": vert, "dice": dc[1:(4 if ms else 5)].mean(), "dice_per_class": dc}
 
 
-def valid_model_with_one_dataset(seg_model, batches: Iterable, d4: bool = True) -> Dict[str, float]:
+def valid_model_with_one_dataset(seg_model, batches: Iterable, d4: bool = True, variant: str = "mscmrseg",
+                                 softmax: bool = True) -> Dict[str, float]:
     """``train_mscmrseg.py:53-99`` without the Hausdorff option: means over the batches of dice / loss /
     valid_vert_loss.  ``batches`` yields ``(x, y_onehot_u8, z)`` device tensors."""
     was_training = seg_model.training
@@ -55,7 +58,7 @@ def valid_model_with_one_dataset(seg_model, batches: Iterable, d4: bool = True) 
     acc = {"dice": [], "loss": [], "vert_loss": []}
     try:
         for x, y, z in batches:
-            r = valid_batch(seg_model, x, y, z, d4)
+            r = valid_batch(seg_model, x, y, z, d4, variant, softmax)
             for k in acc:
                 acc[k].append(r[k])
     finally:

@@ -19,6 +19,13 @@ CASES = {  # name: (n, cin, cout, h, w, k, s, p, d, up)
     "d3e": (32, 128, 256, 64, 64, 4, 2, 2, 1, False), "d3f": (32, 128, 256, 62, 62, 4, 2, 2, 1, False),
     "d4e": (32, 256, 512, 32, 32, 4, 2, 2, 1, False), "d4f": (32, 256, 512, 30, 30, 4, 2, 2, 1, False),
     "d4": (32, 256, 512, 33, 33, 4, 2, 2, 1, False),
+    # the reference's real MS-CMRSeg shape (224x224: train_mscmrseg.py:412): segmenter levels 224 / 112 / 56 / 28 / 14,
+    # discriminator maps 113 / 57 / 29
+    "m32": (32, 32, 32, 224, 224, 3, 1, 1, 1, False), "m64": (32, 64, 64, 112, 112, 3, 1, 1, 1, False),
+    "m128": (32, 128, 128, 56, 56, 3, 1, 1, 1, False), "m256": (32, 256, 256, 28, 28, 3, 1, 1, 1, False),
+    "mb512": (32, 512, 512, 14, 14, 3, 1, 1, 1, False), "mb512d8": (32, 512, 512, 14, 14, 3, 1, 8, 8, False),
+    "md2": (32, 64, 128, 113, 113, 4, 2, 2, 1, False), "md3": (32, 128, 256, 57, 57, 4, 2, 2, 1, False),
+    "md4": (32, 256, 512, 29, 29, 4, 2, 2, 1, False),
 }
 which = sys.argv[1:] or list(CASES)
 for name in which:

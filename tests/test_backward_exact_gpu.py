@@ -138,6 +138,10 @@ def _pn_table(trace):
     # model.eval() -- is a fixed affine in the backward pass
     (dict(filters=8, in_channels=3, n_class=5, pointnet=True, fc_inch=9), True, 2, 128, -1140),
     (dict(filters=4, in_channels=1, n_class=4, pointnet=True, fc_inch=9, batchnorm=False), False, 2, 128, 1150),
+    # the reference's real MS-CMRSeg shape, full width (train_mscmrseg.py:412-414): 224x224x3, fc_inch=81 -- maps of 14 / 28 / 56 /
+    # 112 pixels (off the 32-pixel tiles), dilation 8 on the 14-wide bottleneck, the aligned weight-gradient kernel's
+    # ragged cases
+    (dict(filters=32, in_channels=3, n_class=4, pointnet=True, fc_inch=81), False, 2, 224, 1160),
 ])
 def test_segmenter_backward_shared_routing(dev, cfg_kw, softmax, b, hw, seed):
     """encoder blocks + max-pool + dense-skip 1x1 convs, the dilated bottleneck and its running sum, the point head,
@@ -186,7 +190,8 @@ def test_segmenter_backward_shared_routing(dev, cfg_kw, softmax, b, hw, seed):
           % (worst[0], worst[1], e_dx, pre.get("tag"), pre.get("e", 0.0)))
 
 
-@pytest.mark.parametrize("inch,ext,hw,seed", [(4, False, 64, 1200), (5, True, 128, 1210), (4, False, 256, 1220)])
+@pytest.mark.parametrize("inch,ext,hw,seed", [(4, False, 64, 1200), (5, True, 128, 1210), (4, False, 256, 1220),
+                                                (4, False, 224, 1230)])      # 224: maps of 113 / 57 / 29 / 15 / 8
 def test_discriminator_backward_shared_routing(dev, inch, ext, hw, seed):
     """the full UncertaintyDiscriminator chain (stride-2 4x4 convolutions, their transposed-convolution input gradients
     per parity class, LeakyReLU(0.2) backward, the tap-unfolded first layer) under the domain loss"""

@@ -33,6 +33,19 @@ CASES = [
     (2, 64, 32, 32, 32, 3, 1, 1, 1, True, True, 1.0),       # decoder: nearest x2 folded into the conv
     (2, 4, 64, 16, 24, 4, 2, 2, 1, False, False, 0.2),      # stride-2 halo tile taller than the image, rows of 4k pixels
     (2, 8, 32, 12, 16, 3, 1, 1, 1, False, True, 0.01),      # 3x3 on a map shorter than one tile
+    # shapes the fixed-geometry weight-gradient kernel takes (csrc/conv_wgrad3.hip, w3_eligible: 3x3 / stride 1 / pad 1, cout >= 128
+    # and a multiple of 64, cin a multiple of 32, rows of 32k pixels, 4k rows): two tiles across, one tile across, one tile in
+    # all, three chunks x three co-tile pairs, and the 224x224 network's 32-multiple-free maps that must NOT take it (28, 56)
+    (2, 64, 128, 32, 64, 3, 1, 1, 1, False, True, 0.01),
+    (2, 128, 256, 8, 32, 3, 1, 1, 1, False, True, 0.01),
+    (1, 32, 128, 4, 32, 3, 1, 1, 1, False, True, 1.0),
+    (3, 96, 192, 12, 96, 3, 1, 1, 1, False, True, 0.01),
+    (2, 128, 128, 28, 28, 3, 1, 1, 1, False, True, 0.01),
+    (2, 64, 64, 56, 56, 3, 1, 1, 1, False, True, 0.01),
+    (2, 256, 512, 14, 14, 3, 1, 8, 8, False, True, 0.01),   # 224x224 bottleneck: dilation 8 on a 14-wide map
+    (2, 64, 300, 14, 14, 6, 1, 0, 1, False, True, 0.01),    # 224x224 point head: 6x6 valid on 14x14 -> 9x9
+    (2, 64, 128, 57, 57, 4, 2, 2, 1, False, False, 0.2),    # 224x224 discriminator maps
+    (2, 64, 128, 29, 29, 4, 2, 2, 1, False, False, 0.2),
     (3, 3, 64, 1, 300, 1, 1, 0, 1, False, True, 1.0),       # PointNet conv1d(k=1): H = 1
     (3, 128, 1024, 1, 300, 1, 1, 0, 1, False, True, 1.0),
 ]
@@ -131,6 +144,44 @@ def test_conv_concat_affine_split(dev):
     d1b = base.clone()
     op.dgrad(gz.to(dev), w.to(dev), h, w_, dx=d1b, dx2=d2, accumulate=True)
     assert rel_err(d1b - base, xin.grad[:, :c1]) < 1e-4
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("c1,c2,cout,h,w_", [(64, 64, 128, 16, 32), (32, 96, 192, 8, 64), (128, 0, 128, 12, 32)])
+def test_wgrad3_two_sources_and_affine_on_load(dev, prec, c1, c2, cout, h, w_):
+    """The fixed-geometry weight-gradient kernel's staging path with everything it can be handed at once: two sources
+    (zero-copy concat, both a multiple of 32 channels), the lazy-BatchNorm affine on the first, a bias gradient,
+    accumulation -- against the fp32 CPU gradient of the same convolution."""
+    from pointcloududa_amd import kernels as K
+    from pointcloududa_amd.kernels import TA
+    K.set_precision(prec)
+    try:
+        rng = np.random.default_rng(c1 * 7 + c2 + w_)
+        n = 2
+        a = torch.from_numpy(rng.normal(0, 1, (n, c1, h, w_)).astype(np.float32))
+        sc = torch.from_numpy(rng.normal(1, 0.3, (c1,)).astype(np.float32))
+        sf = torch.from_numpy(rng.normal(0, 0.3, (c1,)).astype(np.float32))
+        parts = [a * sc[None, :, None, None] + sf[None, :, None, None]]
+        b = None
+        if c2:
+            b = torch.from_numpy(rng.normal(0, 1, (n, c2, h, w_)).astype(np.float32))
+            parts.append(b)
+        xin = torch.cat(parts, 1)
+        wr = torch.from_numpy(rng.normal(0, 0.1, (cout, c1 + c2, 3, 3)).astype(np.float32)).requires_grad_(True)
+        br = torch.zeros(cout, requires_grad=True)
+        z = F.conv2d(xin, wr, br, padding=1)
+        gz = torch.from_numpy(rng.normal(0, 1, z.shape).astype(np.float32))
+        z.backward(gz)
+        op = K.ConvOp(c1 + c2, cout, 3, pad=1)
+        src = TA(a.to(dev), sc.to(dev), sf.to(dev))
+        dw = torch.full(wr.shape, float("nan"), device=dev)
+        db = torch.full((cout,), float("nan"), device=dev)
+        op.wgrad(src, gz.to(dev), dw, db, h, w_, x2=(b.to(dev) if c2 else None), accumulate=False)
+        assert rel_err(dw, wr.grad) < TOL[prec] and rel_err(db, br.grad) < 1e-4
+        op.wgrad(src, gz.to(dev), dw, db, h, w_, x2=(b.to(dev) if c2 else None), accumulate=True)
+        assert rel_err(dw, 2 * wr.grad) < TOL[prec] and rel_err(db, 2 * br.grad) < 1e-4
+    finally:
+        K.set_precision("bf16x3")
 
 
 @pytest.mark.parametrize("cin,cout,hw,k,s,p", [(32, 32, 256, 3, 1, 1), (64, 128, 129, 4, 2, 2), (256, 256, 32, 3, 1, 1)])

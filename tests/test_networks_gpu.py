@@ -69,6 +69,9 @@ def _check_grads(mod, g, tol, tol_elem=None):
     ("seg_full256", dict(filters=32, in_channels=1, n_class=4, pointnet=True, fc_inch=121), False),
     # stand-in for BASELINE config 5's input size (no DeepLab exists in the reference): the reference's segmenter at 512x512
     ("seg_full512", dict(filters=32, in_channels=1, n_class=4, pointnet=True, fc_inch=729), False),
+    # the reference's real MS-CMRSeg shape (train_mscmrseg.py:412-414): 224x224x3, constructor defaults in_channels=3, fc_inch=81:
+    # 14x14 bottleneck (dilation 8 on a 14-wide map), 28 / 56 / 112-wide levels, 9x9 head output
+    ("seg_full224", dict(filters=32, in_channels=3, n_class=4, pointnet=True, fc_inch=81), False),
     # extpn=True: two extra 3x3 convolutions in front of the point head (unet.py:81-83,90-92)
     ("seg_small_extpn", dict(filters=4, in_channels=1, n_class=4, pointnet=True, fc_inch=9, extpn=True), False),
     # batchnorm=False (unet.py:25,29): conv -> LeakyReLU -> conv -> LeakyReLU blocks; a constructor variant the reference

@@ -170,6 +170,9 @@ def _check_updates(tr, g, pre):
 @pytest.mark.parametrize("tag,cfg_kw,full,dflags", [
     ("step_small", dict(filters=4, in_channels=1, n_class=4, pointnet=True, fc_inch=9), True, (True, True, True)),
     ("step_full256", dict(filters=32, in_channels=1, n_class=4, pointnet=True, fc_inch=121), False, (True, True, True)),
+    # the reference's real MS-CMRSeg operating point (train_mscmrseg.py:412-425): 224x224x3, fc_inch=81, discriminator maps
+    # 113 / 57 / 29 / 15 / 8
+    ("step_full224", dict(filters=32, in_channels=3, n_class=4, pointnet=True, fc_inch=81), False, (True, True, True)),
     # BASELINE config 2 in miniature: train_mscmrseg.py -d2 (no point head, the entropy-map discriminator only)
     ("step_d2only_small", dict(filters=4, in_channels=1, n_class=4, pointnet=False), True, (False, True, False)),
 ])
@@ -364,6 +367,15 @@ def test_config5_standin_512_step(dev):
     worst = _full_size_property_step(dev, dict(filters=32, in_channels=1, n_class=4, pointnet=True, fc_inch=729), 8, 512,
                                      "mscmrseg", None, 0.99, 51, False)
     print("config 5 stand-in (512x512): worst first-step loss error against the CPU restatement %.2e" % worst)
+
+
+def test_mscmrseg_224_full_size_step(dev):
+    """The reference's real MS-CMRSeg operating point at its batch scale: 224x224x3 input, fc_inch=81 (train_mscmrseg.py:412-414),
+    the three discriminators, B = 32: bit-reproducible trajectory, first-step losses against the CPU restatement.  (The
+    segmenter and one step at this shape are pinned by tests/golden/seg_full224.npz / step_full224.npz from the reference.)"""
+    worst = _full_size_property_step(dev, dict(filters=32, in_channels=3, n_class=4, pointnet=True, fc_inch=81), 32, 224,
+                                     "mscmrseg", None, 0.99, 61, False)
+    print("MS-CMRSeg 224x224x3 B=32: worst first-step loss error against the CPU restatement %.2e" % worst)
 
 
 def test_graph_replay_matches_eager_steps(dev):
