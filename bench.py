@@ -255,12 +255,30 @@ def spawn_ranks(n, argv):
     print(box["last"], flush=True)
 
 
+def pin_rank_to_cores(local_rank, local_world):
+    """One process per GPU issues ~900 launches per step from Python: N ranks on one host must not migrate over each
+    other's cores.  Rank r of N takes the r-th contiguous slice of the cores this process may run on (cores / N each),
+    BEFORE its first GPU call, so the HIP runtime's helper threads inherit the mask.  PCUDA_NO_AFFINITY=1 leaves the
+    scheduler alone.  Returns the slice (tests)."""
+    if local_world <= 1 or os.environ.get("PCUDA_NO_AFFINITY") == "1" or not hasattr(os, "sched_setaffinity"):
+        return None
+    cores = sorted(os.sched_getaffinity(0))
+    per = len(cores) // local_world
+    if per < 1:
+        return None
+    mine = cores[local_rank * per:(local_rank + 1) * per]
+    os.sched_setaffinity(0, mine)
+    torch.set_num_threads(max(1, min(per, 4)))       # the host side of a step is one Python thread + small torch ops
+    return mine
+
+
 def dry_run(args, world, rank):
     """``--dry-run``: the launcher and the collective plumbing without a GPU (CPU tests): a gloo group of the spawned
     ranks, the same barrier + max-over-ranks timing, a surrogate step (an all-reduced vector), ONE JSON line."""
     import torch.distributed as dist
     if os.environ.get("PCUDA_DRYRUN_FAIL_RANK") == str(rank):      # (tests: a rank that dies during start-up)
         raise SystemExit(3)
+    cores = pin_rank_to_cores(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     if world > 1:
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     g = torch.full((1024,), float(rank + 1))
@@ -276,12 +294,22 @@ def dry_run(args, world, rank):
         dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
         dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
         dt, ranks = float(t[0]), int(t[1])
+        # every rank's core slice, gathered: the slices must be disjoint
+        mine = torch.full((64,), -1, dtype=torch.int64)
+        if cores:
+            mine[:min(64, len(cores))] = torch.tensor(cores[:64])
+        allc = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allc, mine)
+        core_sets = [sorted(int(c) for c in t_ if c >= 0) for t_ in allc]
         dist.barrier()
         dist.destroy_process_group()
+    else:
+        core_sets = [cores or []]
     if rank == 0:
         print(json.dumps({"metric": "dry-run (no kernels)", "value": round(ranks * args.steps / max(dt, 1e-9), 2), "unit": "steps/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle": args.settle,
-                          "config": {"workload": "dry-run", "ranks_in_group": ranks, "backend": "gloo"}}), flush=True)
+                          "config": {"workload": "dry-run", "ranks_in_group": ranks, "backend": "gloo",
+                                     "rank_cores": core_sets}}), flush=True)
 
 
 def main():
@@ -310,6 +338,7 @@ def main():
     if args.dry_run:
         dry_run(args, world, rank)
         return
+    pin_rank_to_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))    # before the first GPU call
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -339,7 +368,7 @@ def main():
 
     # PCUDA_GRAPH=1 (single process): replay the step from a captured hipGraph.  Off by default: measured 68.7 vs
     # 69.4 ms/step -- the ~4 ms between kernels is dependent-launch latency on the GPU, not host launch time.
-    use_graph = world == 1 and os.environ.get("PCUDA_GRAPH", "0") == "1"
+    use_graph = os.environ.get("PCUDA_GRAPH", "0") == "1"
     step = tr.step_graphed if use_graph else tr.step
     # settle phase (untimed setup, not part of --warmup): lazily created buffers, packed-weight caches, allocator pools
     # of the side streams and the GPU's clocks reach their steady state only after a second or two of work
@@ -365,12 +394,50 @@ def main():
     if not all(np.isfinite(v) for v in host.values()):
         raise SystemExit("non-finite loss in the benchmark step: %r" % host)
 
+    # host side of a step: time to ISSUE it (Python + launches, nothing waited for) and the library's launch count.  With
+    # N ranks on one host this, not the GPU, is what has to stay below ms_per_step.
+    n_issue = max(4, min(10, args.steps))
+    K.launch_count(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(n_issue):
+        step(*batch)
+    host_issue_ms = 1000.0 * (time.perf_counter() - t0) / n_issue
+    launches_per_step = K.launch_count(reset=True) / n_issue
+    sync()
+    # exposed communication: the same steps with the gradient all-reduces switched off on every rank
+    comm_exposed_ms = None
+    if dist is not None and not use_graph:
+        from pointcloududa_amd import optim as O
+        n_cmp = max(5, min(30, args.steps))
+
+        def timed(n):
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                step(*batch)
+            sync()
+            tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return 1000.0 * float(tt.item()) / n
+        with_c = timed(n_cmp)
+        O.set_collectives(False)
+        try:
+            for _ in range(3):
+                step(*batch)
+            without_c = timed(n_cmp)
+        finally:
+            O.set_collectives(None)
+        tr.broadcast_parameters()          # the replicas drifted apart while nothing was all-reduced
+        comm_exposed_ms = round(with_c - without_c, 3)
+
     result = {
         "metric": "adversarial train-step images/sec (seg+3 discr) at %dx%d" % (wl.get("hw", 256), wl.get("hw", 256)),
         "value": round(b * world * args.steps / dt, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "settle": args.settle, "ms_per_step": round(1000.0 * dt / args.steps, 3),
         "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
+        "host_issue_ms_per_step": round(host_issue_ms, 3), "launches_per_step": round(launches_per_step, 1),
+        "comm_exposed_ms": comm_exposed_ms,
         "dtype": "bf16x3 MFMA (split-bf16, fp32 accumulate; fp32 storage)" if args.precision == "bf16x3"
                  else "bf16 MFMA (fp32 accumulate; fp32 storage)",
         "data": "synthetic",
@@ -392,9 +459,10 @@ def main():
                    "losses": {k: round(host[k], 5) for k in ("seg_loss", "adv_loss") if k in host}},
     }
 
-    if rank == 0 and world == 1 and not args.no_roofline:
+    if not args.no_roofline:
+        # every rank runs the profiled steps (they hold collectives when world > 1); rank 0 reports its own kernels
         K.prof_reset()
-        K.prof_enable(True)
+        K.prof_enable(rank == 0)
         nprof = 2
         # per-launch durations are taken with the discriminator streams serialised (PCUDA_DSTREAMS=0 behaviour): kernels
         # that share the CUs with another stream's kernels would each be billed the shared time
@@ -411,9 +479,10 @@ def main():
         pms, pbytes, pl_n = K.prof_read(2)
         dms, dflops, dl_n = K.prof_read(3)
         K.prof_reset()
+    if rank == 0 and not args.no_roofline:
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         # the committed PMC passes were taken on the default command (full_uda, batch 32, bf16x3): only that run quotes them
-        same_cmd = args.workload == "full_uda" and b == wl["batch"] and args.precision == "bf16x3"
+        same_cmd = args.workload == "full_uda" and b == wl["batch"] and args.precision == "bf16x3" and world == 1
         traffic, traffic_src = pmc_traffic_per_launch() if same_cmd else (None, None)
         result["roofline"] = {
             "kernel": "igemm_pipe_kernel / igemm8_kernel (implicit-GEMM MFMA conv: forward + dgrad launches)", "bound": "mfma",

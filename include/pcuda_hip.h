@@ -45,6 +45,8 @@ typedef void* pcuda_stream_t; /* hipStream_t */
 int pcuda_version(void);                 /* ABI version of this header */
 int pcuda_device_count(void);            /* hipGetDeviceCount, 0 when no GPU */
 const char* pcuda_last_error(void);      /* text of the last failing call on this thread */
+const char* pcuda_build_hash(void);      /* sha256[:16] of the kernel sources the loaded library was compiled from */
+long long pcuda_launch_count(int reset); /* kernel launches issued by this library since the last reset (host-side count) */
 
 /* kernel-family timing (HIP events recorded on the launch stream around every launch of
  * a family while enabled; used by bench.py for the live roofline figure) */
@@ -386,6 +388,31 @@ int pcuda_adam_step_dev(float* p, const float* g, float* m, float* v, long long 
                         pcuda_stream_t s);
 int pcuda_sgd_step(float* p, const float* g, float* mom, long long numel, float lr, float momentum,
                    float weight_decay, int first_step, float grad_scale, pcuda_stream_t s);
+
+/* ------------------------------------------------------------------------------------
+ * "record" activations (csrc/conv_rec.hip): the 32- / 64-channel levels of the segmenter (unet.py:23-30,116-125 at full
+ * and half resolution) keep their activations in HBM as the MFMA consumes them -- per pixel and 32-channel chunk one
+ * 128-byte record, bf16 hi[32] | bf16 lo[32] (hi + lo = the fp32 value to 2^-17; 4 bytes per element like fp32), tensor
+ * layout [N][C/32][H][W][128 B] -- so that a convolution stages its input by LDS-DMA copies and writes its output
+ * records straight from the accumulators.
+ * ---------------------------------------------------------------------------------- */
+size_t pcuda_rec_bytes(int n, int c, int h, int w);
+/* NCHW fp32 (element strides sn / sc, dense planes) -> records, with an optional per-channel affine (a lazy BatchNorm:
+ * scale and shift both given or both NULL); channels past c inside the last chunk are zero */
+int pcuda_rec_from_nchw(const float* x, long long sn, long long sc, int n, int c, int h, int w, const float* scale,
+                        const float* shift, void* out, pcuda_stream_t s);
+int pcuda_rec_to_nchw(const void* rec, int n, int c, int h, int w, float* y, long long sn, long long sc, pcuda_stream_t s);
+/* weights of a 3x3 / stride 1 / pad 1 layer (nn.Conv2d OIHW fp32, unet.py:23,27,116,122), optionally scaled per INPUT
+ * channel (BatchNorm scale of the producing layer folded in), into the kernel's swizzled record image */
+size_t pcuda_rconv3_packed_bytes(int cout, int cin);
+int pcuda_rconv3_pack(const float* w, int cout, int cin, const float* in_scale, void* out, pcuda_stream_t s);
+int pcuda_rconv3_tiles(int n, int h, int w);       /* rows of the stats buffer */
+/* y = LeakyReLU_slope(conv3x3(x) + bias) on record tensors; pad_records [cin/32][128 B] is what the convolution reads
+ * outside the image (zeros; or, with a folded BatchNorm, the record of -shift/scale); stats [tiles][cout][2] receives the
+ * per-tile (sum, sum of squares) of the stored values (BatchNorm batch statistics, unet.py:26,30) or is NULL.
+ * Needs cin, cout multiples of 32, w a multiple of 32, h a multiple of 8: PCUDA_E_UNSUPPORTED otherwise. */
+int pcuda_rconv3_forward(const void* x, int n, int cin, int h, int w, const void* pad_records, const void* wpacked,
+                         const float* bias, float slope, int cout, void* y, float* stats, pcuda_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -43,6 +43,15 @@ _PROTOS = {
     "pcuda_version": (i32, []),
     "pcuda_device_count": (i32, []),
     "pcuda_last_error": (C.c_char_p, []),
+    "pcuda_build_hash": (C.c_char_p, []),
+    "pcuda_launch_count": (i64, [i32]),
+    "pcuda_rec_bytes": (sz, [i32, i32, i32, i32]),
+    "pcuda_rec_from_nchw": (i32, [vp, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "pcuda_rec_to_nchw": (i32, [vp, i32, i32, i32, i32, vp, i64, i64, vp]),
+    "pcuda_rconv3_packed_bytes": (sz, [i32, i32]),
+    "pcuda_rconv3_pack": (i32, [vp, i32, i32, vp, vp, vp]),
+    "pcuda_rconv3_tiles": (i32, [i32, i32, i32]),
+    "pcuda_rconv3_forward": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, f32, i32, vp, vp, vp]),
     "pcuda_prof_enable": (i32, [i32]),
     "pcuda_prof_reset": (i32, []),
     "pcuda_prof_read": (i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]),
@@ -148,21 +157,35 @@ def lib():
     return _lib
 
 
-def csrc_hash() -> str:
-    """sha256 over the kernel sources (csrc/*.hip, *.h, Makefile and include/pcuda_hip.h; names and bytes, sorted): what a
-    committed profile records next to its numbers, so that a figure measured on another build is never quoted as this
-    build's (bench.py refuses a traffic summary whose hash differs from the running tree's)"""
+def source_hash(csrc: str) -> str:
+    """sha256[:16] over the kernel sources (csrc/*.hip, *.h, Makefile and include/pcuda_hip.h; names and bytes, sorted).
+    The Makefile runs this same function to stamp the library (build/srchash.h -> pcuda_build_hash())."""
     import glob
     import hashlib
     h = hashlib.sha256()
-    csrc = os.path.join(_HERE, "csrc")
     files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) +
-                   [os.path.join(csrc, "Makefile"), os.path.join(os.path.dirname(_HERE), "include", "pcuda_hip.h")])
+                   [os.path.join(csrc, "Makefile"), os.path.join(os.path.dirname(os.path.dirname(csrc)), "include", "pcuda_hip.h")])
     for f in files:
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+def csrc_hash() -> str:
+    """The hash the LOADED library was compiled from (``pcuda_build_hash``): what a committed profile records next to its
+    numbers, so that a figure measured on another build is never quoted as this build's (bench.py refuses a traffic
+    summary whose hash differs).  ``tree_hash()`` is the same recipe over the sources on disk, when they are there."""
+    v = lib().pcuda_build_hash()
+    return v.decode() if v else "unknown"
+
+
+def tree_hash():
+    """hash of the sources on disk, or None when the package is installed without them"""
+    try:
+        return source_hash(os.path.join(_HERE, "csrc"))
+    except OSError:
+        return None
 
 
 def check(rc: int, what: str = ""):

@@ -28,6 +28,17 @@ void pcuda_set_error(const char* fmt, ...);
     if (e__ != hipSuccess) PCUDA_FAIL(PCUDA_E_LAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
   } while (0)
 
+// ---------------------------------------------------------------- launch count (prof.hip)
+// Every kernel launch of the library goes through hipLaunchKernelGGL: counted here (one relaxed atomic add on the host),
+// so that bench.py can report launches per step next to the host's issue time per step (pcuda_launch_count).
+extern long long g_pcuda_launches;
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, ...)                            \
+  do {                                                                 \
+    __atomic_fetch_add(&g_pcuda_launches, 1ll, __ATOMIC_RELAXED);      \
+    hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__);             \
+  } while (0)
+
 // ---------------------------------------------------------------- profiling hooks (prof.hip)
 // VMEM address rule (round 2, profiles/r02_two_process_determinism.txt).  On a GPU shared by two processes a vector-memory
 // load returned wrong data -- for whole 16-lane groups -- when the registers holding ITS ADDRESS were overwritten while it

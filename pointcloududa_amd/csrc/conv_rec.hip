@@ -1,0 +1,379 @@
+// "Record" activations: 3x3 / stride-1 / pad-1 convolution whose input (and output) tensors live in HBM ALREADY in the
+// form the MFMA consumes -- per pixel and 32-channel chunk one 128-byte record, bf16 hi[32] | bf16 lo[32] (hi + lo = the
+// fp32 value to 2^-17: the same 4 bytes per element as fp32) -- so that staging is a copy: LDS-DMA
+// (global_load_lds_dwordx4: no VGPR destination, no affine, no split, no transposition) instead of ~14 vector
+// instructions per staged value, and the epilogue writes records straight from the accumulators (a 32x32 MFMA lane
+// already holds 16 output channels of ONE pixel: after one v_permlane32_swap per register pair, two runs of 8 consecutive
+// channels = 16-byte pieces of that pixel's record).  Replaces, for the 32- / 64-channel levels of the segmenter
+// (unet.py:23-30,116-125 at 256x256 / 128x128), igemm_pipe_kernel's per-ELEMENT work: the layers that were issue-bound at
+// 24-27 % MFMA-pipe utilisation (profiles/r03_mfma_counters.csv).
+//
+// Tensor layout ("R32"):  [N][C / 32][H][W][64 x u16]   (u16[0..31] = bf16 hi of channels 32 cb + 0..31, [32..63] = lo)
+// LDS image of a haloed tile: the records row-major, 128 B each, the eight 16-byte pieces of record p XOR-swizzled by
+// (p >> 1) & 7 -- piece c sits in slot c ^ ((p >> 1) & 7) -- which makes every ds_read_b128 fragment read (16-lane
+// groups over consecutive records) conflict-free; LDS-DMA writes LDS lane-linearly, so the swizzle is applied to the
+// SOURCE address of each lane (cdna_hip_programming.md, rule 21).  The packed weights carry the same swizzle in global
+// memory and are copied linearly.
+#include "common.h"
+#include "conv_host.h"
+
+namespace {
+
+constexpr int REC_B = 128;             // bytes per record
+constexpr int RC_TH = 8, RC_TW = 32;   // output tile: 4 waves x 2 rows of 32 pixels
+constexpr int RC_HH = RC_TH + 2, RC_HW = RC_TW + 2;
+constexpr int RC_NREC = RC_HH * RC_HW;                 // 340 halo records
+constexpr int RC_XPIECES = (RC_NREC * 8 + 63) / 64;    // 43 one-KiB DMA pieces
+constexpr int RC_XBYTES = RC_XPIECES * 1024;           // 44032 (the last piece's tail is scratch)
+constexpr int RC_WBYTES = 9 * 32 * REC_B;              // 36864: nine taps x 32 rows
+constexpr int RC_NJ = (RC_XPIECES + 3) / 4;            // DMA pieces per wave (11)
+
+struct RConvParams {
+  const unsigned char* x;     // R32 input
+  long long x_sn;             // bytes per image
+  int cb_in;                  // input chunks (cin / 32)
+  int H, W;
+  const unsigned char* pad;   // [cb_in][128 B]: the record read outside the image (zeros, or -shift/scale of a folded BatchNorm)
+  const unsigned char* wpack; // [n_co_tiles][cb_in][9 taps][32 rows][128 B], swizzled
+  const float* bias;          // [cout] or null
+  float slope;
+  unsigned char* y;           // R32 output
+  long long y_sn;
+  int cout;
+  float* stats;               // [tiles][cout][2] partial (sum, sum of squares) of the stored values, or null
+  int tiles_x, tiles_y, n, n_co_tiles, total;
+};
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void dma16(const unsigned char* g, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void split8(const float* v, u32x4& hi4, u32x4& lo4) {
+  uint32_t a, b, c, d, e, f, g, hh;
+  split2(v[0], v[1], a, b); split2(v[2], v[3], c, d); split2(v[4], v[5], e, f); split2(v[6], v[7], g, hh);
+  hi4 = u32x4{a, c, e, g};
+  lo4 = u32x4{b, d, f, hh};
+}
+
+__device__ __forceinline__ bf16x8 frag(const unsigned char* p) { return __builtin_bit_cast(bf16x8, *(const uint4*)p); }
+
+template <bool STATS>
+__global__ __launch_bounds__(256, 2) void rconv3_kernel(const RConvParams p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  unsigned char* const Ws = smem;                 // (first: a tap's fragment address is a per-lane register + an immediate)
+  unsigned char* const Xs = smem + RC_WBYTES;
+  float* const sred = (float*)(Xs + RC_XBYTES);   // [4 waves][32][2]
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = p.H, W = p.W;
+
+  // XCD-aware persistent schedule (as igemm_pipe_kernel): the 8 XCDs own contiguous eighths of the item list, the
+  // workgroups of one XCD interleave over it -- concurrent workgroups of an L2 touch adjacent tiles (shared halo rows)
+  const int nx = min(8, (int)gridDim.x);
+  const int xcd = blockIdx.x % nx, slot = blockIdx.x / nx;
+  const int gx = ((int)gridDim.x - xcd + nx - 1) / nx;
+  const int lo = (int)((long long)p.total * xcd / nx), hi = (int)((long long)p.total * (xcd + 1) / nx);
+
+  // ---- tile-invariant DMA plan: piece j of this wave fills LDS bytes [(w + 4 j) KiB, + 1 KiB) of the X image
+  int xrel[RC_NJ], xpk[RC_NJ];
+#pragma unroll
+  for (int j = 0; j < RC_NJ; ++j) {
+    const int q = (w + 4 * j) * 64 + lane;
+    const int rec = min(q >> 3, RC_NREC - 1), s = q & 7;
+    const int c = s ^ ((rec >> 1) & 7);
+    const int ry = rec / RC_HW, rx = rec - ry * RC_HW;
+    xrel[j] = (ry * W + rx) * REC_B + c * 16;
+    xpk[j] = ry | (rx << 8) | (c << 16);
+  }
+  // ---- tile-invariant fragment addresses (bytes inside Xs / Ws): ks = 0 hi; ^32 -> ks = 1, ^64 -> lo
+  int xa[2][9];
+#pragma unroll
+  for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int pp = (2 * w + pb + t / 3) * RC_HW + r + (t % 3);
+      xa[pb][t] = pp * REC_B + ((h ^ ((pp >> 1) & 7)) << 4);
+    }
+  const int wa = r * REC_B + ((h ^ ((r >> 1) & 7)) << 4);   // tap t: + t * 4096 (the key of row t * 32 + r is (r >> 1) & 7)
+  const int wah[2] = {wa, wa ^ 32}, wal[2] = {wa ^ 64, wa ^ 96};
+
+  int wres = -1;   // (co-tile, chunk) whose weights are resident in Ws
+  f32x16 acc[2];
+  for (int L = lo + slot; L < hi; L += gx) {
+    const int cot = L % p.n_co_tiles, pt = L / p.n_co_tiles;
+    const int txi = pt % p.tiles_x, tmp = pt / p.tiles_x;
+    const int tyi = tmp % p.tiles_y, n = tmp / p.tiles_y;
+    const int y0 = tyi * RC_TH, x0 = txi * RC_TW;
+    const bool border = (y0 == 0) | (y0 + RC_TH == H) | (x0 == 0) | (x0 + RC_TW == W);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+    for (int chunk = 0; chunk < p.cb_in; ++chunk) {
+      __syncthreads();   // every wave is done reading the previous stage's X / W (and the epilogue's scratch)
+      // ---- stage: the haloed input tile, and the weights if another (co-tile, chunk) is resident
+      const unsigned char* xb = p.x + (long long)n * p.x_sn + ((long long)chunk * H * W + ((long long)(y0 - 1) * W + (x0 - 1))) * REC_B;
+      const unsigned char* padp = p.pad + chunk * REC_B;
+      if (border) {
+#pragma unroll
+        for (int j = 0; j < RC_NJ; ++j) {
+          if (w + 4 * j < RC_XPIECES) {
+            const int ry = xpk[j] & 0xff, rx = (xpk[j] >> 8) & 0xff, c = xpk[j] >> 16;
+            const bool in = ((unsigned)(y0 - 1 + ry) < (unsigned)H) & ((unsigned)(x0 - 1 + rx) < (unsigned)W);
+            const unsigned char* src = in ? xb + xrel[j] : padp + c * 16;
+            dma16(src, Xs + (w + 4 * j) * 1024);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < RC_NJ; ++j)
+          if (w + 4 * j < RC_XPIECES) dma16(xb + (unsigned)xrel[j], Xs + (w + 4 * j) * 1024);
+      }
+      const int wkey = cot * p.cb_in + chunk;
+      if (wkey != wres) {   // uniform
+        const unsigned char* wsrc = p.wpack + (long long)wkey * RC_WBYTES + lane * 16;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) dma16(wsrc + (w + 4 * j) * 1024, Ws + (w + 4 * j) * 1024);
+        wres = wkey;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      // ---- MFMA phase: 9 taps x 2 k-steps x (1 row block x 2 pixel blocks) x 3 products
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 ah = frag(Ws + wah[ks] + t * 32 * REC_B);
+          const bf16x8 al = frag(Ws + wal[ks] + t * 32 * REC_B);
+          bf16x8 bh[2], bl[2];
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) {
+            bh[pb] = frag(Xs + (xa[pb][t] ^ (ks * 32)));
+            bl[pb] = frag(Xs + (xa[pb][t] ^ (ks * 32) ^ 64));
+          }
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) {
+            acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[pb], acc[pb], 0, 0, 0);
+            acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[pb], acc[pb], 0, 0, 0);
+            acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[pb], acc[pb], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // ---- epilogue: bias + LeakyReLU, BatchNorm partial sums, records out.  Register i of a lane is output channel
+    // (i & 3) + 8 (i >> 2) + 4 h of pixel r of the block: swapping the upper half of register 4 j + e (j even) with the lower
+    // half of 4 (j + 1) + e leaves lane (r, h) with channels 8 h .. 8 h + 7 and 16 + 8 h .. 16 + 8 h + 7 of its pixel.
+    const int co0 = cot * 32;
+    float bia[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bia[i] = p.bias ? p.bias[co0 + (i & 3) + 8 * (i >> 2) + 4 * h] : 0.f;
+    float s1[16], s2[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+    unsigned char* const yb = p.y + (long long)n * p.y_sn + (long long)cot * H * W * REC_B;
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float t = acc[pb][i] + bia[i];
+        v[i] = fmaxf(t, t * p.slope);      // LeakyReLU for 0 <= slope <= 1 (slope 1: identity)
+        if (STATS) { s1[i] += v[i]; s2[i] = fmaf(v[i], v[i], s2[i]); }
+      }
+      // (inline asm: this hipcc folds the builtin's second result into its first -- the stored pieces repeated channels
+      // 8 j .. 8 j + 3, found with scripts/micro/rconv_debug.py; s_nop: VALU write -> permlane-swap read wait states)
+      asm volatile("s_nop 1\n\t"
+                   "v_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\t"
+                   "v_permlane32_swap_b32 %2, %6\n\tv_permlane32_swap_b32 %3, %7\n\t"
+                   "v_permlane32_swap_b32 %8, %12\n\tv_permlane32_swap_b32 %9, %13\n\t"
+                   "v_permlane32_swap_b32 %10, %14\n\tv_permlane32_swap_b32 %11, %15\n\t"
+                   "s_nop 1"
+                   : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                     "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+      unsigned char* const rec = yb + ((long long)(y0 + 2 * w + pb) * W + (x0 + r)) * REC_B;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        u32x4 hi4, lo4;
+        split8(&v[8 * jj], hi4, lo4);
+        *(u32x4*)(rec + (2 * jj + h) * 16) = hi4;
+        *(u32x4*)(rec + 64 + (2 * jj + h) * 16) = lo4;
+      }
+    }
+    if (STATS) {
+      // per channel: sum over the wave's 64 pixels (two blocks already added per lane), then over the four waves in a
+      // fixed order -- deterministic
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float a = half_wave_sum_hi16(s1[i]), b = half_wave_sum_hi16(s2[i]);
+        if (r == 31) {
+          const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+          sred[(w * 32 + row) * 2 + 0] = a;
+          sred[(w * 32 + row) * 2 + 1] = b;
+        }
+      }
+      __syncthreads();
+      if (tid < 32) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) { a += sred[(ww * 32 + tid) * 2 + 0]; b += sred[(ww * 32 + tid) * 2 + 1]; }
+        p.stats[((long long)pt * p.cout + co0 + tid) * 2 + 0] = a;
+        p.stats[((long long)pt * p.cout + co0 + tid) * 2 + 1] = b;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// layout conversions at the module boundary (and for tests): NCHW fp32 (+ per-channel affine) <-> R32
+// one thread = one 16-byte piece (8 channels of one pixel, hi or lo)
+__global__ void rec_from_nchw_kernel(const float* __restrict__ x, long long sn, long long sc, int c, int hw,
+                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                     unsigned char* __restrict__ out, long long total) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (n, cb, pixel, g): g = 8-channel group 0..3
+  if (gid >= total) return;
+  const int g = (int)(gid & 3);
+  const long long pix = (gid >> 2) % hw;
+  const long long ncb = (gid >> 2) / hw;
+  const int cbn = (c + 31) / 32;
+  const int cb = (int)(ncb % cbn);
+  const long long n = ncb / cbn;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ch = cb * 32 + g * 8 + j;
+    float t = 0.f;
+    if (ch < c) {
+      t = x[n * sn + (long long)ch * sc + pix];
+      if (scale) t = fmaf(t, scale[ch], shift[ch]);
+    }
+    v[j] = t;
+  }
+  u32x4 hi4, lo4;
+  split8(v, hi4, lo4);
+  unsigned char* rec = out + (ncb * hw + pix) * REC_B;
+  *(u32x4*)(rec + g * 16) = hi4;
+  *(u32x4*)(rec + 64 + g * 16) = lo4;
+}
+
+__global__ void rec_to_nchw_kernel(const unsigned char* __restrict__ in, int c, int hw, float* __restrict__ y, long long sn,
+                                   long long sc, long long total) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (n, ch, pixel)
+  if (gid >= total) return;
+  const long long pix = gid % hw;
+  const int ch = (int)((gid / hw) % c);
+  const long long n = gid / hw / c;
+  const int cbn = (c + 31) / 32;
+  const unsigned short* rec = (const unsigned short*)(in + ((n * cbn + ch / 32) * hw + pix) * REC_B);
+  const float hi = __builtin_bit_cast(float, (unsigned)rec[ch & 31] << 16);
+  const float lo = __builtin_bit_cast(float, (unsigned)rec[32 + (ch & 31)] << 16);
+  y[n * sn + (long long)ch * sc + pix] = hi + lo;
+}
+
+// weights: fp32 OIHW [cout][cin][3][3] (x optional per-input-channel scale: a folded BatchNorm) ->
+// [cout / 32][cin / 32][tap][row][128 B] with the LDS swizzle baked in.  One thread = one 16-byte piece.
+__global__ void rconv3_pack_kernel(const float* __restrict__ wsrc, int cout, int cin, const float* __restrict__ scale,
+                                   unsigned char* __restrict__ out, long long total) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (cot, chunk, tap, row, slot)
+  if (gid >= total) return;
+  const int s = (int)(gid & 7);
+  const int row = (int)((gid >> 3) & 31);
+  const int tap = (int)((gid >> 8) % 9);
+  const long long cc = (gid >> 8) / 9;
+  const int cbn = cin / 32;
+  const int chunk = (int)(cc % cbn), cot = (int)(cc / cbn);
+  const int q = tap * 32 + row;
+  const int c = s ^ ((q >> 1) & 7);          // the piece this slot holds
+  const int g = c & 3;
+  const bool lo_plane = c >= 4;
+  const int co = cot * 32 + row;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ci = chunk * 32 + g * 8 + j;
+    float t = co < cout ? wsrc[((long long)co * cin + ci) * 9 + tap] : 0.f;
+    if (scale) t *= scale[ci];
+    v[j] = t;
+  }
+  u32x4 hi4, lo4;
+  split8(v, hi4, lo4);
+  *(u32x4*)(out + gid * 16) = lo_plane ? lo4 : hi4;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" size_t pcuda_rec_bytes(int n, int c, int h, int w) { return (size_t)n * ((c + 31) / 32) * h * w * REC_B; }
+
+extern "C" int pcuda_rec_from_nchw(const float* x, long long sn, long long sc, int n, int c, int h, int w, const float* scale,
+                                   const float* shift, void* out, pcuda_stream_t stream) {
+  if (!x || !out || n <= 0 || c <= 0 || h <= 0 || w <= 0 || ((scale == nullptr) != (shift == nullptr)))
+    PCUDA_FAIL(PCUDA_E_BADARG, "rec_from_nchw: bad argument");
+  const long long total = (long long)n * ((c + 31) / 32) * h * w * 4;
+  hipLaunchKernelGGL(rec_from_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, sn, sc,
+                     c, h * w, scale, shift, (unsigned char*)out, total);
+  PCUDA_CHECK_LAUNCH("rec_from_nchw");
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_rec_to_nchw(const void* rec, int n, int c, int h, int w, float* y, long long sn, long long sc,
+                                 pcuda_stream_t stream) {
+  if (!rec || !y || n <= 0 || c <= 0 || h <= 0 || w <= 0) PCUDA_FAIL(PCUDA_E_BADARG, "rec_to_nchw: bad argument");
+  const long long total = (long long)n * c * h * w;
+  hipLaunchKernelGGL(rec_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned char*)rec, c, h * w, y, sn, sc, total);
+  PCUDA_CHECK_LAUNCH("rec_to_nchw");
+  return PCUDA_OK;
+}
+
+extern "C" size_t pcuda_rconv3_packed_bytes(int cout, int cin) { return (size_t)((cout + 31) / 32) * (cin / 32) * RC_WBYTES; }
+
+extern "C" int pcuda_rconv3_pack(const float* w, int cout, int cin, const float* in_scale, void* out, pcuda_stream_t stream) {
+  if (!w || !out || cout <= 0 || cin <= 0 || (cin & 31)) PCUDA_FAIL(PCUDA_E_BADARG, "rconv3_pack: cin must be a multiple of 32");
+  const long long total = (long long)((cout + 31) / 32) * (cin / 32) * 9 * 32 * 8;
+  hipLaunchKernelGGL(rconv3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, cout, cin,
+                     in_scale, (unsigned char*)out, total);
+  PCUDA_CHECK_LAUNCH("rconv3_pack");
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_rconv3_tiles(int n, int h, int w) { return n * (h / RC_TH) * (w / RC_TW); }
+
+extern "C" int pcuda_rconv3_forward(const void* x, int n, int cin, int h, int w, const void* pad_records, const void* wpacked,
+                                    const float* bias, float slope, int cout, void* y, float* stats, pcuda_stream_t stream) {
+  if (!x || !wpacked || !y || !pad_records || n <= 0) PCUDA_FAIL(PCUDA_E_BADARG, "rconv3_forward: null argument");
+  if ((cin & 31) || (cout & 31) || (w % RC_TW) || (h % RC_TH))
+    PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "rconv3_forward: needs cin, cout multiples of 32, rows of 32 k pixels, 8 k rows (got %d -> %d at %dx%d)",
+               cin, cout, h, w);
+  if (slope < 0.f || slope > 1.f) PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "rconv3_forward: slope outside [0, 1]");
+  RConvParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = (const unsigned char*)x; p.cb_in = cin / 32; p.H = h; p.W = w;
+  p.x_sn = (long long)p.cb_in * h * w * REC_B;
+  p.pad = (const unsigned char*)pad_records; p.wpack = (const unsigned char*)wpacked; p.bias = bias; p.slope = slope;
+  p.y = (unsigned char*)y; p.cout = cout; p.y_sn = (long long)(cout / 32) * h * w * REC_B;
+  p.stats = stats;
+  p.tiles_x = w / RC_TW; p.tiles_y = h / RC_TH; p.n = n; p.n_co_tiles = cout / 32;
+  p.total = n * p.tiles_x * p.tiles_y * p.n_co_tiles;
+  const size_t lds = RC_XBYTES + RC_WBYTES + 4 * 32 * 2 * sizeof(float);
+  int ncu = 256;
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+  }
+  const int grid = p.total < 2 * ncu ? p.total : 2 * ncu;
+  char tag[128];
+  snprintf(tag, sizeof(tag), "rconv3 n%d cin%d cout%d %dx%d lds%zu", n, cin, cout, h, w, lds);
+  ProfScope prof(PCUDA_FAM_CONV_FWD, 2.0 * n * (double)h * w * cout * (double)cin * 9, (hipStream_t)stream, tag);
+  auto launch = [&](auto kern) -> int {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HARD);
+    if (e != hipSuccess) PCUDA_FAIL(PCUDA_E_LAUNCH, "rconv3: cannot raise dynamic LDS: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+    return PCUDA_OK;
+  };
+  const int rc = stats ? launch(rconv3_kernel<true>) : launch(rconv3_kernel<false>);
+  if (rc != PCUDA_OK) return rc;
+  PCUDA_CHECK_LAUNCH("rconv3_kernel");
+  return PCUDA_OK;
+}

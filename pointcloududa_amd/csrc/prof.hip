@@ -17,6 +17,15 @@ void pcuda_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* pcuda_last_error(void) { return g_err; }
+
+long long g_pcuda_launches = 0;
+extern "C" long long pcuda_launch_count(int reset) {
+  return reset ? __atomic_exchange_n(&g_pcuda_launches, 0ll, __ATOMIC_RELAXED) : __atomic_load_n(&g_pcuda_launches, __ATOMIC_RELAXED);
+}
+// sha256[:16] over the kernel sources this library was compiled from (the Makefile writes build/srchash.h with the
+// same recipe as pointcloududa_amd._lib.csrc_hash): a profile is stamped with THIS, not with the tree's hash
+#include "srchash.h"
+extern "C" const char* pcuda_build_hash(void) { return PCUDA_SRC_HASH; }
 extern "C" int pcuda_version(void) { return 1; }
 extern "C" int pcuda_device_count(void) {
   int n = 0;

@@ -892,5 +892,51 @@ def prof_read(family: int):
     return ms.value, work.value, n.value
 
 
+def launch_count(reset: bool = False) -> int:
+    """kernel launches issued by the library since the last reset (host-side counter)"""
+    return int(L.lib().pcuda_launch_count(1 if reset else 0))
+
+
 def prof_dump(path: str):
     check(L.lib().pcuda_prof_dump(path.encode()), "prof_dump")
+
+
+# ------------------------------------------------------------------------------------------
+# "record" activations (csrc/conv_rec.hip): [N][C/32][H][W][128 B] = bf16 hi[32] | bf16 lo[32] per pixel and chunk
+# ------------------------------------------------------------------------------------------
+def rec_from_nchw(x: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """NCHW fp32 (+ per-channel affine) -> record tensor, uint8 [N, ceil(C/32), H, W, 128]"""
+    n, c, hw, sn, sc = _planes(x)
+    h, w = x.shape[2], x.shape[3]
+    out = torch.empty((n, (c + 31) // 32, h, w, 128), dtype=torch.uint8, device=x.device)
+    check(L.lib().pcuda_rec_from_nchw(x.data_ptr(), sn, sc, n, c, h, w, _ptr(scale), _ptr(shift), out.data_ptr(), _stream()),
+          "rec_from_nchw")
+    return out
+
+
+def rec_to_nchw(rec: torch.Tensor, c: int) -> torch.Tensor:
+    n, cb, h, w, _ = rec.shape
+    y = torch.empty((n, c, h, w), dtype=torch.float32, device=rec.device)
+    check(L.lib().pcuda_rec_to_nchw(rec.data_ptr(), n, c, h, w, y.data_ptr(), c * h * w, h * w, _stream()), "rec_to_nchw")
+    return y
+
+
+def rconv3_pack(w: torch.Tensor, in_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    cout, cin = w.shape[0], w.shape[1]
+    out = torch.empty(L.lib().pcuda_rconv3_packed_bytes(cout, cin), dtype=torch.uint8, device=w.device)
+    check(L.lib().pcuda_rconv3_pack(w.contiguous().data_ptr(), cout, cin, _ptr(in_scale), out.data_ptr(), _stream()), "rconv3_pack")
+    return out
+
+
+def rconv3_forward(xrec: torch.Tensor, wpacked: torch.Tensor, bias: Optional[torch.Tensor], slope: float, cout: int,
+                   pad_records: Optional[torch.Tensor] = None, want_stats: bool = False):
+    """3x3 / stride 1 / pad 1 on record tensors -> (yrec, stats[tiles][cout][2] or None, tiles)"""
+    n, cb, h, w, _ = xrec.shape
+    if pad_records is None:
+        pad_records = torch.zeros((cb, 128), dtype=torch.uint8, device=xrec.device)
+    y = torch.empty((n, cout // 32, h, w, 128), dtype=torch.uint8, device=xrec.device)
+    nt = L.lib().pcuda_rconv3_tiles(n, h, w)
+    stats = torch.empty((nt, cout, 2), dtype=torch.float32, device=xrec.device) if want_stats else None
+    check(L.lib().pcuda_rconv3_forward(xrec.data_ptr(), n, cb * 32, h, w, pad_records.data_ptr(), wpacked.data_ptr(), _ptr(bias),
+                                       float(slope), cout, y.data_ptr(), _ptr(stats), _stream()), "rconv3_forward")
+    return y, stats, nt

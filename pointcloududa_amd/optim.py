@@ -53,13 +53,24 @@ def flatten_module(module: nn.Module):
     return flat, grad
 
 
+_collectives_override = None     # None: automatic; False: off (bench.py's "step without communication" leg)
+
+
+def set_collectives(mode) -> None:
+    """``False``: run the step without its gradient all-reduces even in a multi-rank group (measurement only: bench.py's
+    ``comm_exposed_ms`` = step time with the collectives minus step time without; every rank must switch together).
+    ``None``: automatic again."""
+    global _collectives_override
+    _collectives_override = mode
+
+
 def _collectives_on(group=None) -> bool:
     """True when gradients have to be all-reduced: an initialised process group of more than one rank.
     ``PCUDA_FORCE_COLLECTIVES=1`` keeps the collectives in a one-rank group too (to exercise the RCCL path -- stream
     ordering, async handles -- on a single-GPU machine)."""
     import os
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()):
+    if _collectives_override is False or not (dist.is_available() and dist.is_initialized()):
         return False
     return dist.get_world_size(group) > 1 or os.environ.get("PCUDA_FORCE_COLLECTIVES") == "1"
 
@@ -153,7 +164,13 @@ class FusedAdam(_FlatOptimizer):
         step = int(self.step_t.item())
         state = {}
         if step > 0:
-            for i, (o, n, shp) in enumerate(self._slices()):
+            sl = self._slices()
+            # torch.optim.Adam holds no state for a parameter whose .grad was always None (the reference's never-used
+            # encoder.conv1_1; the point head without a loss on it): here that is a second moment that is still all zero
+            used = torch.stack([self.v[o:o + n].max() for o, n, _ in sl]).gt(0).tolist()        # one transfer
+            for i, (o, n, shp) in enumerate(sl):
+                if not used[i]:
+                    continue
                 state[i] = {"step": torch.tensor(float(step)), "exp_avg": self.m[o:o + n].view(shp).clone(),
                             "exp_avg_sq": self.v[o:o + n].view(shp).clone()}
         group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "amsgrad": False,
@@ -216,6 +233,8 @@ class FusedSGD(_FlatOptimizer):
         state = {}
         if self.buf is not None and self.steps > 0:
             for i, (o, n, shp) in enumerate(self._slices()):
+                if not any(lo <= o and o + n <= hi for lo, hi in self.ranges):
+                    continue          # a skipped parameter (.grad is None in the reference): torch.optim.SGD holds no state for it
                 state[i] = {"momentum_buffer": self.buf[o:o + n].view(shp).clone()}
         group = {"lr": self.lr, "momentum": self.momentum, "dampening": 0, "weight_decay": self.wd, "nesterov": False,
                  "maximize": False, "foreach": None, "differentiable": False, "fused": None,
@@ -230,7 +249,8 @@ class FusedSGD(_FlatOptimizer):
             self.buf.zero_()
             for i, (o, n, shp) in enumerate(self._slices()):
                 st = sd["state"].get(i, sd["state"].get(str(i)))
-                if st is not None and st.get("momentum_buffer") is not None:
+                if st is not None and st.get("momentum_buffer") is not None and \
+                        any(lo <= o and o + n <= hi for lo, hi in self.ranges):      # (skipped ranges stay zero)
                     self.buf[o:o + n].copy_(st["momentum_buffer"].reshape(-1))
                     loaded = True
         self.steps = 1 if loaded else 0   # "first step" only decides whether the momentum buffer is initialised

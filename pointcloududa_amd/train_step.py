@@ -22,7 +22,7 @@ from typing import Dict, Optional
 import torch
 
 from . import kernels as K
-from .optim import FusedAdam, FusedSGD, _collectives_on
+from .optim import FusedAdam, FusedSGD, _FlatOptimizer as _FlatOpt, _collectives_on
 from .utils import loss as L
 
 
@@ -88,6 +88,7 @@ class AdversarialTrainer:
         self.d_reuse = os.environ.get("PCUDA_DREUSE", "1") != "0"
         # ... with the source batch's activations written in front of the cached target ones: one backward pass over 2B
         self.d_joint = os.environ.get("PCUDA_DJOINT", "1") != "0"
+        self._segment = None      # "compute": step() leaves out the collectives and the optimiser steps (step_graphed)
 
     def _side_streams(self, names):
         """One side stream PER DISCRIMINATOR, keyed by its name: a network's frozen pass (phase 2), its input-gradient
@@ -204,7 +205,7 @@ class AdversarialTrainer:
         g_works, split = [], 0
         if adv_t:
             eng = getattr(self.gen, "_engine", None)
-            if eng is not None and self.bucketed and _collectives_on(self.group):
+            if eng is not None and self.bucketed and _collectives_on(self.group) and self._segment is None:
                 split = self.opt_gen.split_after("encoder.")
                 if split:
                     eng.after_deep_grads = lambda: g_works.append(
@@ -297,10 +298,14 @@ class AdversarialTrainer:
         # the all-reduce (the encoder's slice, or everything if no bucket went out during the backward pass) starts
         # now, and Adam is applied after the discriminator passes, which hide it.  Single process: no collective, same
         # order of arithmetic as the reference.
-        w_rest, g_scale = self.opt_gen.all_reduce_grads_async(self.group, lo=0, hi=(split or None))
-        g_work = [w for w in g_works + [w_rest] if w is not None] or None
-        if g_work is None:
-            self.opt_gen.step(g_scale)
+        compute_only = self._segment == "compute"      # step_graphed with collectives: gradients only, see there
+        if compute_only:
+            g_work, g_scale = None, 1.0
+        else:
+            w_rest, g_scale = self.opt_gen.all_reduce_grads_async(self.group, lo=0, hi=(split or None))
+            g_work = [w for w in g_works + [w_rest] if w is not None] or None
+            if g_work is None:
+                self.opt_gen.step(g_scale)
 
         # 3./4. discriminators: source batch as 1, target batch as 0 (:250-322)
         if self._dis():
@@ -373,7 +378,7 @@ class AdversarialTrainer:
                             out[nm + "_loss_" + tag], out[hit + "_hit_" + tag] = l.detach(), acc
                     # data-parallel: this network's all-reduce starts behind its own passes (on its stream), under the
                     # other discriminators' kernels
-                    d_works[nm] = getattr(self, "opt_" + nm).all_reduce_grads_async(self.group)
+                    d_works[nm] = (None, 1.0) if compute_only else getattr(self, "opt_" + nm).all_reduce_grads_async(self.group)
                     self._mark(nm + ".update.end")
             for st in side:
                 if st is not None:
@@ -392,7 +397,7 @@ class AdversarialTrainer:
                 g_work = None
             for nm in ("d1", "d2", "d4"):
                 o = getattr(self, "opt_" + nm)
-                if o is not None:
+                if o is not None and not compute_only:
                     work, scale = d_works[nm]
                     o.finish_all_reduce(work)
                     o.step(scale)
@@ -402,18 +407,32 @@ class AdversarialTrainer:
             self.opt_gen.step(g_scale)
 
     # ------------------------------------------------------------------ the same iteration as one hipGraph
-    def step_graphed(self, img_a, mask_a_u8, vert_a, img_b, vert_b) -> Dict[str, torch.Tensor]:
-        """``step`` replayed from a captured hipGraph (single process only: the RCCL all-reduce stays eager).
+    def apply_updates(self, grad_scale: float = 1.0):
+        """phase 5 on its own (:247,:325-330): every optimiser's step on the gradients as they stand (x grad_scale)"""
+        for o in [self.opt_gen] + self._d_opts():
+            o.step(grad_scale)
 
-        The ~650 kernel launches of a step leave the GPU idle for a few milliseconds between kernels when driven
-        from Python; a graph replay removes that.  Every call advances exactly one step: the first two run eagerly
-        (every lazily created buffer, packed-weight cache and kernel attribute exists afterwards), the third
-        captures and replays, later calls copy the batch into the captured input buffers and replay.  Learning rates are baked into the capture
-        (re-capture after changing them: ``self._graph = None``); Adam's step count lives on the device.
-        Falls back to ``step`` if capture is not possible."""
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            return self.step(img_a, mask_a_u8, vert_a, img_b, vert_b)
+    def step_graphed(self, img_a, mask_a_u8, vert_a, img_b, vert_b) -> Dict[str, torch.Tensor]:
+        """``step`` replayed from captured hipGraphs.
+
+        The ~850 kernel launches of a step cost the host ~24 ms to issue from Python (bench.py: host_issue_ms_per_step);
+        one process that is enough to stay ahead of a 47 ms GPU step, eight ranks on one host share its cores.  A
+        replay is one launch.  Every call advances exactly one step: the first two run eagerly (every lazily created
+        buffer, packed-weight cache and kernel attribute exists afterwards), the third captures, later calls copy the
+        batch into the captured input buffers and replay.
+
+        Data parallel: a collective cannot sit inside the capture here (this torch's RCCL watchdog queries the
+        collective's event, which HIP forbids for an event recorded on a capturing stream: the process aborts --
+        measured, round 4).  The step is therefore captured in TWO graphs around the exchange: graph A = phases 1-4
+        (every forward / backward pass, gradients complete in the flat buffers; ``_segment = "compute"``), then the
+        all-reduces of the four flat buffers issued eagerly -- four calls, any backend -- then graph B = phase 5 (the
+        optimiser kernels with the 1 / world mean folded in, and the weight repacks).  What this gives up against the
+        eager schedule is the overlap of the segmenter's all-reduce with the discriminator passes (``comm_exposed_ms``
+        of bench.py prices it); the arithmetic is the eager step's, kernel for kernel.
+
+        Learning rates are baked into the capture (re-capture after changing them: ``self._graph = None``); Adam's step
+        count lives on the device.  Falls back to ``step`` if capture is not possible."""
+        coll = _collectives_on(self.group)
         batch = (img_a, mask_a_u8, vert_a, img_b, vert_b)
         if getattr(self, "_graph", None) is None:
             self._gcalls = getattr(self, "_gcalls", 0) + 1
@@ -423,19 +442,35 @@ class AdversarialTrainer:
                 torch.cuda.synchronize()
                 self._gin = tuple(t.clone() for t in batch)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):   # records only: nothing executes during capture
-                    self._gout = self.step(*self._gin)
+                self._segment = "compute" if coll else None
+                try:
+                    with torch.cuda.graph(graph):   # records only: nothing executes during capture
+                        self._gout = self.step(*self._gin)
+                finally:
+                    self._segment = None
+                self._graph_b = None
+                if coll:
+                    import torch.distributed as dist
+                    scale = 1.0 / dist.get_world_size(self.group)
+                    gb = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gb):
+                        self.apply_updates(scale)
+                    self._graph_b = gb
                 self._graph = graph
             except Exception as e:   # noqa: BLE001 -- any capture failure means: stay eager
                 import warnings
                 warnings.warn("hipGraph capture of the train step failed (%s: %s); running eagerly" % (type(e).__name__, e))
-                self._graph, self._graph_failed = None, True
+                self._graph, self._graph_b, self._graph_failed = None, None, True
                 torch.cuda.synchronize()
                 return self.step(*batch)
         for dst, src in zip(self._gin, batch):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src)
         self._graph.replay()
+        if self._graph_b is not None:
+            works = [o.all_reduce_grads_async(self.group)[0] for o in [self.opt_gen] + self._d_opts()]
+            _FlatOpt.finish_all_reduce(works)
+            self._graph_b.replay()
         return self._gout
 
     @staticmethod

@@ -1,0 +1,29 @@
+"""go / no-go of the record-form convolution (round-3 review item 2A): the 32->32 layer at 256x256 and the 64->64 layer at
+128x128 (n = 32) on csrc/conv_rec.hip (input already in MFMA-record form, LDS-DMA staging, record epilogue + BatchNorm
+partial sums) against the shipped NCHW kernel (igemm_pipe_kernel, forward with statistics).   usage: python3 scripts/micro/rconv_micro.py"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from pointcloududa_amd import kernels as K
+dev = torch.device("cuda", 0)
+CASES = {"g32": (32, 32, 32, 256, 256), "g64": (32, 64, 64, 128, 128), "c64_32": (32, 64, 32, 256, 256),
+         "g32_224": (32, 32, 32, 224, 224)}
+def t(fn, reps=20):
+    fn(); fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps
+for name in (sys.argv[1:] or list(CASES)):
+    n, cin, cout, h, w = CASES[name]
+    x = torch.randn(n, cin, h, w, device=dev); wt = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
+    b = torch.randn(cout, device=dev) * 0.1
+    op = K.ConvOp(cin, cout, 3, pad=1)
+    fl = 2.0 * n * h * w * cout * cin * 9
+    t_old = t(lambda: op.forward(x, wt, b, 0.01, h, w, want_stats=True))
+    xr = K.rec_from_nchw(x); wp = K.rconv3_pack(wt)
+    pad = torch.zeros((cin // 32, 128), dtype=torch.uint8, device=dev)
+    t_new = t(lambda: K.rconv3_forward(xr, wp, b, 0.01, cout, pad_records=pad, want_stats=True))
+    t_nos = t(lambda: K.rconv3_forward(xr, wp, b, 0.01, cout, pad_records=pad, want_stats=False))
+    t_cv = t(lambda: K.rec_from_nchw(x))
+    byts = 4.0 * n * h * w * (cin + cout)
+    print("%-8s NCHW kernel %7.3f ms %6.1f TF | record kernel %7.3f ms %6.1f TF %5.2f TB/s (no stats %7.3f ms) | nchw->rec %6.3f ms"
+          % (name, t_old * 1e3, fl / t_old / 1e12, t_new * 1e3, fl / t_new / 1e12, byts / t_new / 1e12, t_nos * 1e3, t_cv * 1e3), flush=True)

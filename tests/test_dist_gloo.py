@@ -148,6 +148,11 @@ def test_bench_launcher_spawns_its_own_ranks():
     line = r.stdout.strip().splitlines()[-1]
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["config"]["ranks_in_group"] == 2 and res["steps"] == 3 and "settle" in res
+    # every rank pinned itself to its own slice of the cores before its first GPU call (bench.pin_rank_to_cores)
+    cores = res["config"]["rank_cores"]
+    if len(os.sched_getaffinity(0)) >= 2:
+        assert len(cores) == 2 and all(cores) and not (set(cores[0]) & set(cores[1])), cores
+        assert set(cores[0]) | set(cores[1]) <= set(os.sched_getaffinity(0))
     # a failing rank makes the launcher exit non-zero (no JSON line)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--dry-run",
                         "--workload", "nope"], capture_output=True, text=True, timeout=300, env=env)

@@ -534,6 +534,46 @@ def test_step_with_rccl_collectives_in_a_one_rank_group(dev, monkeypatch):
     assert rel_err(tr_b.opt_gen.p, tr_a.opt_gen.p) < 1e-6 and rel_err(tr_b.opt_d1.p, tr_a.opt_d1.p) < 1e-6
 
 
+def test_graph_replay_with_rccl_collectives_in_a_one_rank_group(dev, monkeypatch):
+    """hipGraph replay of the step in a process group (data parallel: 8 ranks x ~850 launches per step share one host; a
+    replay is one launch).  A collective cannot be captured here (AdversarialTrainer.step_graphed), so the step replays
+    as graph A (phases 1-4) + four eager all-reduces + graph B (phase 5): in a one-rank nccl group with
+    PCUDA_FORCE_COLLECTIVES=1 it must walk the eager trajectory."""
+    import socket
+    import torch.distributed as dist
+    from oracle.synth import synth_batch
+    if not dist.is_nccl_available():
+        pytest.skip("no RCCL in this torch build")
+    cfg_kw = dict(filters=4, in_channels=1, n_class=4, pointnet=True, fc_inch=9)
+    cfg, tr_e = _build(cfg_kw, 13, dev)
+    _, tr_g = _build(cfg_kw, 13, dev)
+    batch = [torch.from_numpy(t).to(dev) for t in synth_batch(4, cfg.in_channels, cfg.n_class, 128, seed=302)]
+    for _ in range(5):
+        out_e = tr_e.step(*batch)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1"); monkeypatch.setenv("MASTER_PORT", str(port))
+    monkeypatch.setenv("PCUDA_FORCE_COLLECTIVES", "1")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        calls = []
+        real = tr_g.opt_gen.all_reduce_grads_async
+        monkeypatch.setattr(tr_g.opt_gen, "all_reduce_grads_async",
+                            lambda group=None, lo=0, hi=None: (calls.append((lo, hi)), real(group, lo, hi))[1])
+        for _ in range(5):
+            out_g = tr_g.step_graphed(*batch)
+        torch.cuda.synchronize()
+        assert getattr(tr_g, "_graph", None) is not None and tr_g._graph_b is not None, "the step with collectives was not captured"
+        # two eager steps (two buckets each); the capture issues none; each of the three replays one whole-buffer all-reduce
+        assert calls == [(tr_g.opt_gen.split_after("encoder."), None), (0, tr_g.opt_gen.split_after("encoder."))] * 2 + [(0, None)] * 3, calls
+    finally:
+        dist.destroy_process_group()
+    he, hg = tr_e.to_host(out_e, tr_e.cfg), tr_g.to_host(out_g, tr_g.cfg)
+    for k in ("seg_loss", "adv_loss"):
+        assert abs(he[k] - hg[k]) <= 1e-5 * max(1.0, abs(he[k])), (k, he[k], hg[k])
+    assert int(tr_g.opt_gen.step_t.item()) == 5
+    assert rel_err(tr_g.opt_gen.p, tr_e.opt_gen.p) < 1e-6 and rel_err(tr_g.opt_d2.p, tr_e.opt_d2.p) < 1e-6
+
+
 def test_full_size_step_is_reproducible_and_stream_schedule_keeps_the_arithmetic(dev):
     """BASELINE config 3 at full size (B=32, 256x256, 32 filters, three discriminators).  (a) Two trainers from the
     same weights walk a BIT-IDENTICAL trajectory over three steps with the concurrent-stream schedule on: every
