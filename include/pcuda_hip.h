@@ -407,6 +407,8 @@ int pcuda_rec_to_nchw(const void* rec, int n, int c, int h, int w, float* y, lon
 size_t pcuda_rconv3_packed_bytes(int cout, int cin);
 int pcuda_rconv3_pack(const float* w, int cout, int cin, const float* in_scale, void* out, pcuda_stream_t s);
 int pcuda_rconv3_tiles(int n, int h, int w);       /* rows of the stats buffer */
+/* timing experiments only (PCUDA_RC_DBG=1): six per-phase cycle sums of the record convolution; read + reset */
+int pcuda_rconv3_debug_clocks(unsigned long long* out6);
 /* y = LeakyReLU_slope(conv3x3(x) + bias) on record tensors; pad_records [cin/32][128 B] is what the convolution reads
  * outside the image (zeros; or, with a folded BatchNorm, the record of -shift/scale); stats [tiles][cout][2] receives the
  * per-tile (sum, sum of squares) of the stored values (BatchNorm batch statistics, unet.py:26,30) or is NULL.

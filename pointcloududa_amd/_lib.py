@@ -51,6 +51,7 @@ _PROTOS = {
     "pcuda_rconv3_packed_bytes": (sz, [i32, i32]),
     "pcuda_rconv3_pack": (i32, [vp, i32, i32, vp, vp, vp]),
     "pcuda_rconv3_tiles": (i32, [i32, i32, i32]),
+    "pcuda_rconv3_debug_clocks": (i32, [vp]),
     "pcuda_rconv3_forward": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, f32, i32, vp, vp, vp]),
     "pcuda_prof_enable": (i32, [i32]),
     "pcuda_prof_reset": (i32, []),

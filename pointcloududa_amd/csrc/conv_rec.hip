@@ -42,9 +42,29 @@ struct RConvParams {
   int cout;
   float* stats;               // [tiles][cout][2] partial (sum, sum of squares) of the stored values, or null
   int tiles_x, tiles_y, n, n_co_tiles, total;
+  unsigned long long* dbg_clk;   // PCUDA_RC_DBG=1 (scripts/micro/rconv_micro.py): per-phase cycle sums of wave 0 of every workgroup
 };
 
+#define RC_CLK(i)                                                        \
+  if (DBG) {                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                   \
+    const unsigned long long now_ = __builtin_readcyclecounter();        \
+    clk[i] += now_ - tlast; tlast = now_;                                \
+    __builtin_amdgcn_sched_barrier(0);                                   \
+  }
+
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Workgroup barrier that waits for this wave's LDS operations only.  __syncthreads() also drains vmcnt: every barrier
+// of a stage would wait for the previous tile's global stores to be acknowledged and for the LDS-DMA prefetch to land
+// (cdna_hip_programming.md, "Pipelining across barriers").  LDS-DMA data is ordered for the readers by the issuing
+// wave's counted vmcnt wait in front of a barrier (rc_wait_dma below).
+#define RC_BARRIER()                                        \
+  do {                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+    __builtin_amdgcn_s_barrier();                           \
+    asm volatile("" ::: "memory");                          \
+  } while (0)
 
 __device__ __forceinline__ void dma16(const unsigned char* g, unsigned char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -58,9 +78,15 @@ __device__ __forceinline__ void split8(const float* v, u32x4& hi4, u32x4& lo4) {
   lo4 = u32x4{b, d, f, hh};
 }
 
+__device__ __forceinline__ int opaque_zero_v() {
+  int z;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+  return z;
+}
+
 __device__ __forceinline__ bf16x8 frag(const unsigned char* p) { return __builtin_bit_cast(bf16x8, *(const uint4*)p); }
 
-template <bool STATS>
+template <bool STATS, bool DBG>
 __global__ __launch_bounds__(256, 2) void rconv3_kernel(const RConvParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned char* const Ws = smem;                 // (first: a tap's fragment address is a per-lane register + an immediate)
@@ -78,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void rconv3_kernel(const RConvParams p) {
   const int lo = (int)((long long)p.total * xcd / nx), hi = (int)((long long)p.total * (xcd + 1) / nx);
 
   // ---- tile-invariant DMA plan: piece j of this wave fills LDS bytes [(w + 4 j) KiB, + 1 KiB) of the X image
-  int xrel[RC_NJ], xpk[RC_NJ];
+  int xrel[RC_NJ];
 #pragma unroll
   for (int j = 0; j < RC_NJ; ++j) {
     const int q = (w + 4 * j) * 64 + lane;
@@ -86,7 +112,6 @@ __global__ __launch_bounds__(256, 2) void rconv3_kernel(const RConvParams p) {
     const int c = s ^ ((rec >> 1) & 7);
     const int ry = rec / RC_HW, rx = rec - ry * RC_HW;
     xrel[j] = (ry * W + rx) * REC_B + c * 16;
-    xpk[j] = ry | (rx << 8) | (c << 16);
   }
   // ---- tile-invariant fragment addresses (bytes inside Xs / Ws): ks = 0 hi; ^32 -> ks = 1, ^64 -> lo
   int xa[2][9];
@@ -102,85 +127,166 @@ __global__ __launch_bounds__(256, 2) void rconv3_kernel(const RConvParams p) {
 
   int wres = -1;   // (co-tile, chunk) whose weights are resident in Ws
   f32x16 acc[2];
-  for (int L = lo + slot; L < hi; L += gx) {
-    const int cot = L % p.n_co_tiles, pt = L / p.n_co_tiles;
-    const int txi = pt % p.tiles_x, tmp = pt / p.tiles_x;
-    const int tyi = tmp % p.tiles_y, n = tmp / p.tiles_y;
-    const int y0 = tyi * RC_TH, x0 = txi * RC_TW;
-    const bool border = (y0 == 0) | (y0 + RC_TH == H) | (x0 == 0) | (x0 + RC_TW == W);
+  unsigned long long clk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+
+  struct Item { int cot, pt, n, y0, x0; bool border; };
+  auto decode = [&](int L) {
+    Item it;
+    it.cot = L % p.n_co_tiles; it.pt = L / p.n_co_tiles;
+    const int txi = it.pt % p.tiles_x, tmp = it.pt / p.tiles_x;
+    const int tyi = tmp % p.tiles_y;
+    it.n = tmp / p.tiles_y;
+    it.y0 = tyi * RC_TH; it.x0 = txi * RC_TW;
+    it.border = (it.y0 == 0) | (it.y0 + RC_TH == H) | (it.x0 == 0) | (it.x0 + RC_TW == W);
+    return it;
+  };
+  // stage (item, chunk): the haloed input tile by LDS-DMA, and the weights if another (co-tile, chunk) is resident
+  auto issue = [&](const Item& it, int chunk) {
+    const unsigned char* xb = p.x + (long long)it.n * p.x_sn +
+                              ((long long)chunk * H * W + ((long long)(it.y0 - 1) * W + (it.x0 - 1))) * REC_B;
+    if (it.border) {
+      const unsigned char* padp = p.pad + chunk * REC_B;
+      const int lz = lane + opaque_zero_v();   // (keeps the per-piece record arithmetic below inside the loop: hoisted, it spilled)
+#pragma unroll
+      for (int j = 0; j < RC_NJ; ++j) {
+        if (w + 4 * j < RC_XPIECES) {
+          // (border tiles only -- a tenth of a 256x256 map: the lane's record is recomputed rather than kept in registers)
+          const int q = (w + 4 * j) * 64 + lz;
+          const int rec = min(q >> 3, RC_NREC - 1), c = (q & 7) ^ ((rec >> 1) & 7);
+          const int ry = (rec * 1928) >> 16, rx = rec - ry * RC_HW;      // rec / 34, exact for rec < 340
+          const bool in = ((unsigned)(it.y0 - 1 + ry) < (unsigned)H) & ((unsigned)(it.x0 - 1 + rx) < (unsigned)W);
+          const unsigned char* src = in ? xb + xrel[j] : padp + c * 16;
+          dma16(src, Xs + (w + 4 * j) * 1024);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < RC_NJ; ++j)
+        if (w + 4 * j < RC_XPIECES) dma16(xb + (unsigned)xrel[j], Xs + (w + 4 * j) * 1024);
+    }
+    const int wkey = it.cot * p.cb_in + chunk;
+    if (wkey != wres) {   // uniform
+      const unsigned char* wsrc = p.wpack + (long long)wkey * RC_WBYTES + lane * 16;
+#pragma unroll
+      for (int j = 0; j < 9; ++j) dma16(wsrc + (w + 4 * j) * 1024, Ws + (w + 4 * j) * 1024);
+      wres = wkey;
+    }
+  };
+
+  int L = lo + slot;
+  Item cur = decode(min(L, p.total - 1));
+  if (L < hi) issue(cur, 0);
+  int cot_b = -1;
+  float bia[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) bia[i] = 0.f;
+  // epilogue staging: wave w turns its 64 output records through its own 8 KiB of the (then idle) X image so that the
+  // global stores are whole lines: lane l of store k writes piece (l & 7) of record 8 k + (l >> 3)
+  unsigned char* const stg = Xs + w * 8192;
+  const int sto0 = (lane >> 3) * REC_B + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);   // store k: + k KiB (record 8 k + (lane >> 3))
+  bool first = true;
+  for (; L < hi; L += gx) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+    if (p.bias && cur.cot != cot_b) {   // uniform; (a persistent workgroup of a one-co-tile layer loads it once)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) bia[i] = p.bias[cur.cot * 32 + (i & 3) + 8 * (i >> 2) + 4 * h];
+      cot_b = cur.cot;
+    }
     for (int chunk = 0; chunk < p.cb_in; ++chunk) {
-      __syncthreads();   // every wave is done reading the previous stage's X / W (and the epilogue's scratch)
-      // ---- stage: the haloed input tile, and the weights if another (co-tile, chunk) is resident
-      const unsigned char* xb = p.x + (long long)n * p.x_sn + ((long long)chunk * H * W + ((long long)(y0 - 1) * W + (x0 - 1))) * REC_B;
-      const unsigned char* padp = p.pad + chunk * REC_B;
-      if (border) {
-#pragma unroll
-        for (int j = 0; j < RC_NJ; ++j) {
-          if (w + 4 * j < RC_XPIECES) {
-            const int ry = xpk[j] & 0xff, rx = (xpk[j] >> 8) & 0xff, c = xpk[j] >> 16;
-            const bool in = ((unsigned)(y0 - 1 + ry) < (unsigned)H) & ((unsigned)(x0 - 1 + rx) < (unsigned)W);
-            const unsigned char* src = in ? xb + xrel[j] : padp + c * 16;
-            dma16(src, Xs + (w + 4 * j) * 1024);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < RC_NJ; ++j)
-          if (w + 4 * j < RC_XPIECES) dma16(xb + (unsigned)xrel[j], Xs + (w + 4 * j) * 1024);
-      }
-      const int wkey = cot * p.cb_in + chunk;
-      if (wkey != wres) {   // uniform
-        const unsigned char* wsrc = p.wpack + (long long)wkey * RC_WBYTES + lane * 16;
-#pragma unroll
-        for (int j = 0; j < 9; ++j) dma16(wsrc + (w + 4 * j) * 1024, Ws + (w + 4 * j) * 1024);
-        wres = wkey;
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      RC_CLK(1)
+      // the stage's DMA pieces have landed: everything but the 8 record stores of the previous tile, which were issued
+      // behind them (vmcnt counts loads, stores and LDS-DMA together, in issue order)
+      if (chunk == 0 && !first) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      RC_CLK(2)
+      RC_BARRIER();   // the stage's DMA pieces of every wave have landed
+      RC_CLK(3)
       // ---- MFMA phase: 9 taps x 2 k-steps x (1 row block x 2 pixel blocks) x 3 products
+      // (an opaque zero in the fragment addresses: their three XOR variants per (block, tap) are loop-invariant, were
+      // hoisted out of the item loop -- 72 registers -- and spilled)
+      const int oz = opaque_zero_v();
+      // fragments of step s + 1 (tap, k-step) are requested before the MFMAs of step s: the LDS round trip hides behind
+      // six MFMAs (two waves per SIMD do not cover it on their own: 27 % of the stage was MFMA phase at half speed)
+      bf16x8 fa[2][2], fb[2][4];   // [buffer][ah, al], [buffer][bh0, bl0, bh1, bl1]
+      auto load = [&](int bufi, int st) {
+        const int t = st >> 1, ks = st & 1;
+        const int x0a = xa[0][t] + oz, x1a = xa[1][t] + oz;
+        fa[bufi][0] = frag(Ws + wah[ks] + t * 32 * REC_B);
+        fa[bufi][1] = frag(Ws + wal[ks] + t * 32 * REC_B);
+        fb[bufi][0] = frag(Xs + (x0a ^ (ks * 32)));
+        fb[bufi][1] = frag(Xs + (x0a ^ (ks * 32) ^ 64));
+        fb[bufi][2] = frag(Xs + (x1a ^ (ks * 32)));
+        fb[bufi][3] = frag(Xs + (x1a ^ (ks * 32) ^ 64));
+      };
+      load(0, 0);
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
+      for (int st = 0; st < 18; ++st) {
+        const int cb = st & 1;
+        if (st + 1 < 18) load(cb ^ 1, st + 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const bf16x8 ah = frag(Ws + wah[ks] + t * 32 * REC_B);
-          const bf16x8 al = frag(Ws + wal[ks] + t * 32 * REC_B);
-          bf16x8 bh[2], bl[2];
-#pragma unroll
-          for (int pb = 0; pb < 2; ++pb) {
-            bh[pb] = frag(Xs + (xa[pb][t] ^ (ks * 32)));
-            bl[pb] = frag(Xs + (xa[pb][t] ^ (ks * 32) ^ 64));
-          }
-#pragma unroll
-          for (int pb = 0; pb < 2; ++pb) {
-            acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[pb], acc[pb], 0, 0, 0);
-            acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[pb], acc[pb], 0, 0, 0);
-            acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[pb], acc[pb], 0, 0, 0);
-          }
+        for (int pb = 0; pb < 2; ++pb) {
+          acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cb][1], fb[cb][2 * pb], acc[pb], 0, 0, 0);
+          acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cb][0], fb[cb][2 * pb + 1], acc[pb], 0, 0, 0);
+          acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cb][0], fb[cb][2 * pb], acc[pb], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
+      if (DBG) asm volatile("s_nop 0" ::"v"(acc[0][15]), "v"(acc[1][15]));   // (the MFMAs have completed)
+      RC_CLK(4)
+      RC_BARRIER();   // every wave is done reading this stage's X / W
+      RC_CLK(0)
+      if (chunk + 1 < p.cb_in) issue(cur, chunk + 1);
     }
     // ---- epilogue: bias + LeakyReLU, BatchNorm partial sums, records out.  Register i of a lane is output channel
     // (i & 3) + 8 (i >> 2) + 4 h of pixel r of the block: swapping the upper half of register 4 j + e (j even) with the lower
-    // half of 4 (j + 1) + e leaves lane (r, h) with channels 8 h .. 8 h + 7 and 16 + 8 h .. 16 + 8 h + 7 of its pixel.
-    const int co0 = cot * 32;
-    float bia[16];
+    // half of 4 (j + 1) + e leaves lane (r, h) with channels 8 h .. 8 h + 7 and 16 + 8 h .. 16 + 8 h + 7 of its pixel:
+    // four 16-byte pieces of its record, written into the wave's staging block (slot = piece ^ (record & 7):
+    // conflict-free both ways) and read back as whole records for 1-KiB global stores.
+    const int co0 = cur.cot * 32;
+    unsigned char* const yb = p.y + (long long)cur.n * p.y_sn + (long long)cur.cot * H * W * REC_B;
+    // values in place: bias + LeakyReLU (0 <= slope <= 1; slope 1: identity)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) bia[i] = p.bias ? p.bias[co0 + (i & 3) + 8 * (i >> 2) + 4 * h] : 0.f;
-    float s1[16], s2[16];
+    for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
-    unsigned char* const yb = p.y + (long long)n * p.y_sn + (long long)cot * H * W * REC_B;
+      for (int i = 0; i < 16; ++i) {
+        const float t = acc[pb][i] + bia[i];
+        acc[pb][i] = fmaxf(t, t * p.slope);
+      }
+    if (STATS) {
+      // Per channel and wave: the sum over the wave's 64 pixels.  Lane (r, h) holds 32 partial values (16 channels x {sum, sum
+      // of squares} over its two pixels); they go through the wave's staging block as a [value][lane] table (16-byte chunks
+      // XOR-swizzled by the value index: conflict-free both ways) and lane (v, h') adds up value v over the 32 lanes of
+      // half h' -- 32 ds_write_b32 + 8 ds_read_b128 + 32 adds instead of 160 dependent DPP adds (21 % of the stage by
+      // s_memtime stamps).  Fixed order: deterministic.
+#pragma unroll
+      for (int v = 0; v < 32; ++v) {
+        const float a0 = acc[0][v & 15], a1 = acc[1][v & 15];
+        const float val = v < 16 ? a0 + a1 : fmaf(a1, a1, a0 * a0);
+        *(float*)(stg + v * 256 + ((((lane >> 2) ^ (v & 15)) << 4) | ((lane & 3) << 2))) = val;
+      }
+      const int vv = lane & 31;
+      float tot = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const f32x4 q4 = *(const f32x4*)(stg + vv * 256 + (((h * 8 + jj) ^ (vv & 15)) << 4));
+        tot += (q4[0] + q4[1]) + (q4[2] + q4[3]);
+      }
+      // value vv = (quantity vv >> 4, register i = vv & 15) of the lanes with this h: channel (i & 3) + 8 (i >> 2) + 4 h
+      const int i = vv & 15, row = (i & 3) + 8 * (i >> 2) + 4 * h;
+      sred[(w * 32 + row) * 2 + (vv >> 4)] = tot;
+    }
+    RC_CLK(6)
+    // records: register i of a lane is output channel (i & 3) + 8 (i >> 2) + 4 h of pixel r of the block; swapping the upper
+    // half of register 4 j + e (j even) with the lower half of 4 (j + 1) + e leaves lane (r, h) with channels 8 h .. 8 h + 7
+    // and 16 + 8 h .. 16 + 8 h + 7 of its pixel: four 16-byte pieces of its record, written into the wave's staging block
+    // (slot = piece ^ (record & 7): conflict-free both ways) and read back as whole records for 1-KiB global stores.
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb) {
       float v[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float t = acc[pb][i] + bia[i];
-        v[i] = fmaxf(t, t * p.slope);      // LeakyReLU for 0 <= slope <= 1 (slope 1: identity)
-        if (STATS) { s1[i] += v[i]; s2[i] = fmaf(v[i], v[i], s2[i]); }
-      }
+      for (int i = 0; i < 16; ++i) v[i] = acc[pb][i];
       // (inline asm: this hipcc folds the builtin's second result into its first -- the stored pieces repeated channels
       // 8 j .. 8 j + 3, found with scripts/micro/rconv_debug.py; s_nop: VALU write -> permlane-swap read wait states)
       asm volatile("s_nop 1\n\t"
@@ -191,36 +297,47 @@ __global__ __launch_bounds__(256, 2) void rconv3_kernel(const RConvParams p) {
                    "s_nop 1"
                    : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
                      "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
-      unsigned char* const rec = yb + ((long long)(y0 + 2 * w + pb) * W + (x0 + r)) * REC_B;
+      const int rr = pb * 32 + r;
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
         u32x4 hi4, lo4;
         split8(&v[8 * jj], hi4, lo4);
-        *(u32x4*)(rec + (2 * jj + h) * 16) = hi4;
-        *(u32x4*)(rec + 64 + (2 * jj + h) * 16) = lo4;
+        *(u32x4*)(stg + rr * REC_B + (((2 * jj + h) ^ (rr & 7)) << 4)) = hi4;
+        *(u32x4*)(stg + rr * REC_B + (((4 + 2 * jj + h) ^ (rr & 7)) << 4)) = lo4;
       }
     }
-    if (STATS) {
-      // per channel: sum over the wave's 64 pixels (two blocks already added per lane), then over the four waves in a
-      // fixed order -- deterministic
+    RC_CLK(7)
+    // the wave's two tile rows: 2 x 4 KiB contiguous in global memory
+    unsigned char* const row0 = yb + ((long long)(cur.y0 + 2 * w) * W + cur.x0) * REC_B + lane * 16;
+    u32x4 o[8];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float a = half_wave_sum_hi16(s1[i]), b = half_wave_sum_hi16(s2[i]);
-        if (r == 31) {
-          const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-          sred[(w * 32 + row) * 2 + 0] = a;
-          sred[(w * 32 + row) * 2 + 1] = b;
-        }
-      }
-      __syncthreads();
-      if (tid < 32) {
-        float a = 0.f, b = 0.f;
+    for (int k = 0; k < 8; ++k) o[k] = *(const u32x4*)(stg + sto0 + k * 1024);
+    RC_CLK(8)
+    RC_BARRIER();   // staging reads done (the next stage's DMA may overwrite the X image); partial sums visible
+    RC_CLK(9)
+    if (STATS && tid < 32) {
+      float a = 0.f, b = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) { a += sred[(ww * 32 + tid) * 2 + 0]; b += sred[(ww * 32 + tid) * 2 + 1]; }
-        p.stats[((long long)pt * p.cout + co0 + tid) * 2 + 0] = a;
-        p.stats[((long long)pt * p.cout + co0 + tid) * 2 + 1] = b;
-      }
+      for (int ww = 0; ww < 4; ++ww) { a += sred[(ww * 32 + tid) * 2 + 0]; b += sred[(ww * 32 + tid) * 2 + 1]; }
+      p.stats[((long long)cur.pt * p.cout + co0 + tid) * 2 + 0] = a;
+      p.stats[((long long)cur.pt * p.cout + co0 + tid) * 2 + 1] = b;
     }
+    RC_CLK(5)
+    // next tile's DMA first, this tile's record stores behind it: the loads are in flight while the stores issue
+    if (L + gx < hi) {
+      cur = decode(L + gx);
+      issue(cur, 0);
+    }
+    first = false;
+    RC_CLK(10)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) *(u32x4*)(row0 + (k >> 2) * (W * REC_B) + (k & 3) * 1024) = o[k];
+    __builtin_amdgcn_sched_barrier(0);
+    RC_CLK(11)
+  }
+  if (DBG && tid == 0) {
+    for (int i = 0; i < 12; ++i) atomicAdd(&p.dbg_clk[i], clk[i]);
   }
 }
 
@@ -303,6 +420,19 @@ __global__ void rconv3_pack_kernel(const float* __restrict__ wsrc, int cout, int
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
+static unsigned long long* g_rc_dbg = nullptr;
+// timing experiments (PCUDA_RC_DBG=1): the six per-phase cycle sums of rconv3_kernel -- top barrier, DMA issue, DMA wait,
+// barrier, MFMA phase, epilogue -- over wave 0 of every workgroup since the last call; read + reset
+extern "C" int pcuda_rconv3_debug_clocks(unsigned long long* out6) {
+  if (!out6) PCUDA_FAIL(PCUDA_E_BADARG, "rconv3_debug_clocks: null");
+  memset(out6, 0, 12 * sizeof(unsigned long long));
+  if (!g_rc_dbg) return PCUDA_OK;
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out6, g_rc_dbg, 96, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemset(g_rc_dbg, 0, 128) != hipSuccess)
+    PCUDA_FAIL(PCUDA_E_LAUNCH, "rconv3_debug_clocks: copy failed");
+  return PCUDA_OK;
+}
+
 extern "C" size_t pcuda_rec_bytes(int n, int c, int h, int w) { return (size_t)n * ((c + 31) / 32) * h * w * REC_B; }
 
 extern "C" int pcuda_rec_from_nchw(const float* x, long long sn, long long sc, int n, int c, int h, int w, const float* scale,
@@ -355,6 +485,14 @@ extern "C" int pcuda_rconv3_forward(const void* x, int n, int cin, int h, int w,
   p.stats = stats;
   p.tiles_x = w / RC_TW; p.tiles_y = h / RC_TH; p.n = n; p.n_co_tiles = cout / 32;
   p.total = n * p.tiles_x * p.tiles_y * p.n_co_tiles;
+  {
+    static int dbg = -1;
+    static unsigned long long* buf = nullptr;
+    if (dbg < 0) { const char* e = getenv("PCUDA_RC_DBG"); dbg = (e && atoi(e)) ? 1 : 0; }
+    if (dbg && !buf && hipMalloc(&buf, 16 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemset(buf, 0, 128);
+    p.dbg_clk = dbg ? buf : nullptr;
+    g_rc_dbg = buf;
+  }
   const size_t lds = RC_XBYTES + RC_WBYTES + 4 * 32 * 2 * sizeof(float);
   int ncu = 256;
   {
@@ -372,7 +510,8 @@ extern "C" int pcuda_rconv3_forward(const void* x, int n, int cin, int h, int w,
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
     return PCUDA_OK;
   };
-  const int rc = stats ? launch(rconv3_kernel<true>) : launch(rconv3_kernel<false>);
+  const int rc = p.dbg_clk ? (stats ? launch(rconv3_kernel<true, true>) : launch(rconv3_kernel<false, true>))
+                           : (stats ? launch(rconv3_kernel<true, false>) : launch(rconv3_kernel<false, false>));
   if (rc != PCUDA_OK) return rc;
   PCUDA_CHECK_LAUNCH("rconv3_kernel");
   return PCUDA_OK;

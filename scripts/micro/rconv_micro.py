@@ -24,6 +24,16 @@ for name in (sys.argv[1:] or list(CASES)):
     t_new = t(lambda: K.rconv3_forward(xr, wp, b, 0.01, cout, pad_records=pad, want_stats=True))
     t_nos = t(lambda: K.rconv3_forward(xr, wp, b, 0.01, cout, pad_records=pad, want_stats=False))
     t_cv = t(lambda: K.rec_from_nchw(x))
+    if os.environ.get("PCUDA_RC_DBG") == "1":
+        import ctypes
+        buf = (ctypes.c_ulonglong * 12)()
+        K.L.lib().pcuda_rconv3_debug_clocks(buf)
+        for _ in range(10): K.rconv3_forward(xr, wp, b, 0.01, cout, pad_records=pad, want_stats=True)
+        K.L.lib().pcuda_rconv3_debug_clocks(buf)
+        tot = float(sum(buf)) or 1.0
+        names = ["barrier after MFMA", "loop top", "DMA wait", "barrier", "MFMA", "stats store", "epilogue math + LDS stage", "LDS read + global stores",
+                 "stats DPP", "barrier", "decode + DMA issue", "-"]
+        print("   phases (share of wave 0's time):", " | ".join("%s %.1f%%" % (nm, 100.0 * v / tot) for nm, v in zip(names, buf) if v))
     byts = 4.0 * n * h * w * (cin + cout)
     print("%-8s NCHW kernel %7.3f ms %6.1f TF | record kernel %7.3f ms %6.1f TF %5.2f TB/s (no stats %7.3f ms) | nchw->rec %6.3f ms"
           % (name, t_old * 1e3, fl / t_old / 1e12, t_new * 1e3, fl / t_new / 1e12, byts / t_new / 1e12, t_nos * 1e3, t_cv * 1e3), flush=True)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ / TA / TCP counters of single conv layers (scripts/conv_micro.py cases), one rocprofv3 --pmc pass per counter set,
-# no trace domains; aggregates per kernel into gpurun_out/${TAG}_pmc_conv.csv.   usage: CASES="g32" TAG=r02 bash scripts/pmc_conv.sh
+# no trace domains; aggregates per kernel into gpurun_out/${TAG}_pmc_conv.csv.   usage: CASES="g32" TAG=r02 [SCRIPT=scripts/micro/rconv_micro.py] bash scripts/pmc_conv.sh
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 TAG=${TAG:-r03}
@@ -16,7 +16,7 @@ SETS=(
 # NSETS=2: only the issue / MFMA sets (the per-layer-class table of profiles/rNN_mfma_counters.csv)
 i=0
 for set in "${SETS[@]:0:${NSETS:-6}}"; do
-  timeout ${PMC_TIMEOUT:-200} rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmcc/s$i -o $TAG -- python3 scripts/conv_micro.py ${CASES:-g32} > gpurun_out/pmcc_s$i.log 2>&1
+  timeout ${PMC_TIMEOUT:-200} rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmcc/s$i -o $TAG -- python3 ${SCRIPT:-scripts/conv_micro.py} ${CASES:-g32} > gpurun_out/pmcc_s$i.log 2>&1
   echo "set $i rc=$?"
   i=$((i+1))
 done
@@ -30,7 +30,7 @@ for f in glob.glob("gpurun_out/pmcc/**/*counter_collection.csv", recursive=True)
 with open("gpurun_out/%s_pmc_conv.csv" % tag, "w") as o:
     o.write("kernel,counter,per_launch,launches\n")
     for k, d in sorted(agg.items()):
-        if "igemm" not in k and "wgrad" not in k: continue
+        if "igemm" not in k and "wgrad" not in k and "rconv3" not in k: continue
         for c, (v, n) in sorted(d.items()):
             o.write('"%s",%s,%.1f,%d\n' % (k[:90], c, v / max(n, 1), n))
 print(open("gpurun_out/%s_pmc_conv.csv" % tag).read()[:6000])
