@@ -438,6 +438,8 @@ def main():
         "scaling": "weak", "vs_baseline": None,
         "host_issue_ms_per_step": round(host_issue_ms, 3), "launches_per_step": round(launches_per_step, 1),
         "comm_exposed_ms": comm_exposed_ms,
+        # launches that ran on a generic fallback kernel (csrc/variants.h: pruned default build): must be 0 for a benchmark line
+        "fallback_launches": int(K.L.lib().pcuda_fallback_count()),
         "dtype": "bf16x3 MFMA (split-bf16, fp32 accumulate; fp32 storage)" if args.precision == "bf16x3"
                  else "bf16 MFMA (fp32 accumulate; fp32 storage)",
         "data": "synthetic",

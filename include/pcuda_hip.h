@@ -47,6 +47,9 @@ int pcuda_device_count(void);            /* hipGetDeviceCount, 0 when no GPU */
 const char* pcuda_last_error(void);      /* text of the last failing call on this thread */
 const char* pcuda_build_hash(void);      /* sha256[:16] of the kernel sources the loaded library was compiled from */
 long long pcuda_launch_count(int reset); /* kernel launches issued by this library since the last reset (host-side count) */
+/* convolution launches that ran on a generic fallback kernel because the geometry's specialised template instantiation is
+ * not in this build (csrc/variants.h: the default build holds the variants of the benchmark configurations and tests) */
+long long pcuda_fallback_count(void);
 
 /* kernel-family timing (HIP events recorded on the launch stream around every launch of
  * a family while enabled; used by bench.py for the live roofline figure) */

@@ -45,6 +45,7 @@ _PROTOS = {
     "pcuda_last_error": (C.c_char_p, []),
     "pcuda_build_hash": (C.c_char_p, []),
     "pcuda_launch_count": (i64, [i32]),
+    "pcuda_fallback_count": (i64, []),
     "pcuda_rec_bytes": (sz, [i32, i32, i32, i32]),
     "pcuda_rec_from_nchw": (i32, [vp, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp]),
     "pcuda_rec_to_nchw": (i32, [vp, i32, i32, i32, i32, vp, i64, i64, vp]),

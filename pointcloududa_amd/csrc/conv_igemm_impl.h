@@ -3,6 +3,7 @@
 #pragma once
 #include "conv_device.h"
 #include "conv_host.h"
+#include "variants.h"
 
 // ------------------------------------------------------------------------------------------
 // forward / dgrad kernel.  256 threads = 4 waves; tile = CO_TILE rows x (128*NPB) logical pixels;
@@ -985,6 +986,12 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
 
 template <bool X3, int CO_BLKS, bool CLAMP, int NPBT, int PF, bool XQ, bool STATS>
 static int launch_igemm8_s(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
+  constexpr unsigned vkey = ig8_key(X3, CO_BLKS, CLAMP, NPBT, PF, XQ, STATS);
+  variant_log("ig8", vkey);
+  if constexpr (!ig8_built(vkey)) {
+    variant_fallback_note("igemm8_kernel", vkey);
+    return PCUDA_E_NOTBUILT;
+  } else {
   auto kern = igemm8_kernel<X3, CO_BLKS, CLAMP, NPBT, PF, XQ, STATS>;
   static DeviceOnce lds_opt;
   if (const unsigned long long devbit = lds_opt.pending()) {
@@ -998,6 +1005,7 @@ static int launch_igemm8_s(const IgemmParams& p, const IgemmPlan& pl, hipStream_
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pl.lds, s, p, pl.x_cap, total);
   PCUDA_CHECK_LAUNCH("igemm8_kernel");
   return PCUDA_OK;
+  }
 }
 
 // (BatchNorm partial sums are a template parameter too: only the segmenter's forward convolutions produce them)
@@ -1046,6 +1054,12 @@ static int launch_igemm_c(const IgemmParams& p, const IgemmPlan& pl, hipStream_t
 
 template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ, int STATS, bool TE>
 static int launch_pipe_s(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
+  constexpr unsigned vkey = pipe_key(X3, CO_BLKS, CLAMP, NPB, PF, XQ, STATS, TE);
+  variant_log("pipe", vkey);
+  if constexpr (!pipe_built(vkey)) {
+    variant_fallback_note("igemm_pipe_kernel", vkey);
+    return PCUDA_E_NOTBUILT;
+  } else {
   auto kern = igemm_pipe_kernel<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, STATS, TE>;
   static DeviceOnce lds_opt;
   if (const unsigned long long devbit = pl.lds > 32 * 1024 ? lds_opt.pending() : 0ull) {
@@ -1071,6 +1085,7 @@ static int launch_pipe_s(const IgemmParams& p, const IgemmPlan& pl, hipStream_t 
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), pl.lds, s, p, pl.x_cap, total);
   PCUDA_CHECK_LAUNCH("igemm_pipe_kernel");
   return PCUDA_OK;
+  }
 }
 
 template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ>
@@ -1113,7 +1128,12 @@ static int launch_pipe_c(const IgemmParams& p, const IgemmPlan& pl, int pf, hipS
 
 template <bool X3>
 static int igemm_dispatch(const IgemmParams& p, const IgemmPlan& pl, int co_blks, int pf, bool pipe, hipStream_t s) {
-  if (pipe && pl.w8) return igemm8_dispatch<X3>(p, pl, co_blks, pf, s);
-  if (pipe) return co_blks == 2 ? launch_pipe_c<X3, 2>(p, pl, pf, s) : launch_pipe_c<X3, 1>(p, pl, pf, s);
+  if (pipe) {
+    const int rc = pl.w8 ? igemm8_dispatch<X3>(p, pl, co_blks, pf, s)
+                         : (co_blks == 2 ? launch_pipe_c<X3, 2>(p, pl, pf, s) : launch_pipe_c<X3, 1>(p, pl, pf, s));
+    if (rc != PCUDA_E_NOTBUILT) return rc;
+    // the selected instantiation is not in this build (variants.h): the unpipelined kernel runs any plan
+    if (p.red_a) PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv2d_dgrad_bnred: the transposed-epilogue variant of this geometry is not in this build");
+  }
   return co_blks == 2 ? launch_igemm_c<X3, 2>(p, pl, s) : launch_igemm_c<X3, 1>(p, pl, s);
 }

@@ -3,6 +3,7 @@
 #pragma once
 #include "conv_device.h"
 #include "conv_host.h"
+#include "variants.h"
 
 // ------------------------------------------------------------------------------------------
 // wgrad kernel.  Block = (co-tile, 32-channel chunk, tap group) x split-K slice; loops over its
@@ -429,6 +430,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (TAPS_MAX <= 9 && PF <= 1)) ? 
 
 template <bool X3, int CO_BLKS, int MODE, int TAPS_MAX, int PF, int NW, bool XQ>
 static int launch_wgrad_q(const WgradParams& p, int x_cap, size_t lds, float* dbp, dim3 grid, hipStream_t s) {
+  constexpr unsigned vkey = wgrad_key(X3, CO_BLKS, MODE, TAPS_MAX, PF, NW, XQ);
+  variant_log("wgrad", vkey);
+  if constexpr (!wgrad_built(vkey)) {
+    // not in this build (variants.h): the same plan on the four-wave kernel without register prefetch (always built)
+    variant_fallback_note("wgrad_kernel", vkey);
+    return launch_wgrad_q<X3, CO_BLKS, MODE, TAPS_MAX, 0, NW, false>(p, x_cap, lds, dbp, grid, s);
+  } else {
   auto kern = wgrad_kernel<X3, CO_BLKS, MODE, TAPS_MAX, PF, NW, XQ>;
   static DeviceOnce lds_opt;
   if (const unsigned long long devbit = lds > 32 * 1024 ? lds_opt.pending() : 0ull) {
@@ -439,6 +447,7 @@ static int launch_wgrad_q(const WgradParams& p, int x_cap, size_t lds, float* db
   hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, s, p, x_cap, dbp);
   PCUDA_CHECK_LAUNCH("wgrad_kernel");
   return PCUDA_OK;
+  }
 }
 
 template <bool X3, int CO_BLKS, int MODE, int TAPS_MAX, int PF, int NW = 4>

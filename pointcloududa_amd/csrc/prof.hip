@@ -1,5 +1,6 @@
 // Error text + per-family kernel timing with HIP events on the launch stream.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <mutex>
 #include <string>
@@ -17,6 +18,32 @@ void pcuda_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* pcuda_last_error(void) { return g_err; }
+
+#include <set>
+#include "variants.h"
+void variant_log(const char* family, unsigned key) {
+  static const char* path = getenv("PCUDA_VARIANT_LOG");
+  if (!path || !*path) return;
+  static std::mutex mu;
+  static std::set<std::pair<std::string, unsigned>> seen;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!seen.insert({family, key}).second) return;
+  if (FILE* f = fopen(path, "a")) {
+    fprintf(f, "%s %u\n", family, key);
+    fclose(f);
+  }
+}
+static long long g_fallbacks = 0;
+extern "C" long long pcuda_fallback_count(void) { return __atomic_load_n(&g_fallbacks, __ATOMIC_RELAXED); }
+void variant_fallback_note(const char* family, unsigned key) {
+  __atomic_fetch_add(&g_fallbacks, 1ll, __ATOMIC_RELAXED);
+  static std::mutex mu;
+  static std::set<std::pair<std::string, unsigned>> seen;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!seen.insert({family, key}).second) return;
+  fprintf(stderr, "libpcuda_hip: %s variant %u is not in this build (pruned to the shapes of the benchmark configurations and "
+                  "tests): running on the generic kernel; `make FULL=1` builds every variant\n", family, key);
+}
 
 long long g_pcuda_launches = 0;
 extern "C" long long pcuda_launch_count(int reset) {

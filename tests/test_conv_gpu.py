@@ -329,3 +329,28 @@ def test_table_repack_matches_the_per_layer_pack(dev, prec):
                     assert torch.equal(img.view(torch.uint8), fresh.view(torch.uint8)), (kind, op.cin, op.cout, op.k)
     finally:
         K.set_precision("bf16x3")
+
+
+def test_pruned_build_falls_back_to_the_generic_kernels(dev):
+    """The default build holds the template instantiations the benchmark configurations and the network-level tests reach
+    (csrc/variants.h, built_variants.h); any other geometry must run -- correctly -- on the generic kernels and say so.
+    A 3x3 layer on a 20 x 52 map (ragged tiles, dword staging) is in no configuration: forward, dgrad and wgrad against the
+    CPU reference, and the fallback counter moves unless this is a FULL build."""
+    from pointcloududa_amd import kernels as K
+    lib = K.L.lib()
+    n, cin, cout, h, w_ = 2, 48, 80, 20, 52
+    rng = np.random.default_rng(77)
+    x = torch.from_numpy(rng.normal(0, 1, (n, cin, h, w_)).astype(np.float32))
+    w = torch.from_numpy(rng.normal(0, 0.1, (cout, cin, 3, 3)).astype(np.float32))
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    z = F.conv2d(xr, wr, None, padding=1)
+    gz = torch.from_numpy(rng.normal(0, 1, z.shape).astype(np.float32))
+    z.backward(gz)
+    before = lib.pcuda_fallback_count()
+    op = K.ConvOp(cin, cout, 3, pad=1)
+    y, _, _ = op.forward(x.to(dev), w.to(dev), None, 1.0, h, w_)
+    dx = op.dgrad(gz.to(dev), w.to(dev), h, w_)
+    dw = torch.zeros_like(w, device=dev)
+    op.wgrad(x.to(dev), gz.to(dev), dw, None, h, w_, accumulate=False)
+    assert rel_err(y, z) < 1e-4 and rel_err(dx, xr.grad) < 1e-4 and rel_err(dw, wr.grad) < 1e-4
+    print("fallback launches for this geometry:", lib.pcuda_fallback_count() - before)
