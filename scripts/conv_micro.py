@@ -30,9 +30,15 @@ CASES = {  # name: (n, cin, cout, h, w, k, s, p, d, up)
 which = sys.argv[1:] or list(CASES)
 for name in which:
     n, cin, cout, h, w, k, s, p, d, up = CASES[name]
+    # the variants the NETWORKS launch (and the default build holds, csrc/variants.h): the segmenter's 3x3 layers have a bias,
+    # LeakyReLU(0.01) and BatchNorm partial sums -- the bottleneck (b*/mb*) no BatchNorm; the discriminators' stride-2 layers
+    # (d*/md*) no bias, LeakyReLU(0.2), no statistics
+    disc, bott = name.lstrip("m").startswith("d"), name.lstrip("m").startswith("b")
+    stats, slope = not (disc or bott), (0.2 if disc else 0.01)
+    if os.environ.get("MICRO_NOSTATS") == "1": stats = False
     op = K.ConvOp(cin, cout, k, stride=s, pad=p, dil=d, in_up=up)
     x = torch.randn(n, cin, h, w, device=dev); wt = torch.randn(cout, cin, k, k, device=dev) * 0.05
-    b = torch.zeros(cout, device=dev)
+    b = None if disc else torch.zeros(cout, device=dev)
     oh, ow = op.out_hw(h, w)
     gz = torch.randn(n, cout, oh, ow, device=dev)
     dw = torch.zeros_like(wt)
@@ -41,7 +47,7 @@ for name in which:
         fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(reps): fn()
         torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps
-    tf = t(lambda: op.forward(x, wt, b, 0.01, h, w, want_stats=True))
+    tf = t(lambda: op.forward(x, wt, b, slope, h, w, want_stats=stats))
     td = t(lambda: op.dgrad(gz, wt, h, w))
     tw = t(lambda: op.wgrad(x, gz, dw, b, h, w))
     print("%-5s fwd %7.3f ms %6.1f TF | dgrad %7.3f ms %6.1f TF | wgrad %7.3f ms %6.1f TF" % (name, tf*1e3, fl/tf/1e12, td*1e3, fl/td/1e12, tw*1e3, fl/tw/1e12), flush=True)
