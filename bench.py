@@ -341,6 +341,11 @@ def main():
     pin_rank_to_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))    # before the first GPU call
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    # PCUDA_SHARE_GPU=1 (rehearsal of the N > 1 control flow on a one-GPU box, with PCUDA_DIST_BACKEND=gloo: RCCL refuses two
+    # ranks per device): every rank uses device 0.  Not a measurement.
+    share = os.environ.get("PCUDA_SHARE_GPU") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -348,7 +353,11 @@ def main():
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"))
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)      # RCCL over xGMI
+        backend = os.environ.get("PCUDA_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)      # RCCL over xGMI
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     if args.gpus != world:
         raise SystemExit("bench.py: --gpus %d but the launcher's WORLD_SIZE is %d" % (args.gpus, world))
 
@@ -445,7 +454,9 @@ def main():
         "data": "synthetic",
         "config": {"workload": wl["desc"], "per_gpu_batch": b, "global_batch": b * world, "precision": args.precision,
                    "parallelism": "dp%d" % world, "ranks_in_group": ranks_in_group,
-                   "collective": "RCCL all-reduce of the flat gradient buffers (G: 2 buckets, D: 1 each)" if world > 1 else "none",
+                   "collective": ("%s all-reduce of the flat gradient buffers (G: 2 buckets, D: 1 each)" % (
+                       "RCCL" if os.environ.get("PCUDA_DIST_BACKEND", "nccl") == "nccl" else os.environ["PCUDA_DIST_BACKEND"] + " (REHEARSAL, ranks share one GPU)"))
+                                 if world > 1 else "none",
                    "algorithmic_gflop_per_pair": wl["gflop_per_pair"],
                    # the SURVEY 8d convention counts 8 passes per discriminator; with the target forward of d1 / d2
                    # replayed from the adversarial pass, 7 of them execute for those two networks
