@@ -342,6 +342,242 @@ __global__ __launch_bounds__(256, 2) void rconv3_kernel(const RConvParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// One-chunk / one-co-tile layers (32 -> 32: the 256x256 level): ONE 512-thread workgroup per CU, two groups of four waves that
+// alternate roles at every barrier -- while group A runs the MFMA phase of its tile, group B issues the DMA of ITS next tile
+// into its own input image, finishes its previous tile (values, statistics, records out) and waits for that DMA; at the
+// barrier they swap.  The 36 KB of weights are resident for the whole launch and shared by both groups, each group owns a
+// 43-KB input image and 16 KB of record staging: 155 KB.  Against two independent 256-thread workgroups (rconv3_kernel) the
+// matrix pipe always has one group feeding it, and a tile's loads are in flight for the whole of the other group's phase.
+template <bool STATS, bool DBG>
+__global__ __launch_bounds__(512, 1) void rconv3w_kernel(const RConvParams p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wv >> 2, w = wv & 3;                       // group, wave inside the group
+  unsigned char* const Ws = smem;
+  unsigned char* const Xs = smem + RC_WBYTES + g * RC_XBYTES;
+  unsigned char* const stg = smem + RC_WBYTES + 2 * RC_XBYTES + (g * 4 + w) * 4096;      // 32 records per wave
+  float* const sred = (float*)(smem + RC_WBYTES + 2 * RC_XBYTES + 8 * 4096) + g * 256;   // [4 waves][32][2] per group
+  const int H = p.H, W = p.W;
+
+  const int nx = min(8, (int)gridDim.x);
+  const int xcd = blockIdx.x % nx, slot = blockIdx.x / nx;
+  const int gx = ((int)gridDim.x - xcd + nx - 1) / nx;
+  const int lo = (int)((long long)p.total * xcd / nx), hi = (int)((long long)p.total * (xcd + 1) / nx);
+  // group g of workgroup `slot` takes items lo + 2 slot + g, + 2 gx, ...: the two groups walk adjacent tiles
+  const int Lstep = 2 * gx;
+  int L = lo + 2 * slot + g;
+  const int n_mine = L < hi ? (hi - L + Lstep - 1) / Lstep : 0;
+  const int L0 = lo + 2 * slot;
+  const int n_a = L0 < hi ? (hi - L0 + Lstep - 1) / Lstep : 0;      // group A has the most items
+  const int nint = 2 * n_a + 1;                                     // barrier intervals, the same for every wave
+
+  int xrel[RC_NJ];
+#pragma unroll
+  for (int j = 0; j < RC_NJ; ++j) {
+    const int q = (w + 4 * j) * 64 + lane;
+    const int rec = min(q >> 3, RC_NREC - 1), s = q & 7;
+    const int c = s ^ ((rec >> 1) & 7);
+    const int ry = rec / RC_HW, rx = rec - ry * RC_HW;
+    xrel[j] = (ry * W + rx) * REC_B + c * 16;
+  }
+  int xa[2][9];
+#pragma unroll
+  for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int pp = (2 * w + pb + t / 3) * RC_HW + r + (t % 3);
+      xa[pb][t] = pp * REC_B + ((h ^ ((pp >> 1) & 7)) << 4);
+    }
+  const int wa = r * REC_B + ((h ^ ((r >> 1) & 7)) << 4);
+  const int wah[2] = {wa, wa ^ 32}, wal[2] = {wa ^ 64, wa ^ 96};
+  const int sto0 = (lane >> 3) * REC_B + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);
+
+  struct Item { int pt, n, y0, x0; bool border; };
+  auto decode = [&](int Li) {
+    Item it;
+    it.pt = Li;
+    const int txi = Li % p.tiles_x, tmp = Li / p.tiles_x;
+    const int tyi = tmp % p.tiles_y;
+    it.n = tmp / p.tiles_y;
+    it.y0 = tyi * RC_TH; it.x0 = txi * RC_TW;
+    it.border = (it.y0 == 0) | (it.y0 + RC_TH == H) | (it.x0 == 0) | (it.x0 + RC_TW == W);
+    return it;
+  };
+  auto issue = [&](const Item& it) {
+    const unsigned char* xb = p.x + (long long)it.n * p.x_sn + ((long long)(it.y0 - 1) * W + (it.x0 - 1)) * REC_B;
+    if (it.border) {
+      const int lz = lane + opaque_zero_v();
+#pragma unroll
+      for (int j = 0; j < RC_NJ; ++j) {
+        if (w + 4 * j < RC_XPIECES) {
+          const int q = (w + 4 * j) * 64 + lz;
+          const int rec = min(q >> 3, RC_NREC - 1), c = (q & 7) ^ ((rec >> 1) & 7);
+          const int ry = (rec * 1928) >> 16, rx = rec - ry * RC_HW;
+          const bool in = ((unsigned)(it.y0 - 1 + ry) < (unsigned)H) & ((unsigned)(it.x0 - 1 + rx) < (unsigned)W);
+          const unsigned char* src = in ? xb + xrel[j] : p.pad + c * 16;
+          dma16(src, Xs + (w + 4 * j) * 1024);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < RC_NJ; ++j)
+        if (w + 4 * j < RC_XPIECES) dma16(xb + (unsigned)xrel[j], Xs + (w + 4 * j) * 1024);
+    }
+  };
+
+  float bia[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) bia[i] = p.bias ? p.bias[(i & 3) + 8 * (i >> 2) + 4 * h] : 0.f;
+  // ---- prologue: the weights (36 pieces over the 8 waves), each group's first tile
+  {
+    const unsigned char* wsrc = p.wpack + lane * 16;
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+      if (wv + 8 * j < 36) dma16(wsrc + (wv + 8 * j) * 1024, Ws + (wv + 8 * j) * 1024);
+  }
+  Item cur = decode(min(L, p.total - 1)), done = cur;
+  if (n_mine > 0) issue(cur);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  RC_BARRIER();
+
+  f32x16 acc[2];
+  unsigned long long clk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+  int k_mine = 0;          // tiles this group has computed
+  bool pending = false;    // a computed tile whose epilogue has not run yet
+  for (int it = 0; it < nint; ++it) {
+    if ((it & 1) == g) {
+      // ================= compute interval =================
+      RC_CLK(0)
+      if (k_mine < n_mine) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+        const int oz = opaque_zero_v();
+        bf16x8 fa[2][2], fb[2][4];
+        auto load = [&](int bufi, int st) {
+          const int t = st >> 1, ks = st & 1;
+          const int x0a = xa[0][t] + oz, x1a = xa[1][t] + oz;
+          fa[bufi][0] = frag(Ws + wah[ks] + t * 32 * REC_B);
+          fa[bufi][1] = frag(Ws + wal[ks] + t * 32 * REC_B);
+          fb[bufi][0] = frag(Xs + (x0a ^ (ks * 32)));
+          fb[bufi][1] = frag(Xs + (x0a ^ (ks * 32) ^ 64));
+          fb[bufi][2] = frag(Xs + (x1a ^ (ks * 32)));
+          fb[bufi][3] = frag(Xs + (x1a ^ (ks * 32) ^ 64));
+        };
+        load(0, 0);
+#pragma unroll
+        for (int st = 0; st < 18; ++st) {
+          const int cb = st & 1;
+          if (st + 1 < 18) load(cb ^ 1, st + 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) {
+            acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cb][1], fb[cb][2 * pb], acc[pb], 0, 0, 0);
+            acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cb][0], fb[cb][2 * pb + 1], acc[pb], 0, 0, 0);
+            acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cb][0], fb[cb][2 * pb], acc[pb], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (DBG) asm volatile("s_nop 0" ::"v"(acc[0][15]), "v"(acc[1][15]));
+        RC_CLK(1)
+        done = cur;
+        ++k_mine;
+        pending = true;
+      }
+    } else if (pending) {
+      // ================= memory interval: next tile's DMA first, then this tile's epilogue behind it =================
+      RC_CLK(0)
+      L += Lstep;
+      const bool more = k_mine < n_mine;
+      if (more) {
+        cur = decode(L);
+        issue(cur);
+      }
+      RC_CLK(2)
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float t = acc[pb][i] + bia[i];
+          acc[pb][i] = fmaxf(t, t * p.slope);
+        }
+      if (STATS) {
+        // (as rconv3_kernel: a [value][lane] table in the wave's staging block, 16-byte chunks XOR-swizzled by the value
+        // index; the block holds 4 KiB = 16 values x 64 lanes, so the sums and the sums of squares go through it in turn)
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const float a0 = acc[0][v], a1 = acc[1][v];
+            const float val = qq == 0 ? a0 + a1 : fmaf(a1, a1, a0 * a0);
+            *(float*)(stg + v * 256 + ((((lane >> 2) ^ v) << 4) | ((lane & 3) << 2))) = val;
+          }
+          const int vv = lane & 15, part = (lane >> 4) & 1;      // lane (vv, part, h): value vv, 16 of the 32 lanes of half h
+          float tot = 0.f;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const f32x4 q4 = *(const f32x4*)(stg + vv * 256 + (((h * 8 + part * 4 + jj) ^ vv) << 4));
+            tot += (q4[0] + q4[1]) + (q4[2] + q4[3]);
+          }
+          tot += __shfl_xor(tot, 16, 64);                        // the two 16-lane parts of the half
+          const int row = (vv & 3) + 8 * (vv >> 2) + 4 * h;
+          if (part == 0) sred[(w * 32 + row) * 2 + qq] = tot;
+        }
+      }
+      RC_CLK(3)
+      unsigned char* const yb = p.y + (long long)done.n * p.y_sn;
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = acc[pb][i];
+        asm volatile("s_nop 1\n\t"
+                     "v_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\t"
+                     "v_permlane32_swap_b32 %2, %6\n\tv_permlane32_swap_b32 %3, %7\n\t"
+                     "v_permlane32_swap_b32 %8, %12\n\tv_permlane32_swap_b32 %9, %13\n\t"
+                     "v_permlane32_swap_b32 %10, %14\n\tv_permlane32_swap_b32 %11, %15\n\t"
+                     "s_nop 1"
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                       "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          u32x4 hi4, lo4;
+          split8(&v[8 * jj], hi4, lo4);
+          *(u32x4*)(stg + r * REC_B + (((2 * jj + h) ^ (r & 7)) << 4)) = hi4;
+          *(u32x4*)(stg + r * REC_B + (((4 + 2 * jj + h) ^ (r & 7)) << 4)) = lo4;
+        }
+        unsigned char* const row0 = yb + ((long long)(done.y0 + 2 * w + pb) * W + done.x0) * REC_B + lane * 16;
+        u32x4 o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = *(const u32x4*)(stg + sto0 + k * 1024);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *(u32x4*)(row0 + k * 1024) = o[k];
+      }
+      pending = false;
+      RC_CLK(4)
+      // the DMA pieces of the next tile have landed: all but the 8 record stores issued behind them
+      if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      RC_CLK(5)
+    }
+    RC_BARRIER();
+    RC_CLK(6)
+    if (STATS && (it & 1) != g && w == 0 && lane < 32 && !pending && k_mine > 0 && it >= 1) {
+      // (after the barrier that closed this group's memory interval: its four waves' partial sums are complete)
+      if (it == 2 * (k_mine - 1) + 1 + g) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) { a += sred[(ww * 32 + lane) * 2 + 0]; b += sred[(ww * 32 + lane) * 2 + 1]; }
+        p.stats[((long long)done.pt * p.cout + lane) * 2 + 0] = a;
+        p.stats[((long long)done.pt * p.cout + lane) * 2 + 1] = b;
+      }
+    }
+  }
+  if (DBG && lane == 0 && w == 0) {
+    for (int i = 0; i < 7; ++i) atomicAdd(&p.dbg_clk[i], clk[i]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // layout conversions at the module boundary (and for tests): NCHW fp32 (+ per-channel affine) <-> R32
 // one thread = one 16-byte piece (8 channels of one pixel, hi or lo)
 __global__ void rec_from_nchw_kernel(const float* __restrict__ x, long long sn, long long sc, int c, int hw,
@@ -510,8 +746,25 @@ extern "C" int pcuda_rconv3_forward(const void* x, int n, int cin, int h, int w,
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
     return PCUDA_OK;
   };
-  const int rc = p.dbg_clk ? (stats ? launch(rconv3_kernel<true, true>) : launch(rconv3_kernel<false, true>))
-                           : (stats ? launch(rconv3_kernel<true, false>) : launch(rconv3_kernel<false, false>));
+  static int wmode = -1;
+  if (wmode < 0) { const char* e = getenv("PCUDA_RC_W"); wmode = (e && !atoi(e)) ? 0 : 1; }
+  int rc;
+  if (wmode && p.cb_in == 1 && p.n_co_tiles == 1) {
+    // one chunk, one co-tile: the two-group kernel, one 512-thread workgroup per CU with the weights resident
+    const size_t ldsw = RC_WBYTES + 2 * RC_XBYTES + 8 * 4096 + 2 * 1024;
+    const int gridw = p.total < 2 * ncu ? (p.total + 1) / 2 : ncu;
+    auto launchw = [&](auto kern) -> int {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HARD);
+      if (e != hipSuccess) PCUDA_FAIL(PCUDA_E_LAUNCH, "rconv3w: cannot raise dynamic LDS: %s", hipGetErrorString(e));
+      hipLaunchKernelGGL(kern, dim3(gridw), dim3(512), ldsw, (hipStream_t)stream, p);
+      return PCUDA_OK;
+    };
+    rc = p.dbg_clk ? (stats ? launchw(rconv3w_kernel<true, true>) : launchw(rconv3w_kernel<false, true>))
+                   : (stats ? launchw(rconv3w_kernel<true, false>) : launchw(rconv3w_kernel<false, false>));
+  } else {
+    rc = p.dbg_clk ? (stats ? launch(rconv3_kernel<true, true>) : launch(rconv3_kernel<false, true>))
+                   : (stats ? launch(rconv3_kernel<true, false>) : launch(rconv3_kernel<false, false>));
+  }
   if (rc != PCUDA_OK) return rc;
   PCUDA_CHECK_LAUNCH("rconv3_kernel");
   return PCUDA_OK;

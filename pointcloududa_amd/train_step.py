@@ -89,6 +89,7 @@ class AdversarialTrainer:
         # ... with the source batch's activations written in front of the cached target ones: one backward pass over 2B
         self.d_joint = os.environ.get("PCUDA_DJOINT", "1") != "0"
         self._segment = None      # "compute": step() leaves out the collectives and the optimiser steps (step_graphed)
+        self._timeline = os.environ.get("PCUDA_TIMELINE", "0") == "1"     # (read per trainer, not at import time)
 
     def _side_streams(self, names):
         """One side stream PER DISCRIMINATOR, keyed by its name: a network's frozen pass (phase 2), its input-gradient
@@ -138,14 +139,17 @@ class AdversarialTrainer:
     # ------------------------------------------------------------------ one loop iteration
     # PCUDA_TIMELINE=1 (diagnostics, scripts/step_timeline.py): timed events on the streams at the schedule's joints -- where
     # each stream is when, without a profiler in the host's way.  Off: ``_mark`` returns at once.
-    _timeline = os.environ.get("PCUDA_TIMELINE", "0") == "1"
+    _MARKS_KEPT = 8 * 32      # the last ~8 steps' marks: a training run with the variable left set does not grow without bound
 
     def _mark(self, label, stream=None):
         if not self._timeline:
             return
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(stream if stream is not None else torch.cuda.current_stream())
-        self.__dict__.setdefault("_marks", []).append((label, ev))
+        marks = self.__dict__.setdefault("_marks", [])
+        marks.append((label, ev))
+        if len(marks) > 2 * self._MARKS_KEPT:
+            del marks[:len(marks) - self._MARKS_KEPT]
 
     def step(self, img_a, mask_a_u8, vert_a, img_b, vert_b, drop_mask=None, keep=False) -> Dict[str, torch.Tensor]:
         c, out = self.cfg, {}

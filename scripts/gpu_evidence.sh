@@ -4,13 +4,14 @@
 # calibration.  Everything lands in gpurun_out/ (copy the summaries to profiles/).   usage: TAG=r03 bash scripts/gpu_evidence.sh
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-TAG=${TAG:-r03}
+TAG=${TAG:-r04}
 python3 -c "import sys; sys.path.insert(0, '.'); from pointcloududa_amd._lib import csrc_hash; print('csrc_sha256', csrc_hash())" | tee gpurun_out/${TAG}_build_hash.txt
 # (the whole-step traffic first: bench.py quotes roofline.traffic from profiles/rNN_pmc_traffic.csv of THIS build's hash)
-TAG=$TAG bash scripts/gpu_pmc_step.sh > gpurun_out/${TAG}_pmc_step.log 2>&1; echo "pmc_step rc=$?"
-cp gpurun_out/${TAG}_pmc_traffic.csv profiles/${TAG}_pmc_traffic.csv
+TAG=$TAG bash scripts/gpu_pmc_step.sh > gpurun_out/${TAG}_pmc_step.log 2>&1; rc=$?; echo "pmc_step rc=$rc"
+# (only a pass that succeeded AND produced rows replaces the committed summary)
+if [ $rc -eq 0 ] && [ "$(grep -vc '^#' gpurun_out/${TAG}_pmc_traffic.csv 2>/dev/null)" -gt 1 ]; then cp gpurun_out/${TAG}_pmc_traffic.csv profiles/${TAG}_pmc_traffic.csv; else echo "pmc_traffic NOT copied"; fi
 TAG=$TAG bash scripts/gpu_profile.sh > gpurun_out/${TAG}_profile.log 2>&1; echo "profile rc=$?"
-for wl in unet_d2 mmwhs_uda uda_512; do
+for wl in unet_d2 mmwhs_uda uda_512 mscmrseg_224; do
   python3 bench.py --workload $wl --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_$wl.json; echo "$wl: $(cut -c1-160 gpurun_out/${TAG}_bench_$wl.json)"
 done
 python3 bench.py --precision bf16 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_full_uda_bf16.json; echo "bf16: $(cut -c1-160 gpurun_out/${TAG}_bench_full_uda_bf16.json)"

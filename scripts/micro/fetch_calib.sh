@@ -4,6 +4,8 @@
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 TAG=${TAG:-r03}
+# (the binary is not tracked: build it here, before anything touches the GPU)
+mkdir -p scripts/micro/bin && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 scripts/micro/fetch_calib.hip -o scripts/micro/bin/fetch_calib || exit 1
 rm -rf gpurun_out/fcal; mkdir -p gpurun_out/fcal
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --output-format csv -d gpurun_out/fcal/$c -o cal -- ./scripts/micro/bin/fetch_calib > gpurun_out/fcal/$c.log 2>&1

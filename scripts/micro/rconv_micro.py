@@ -31,6 +31,11 @@ for name in (sys.argv[1:] or list(CASES)):
         for _ in range(10): K.rconv3_forward(xr, wp, b, 0.01, cout, pad_records=pad, want_stats=True)
         K.L.lib().pcuda_rconv3_debug_clocks(buf)
         tot = float(sum(buf)) or 1.0
+        if cin == 32 and cout == 32 and os.environ.get("PCUDA_RC_W", "1") != "0":
+            names = ["interval top", "MFMA phase", "decode + DMA issue", "values + statistics", "swap / split / stage / stores", "DMA wait", "barrier"] + ["-"] * 5
+            print("   two-group kernel, wave 0 of each group (share of time):", " | ".join("%s %.1f%%" % (nm, 100.0 * v / tot) for nm, v in zip(names, buf) if v),
+                  " time per workgroup-group and launch: %.0f" % (tot / 10 / 512))
+            continue
         names = ["barrier after MFMA", "loop top", "DMA wait", "barrier", "MFMA", "stats store", "epilogue math + LDS stage", "LDS read + global stores",
                  "stats DPP", "barrier", "decode + DMA issue", "-"]
         print("   phases (share of wave 0's time):", " | ".join("%s %.1f%%" % (nm, 100.0 * v / tot) for nm, v in zip(names, buf) if v))
