@@ -93,11 +93,19 @@ typedef struct pcuda_src {
   const float* p1; long long sn1, sc1; const float* scale1; const float* shift1;
   const float* p2; long long sn2, sc2; const float* scale2; const float* shift2;
   int c1;
+  /* record form (round 4; csrc/conv_rec.hip has the layout): rec != 0 marks BOTH sources as record tensors
+   * [N][C/32][H][W][bf16 hi x 32 | lo x 32]: p = the tensor, sn = floats (4-byte units) per image, sc = floats per 32-CHANNEL
+   * plane (32 x H x W); the channel counts are multiples of 32 and no affine is applied on load (a BatchNorm in front is
+   * folded into the packed weights and the bias); pad1 / pad2: [C/32][128 B], the record read outside the image (zeros, or
+   * -shift / scale of a folded BatchNorm); never NULL when rec is set */
+  int rec;
+  const void* pad1; const void* pad2;
 } pcuda_src;
 typedef struct pcuda_dst {
   float* p1; long long sn1, sc1;
   float* p2; long long sn2, sc2;
   int c1;
+  int rec;      /* both destinations are record tensors (sn / sc as in pcuda_src) */
 } pcuda_dst;
 
 /* packed-weight sizes (bytes) for a given geometry / precision */

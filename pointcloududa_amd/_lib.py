@@ -32,11 +32,12 @@ class ReduceJob(C.Structure):      # pcuda_reduce_job (include/pcuda_hip.h)
 
 class Src(C.Structure):
     _fields_ = [("p1", vp), ("sn1", i64), ("sc1", i64), ("scale1", vp), ("shift1", vp),
-                ("p2", vp), ("sn2", i64), ("sc2", i64), ("scale2", vp), ("shift2", vp), ("c1", i32)]
+                ("p2", vp), ("sn2", i64), ("sc2", i64), ("scale2", vp), ("shift2", vp), ("c1", i32),
+                ("rec", i32), ("pad1", vp), ("pad2", vp)]
 
 
 class Dst(C.Structure):
-    _fields_ = [("p1", vp), ("sn1", i64), ("sc1", i64), ("p2", vp), ("sn2", i64), ("sc2", i64), ("c1", i32)]
+    _fields_ = [("p1", vp), ("sn1", i64), ("sc1", i64), ("p2", vp), ("sn2", i64), ("sc2", i64), ("c1", i32), ("rec", i32)]
 
 
 _PROTOS = {

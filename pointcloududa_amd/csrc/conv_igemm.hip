@@ -307,8 +307,8 @@ int plan_igemm_mode(int rows, int lh, int lw, int in_h, int in_w, int in_step, c
 // (tile, co-tile) items for two workgroups per CU (16x16 maps); measured slower elsewhere (3x3 layers at
 // 32x32 and up, the 4-tap dgrad classes), where two independent workgroups per CU overlap better.
 int plan_igemm(int rows, int red, int n, int lh, int lw, int in_h, int in_w, int in_step, const TapSet& taps, bool x3,
-               IgemmPlan* best) {
-  const int mode_env = ig_plan_mode();
+               IgemmPlan* best, bool allow8 = true) {
+  const int mode_env = allow8 ? ig_plan_mode() : 0;
   const bool single_chunk = red <= 32;
   IgemmPlan p0;
   const int rc0 = plan_igemm_mode(rows, lh, lw, in_h, in_w, in_step, taps, x3, mode_env == 2 ? 0 : mode_env, &p0);
@@ -330,7 +330,8 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
   const int co_blks = ig_co_blks(p.cout);
   const int co_tile = 32 * co_blks;
   IgemmPlan pl;
-  if (plan_igemm(p.cout, p.cin, p.n, p.lh, p.lw, p.in_h, p.in_w, p.in_step, taps, x3, &pl) < 0)
+  // (record sources are staged by the four-wave pipelined kernel only)
+  if (plan_igemm(p.cout, p.cin, p.n, p.lh, p.lw, p.in_h, p.in_w, p.in_step, taps, x3, &pl, !p.x.rec) < 0)
     PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "igemm: no tile of this convolution fits LDS (in_step %d, tap span %d)",
                p.in_step, taps.dy_max - taps.dy_min);
   p.n_co_tiles = cdiv(p.cout, co_tile);
@@ -365,13 +366,21 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
     const int ih = (pl.clamp && pl.ih_t > p.in_h) ? p.in_h : pl.ih_t;   // rows the kernel stages (unclamped: all of the halo)
     const int pfq = (ih * ((pl.iw_t + 6) / 4) + 63) / 64;
     p.xq = (!noxq && (p.in_w & 3) == 0 && p.in_shift == 0 && pfq <= 3) ? 1 : 0;
+    p.xr = p.x.rec ? 1 : 0;
+    if (p.xr) {
+      // record sources: bf16x3 only, whole 32-channel chunks, the pipelined four-wave kernel (no fallback reads records)
+      if (!x3 || (p.cin & 31) || (p.x.c1 < p.cin && (p.x.c1 & 31)) || !p.x.pad1 || (p.x.c1 < p.cin && !p.x.pad2))
+        PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "igemm: record sources need bf16x3, channel counts in multiples of 32 and pad records");
+      p.xq = 0;
+      if (pl.w8) PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "igemm: record sources are not staged by the eight-wave kernel");
+    }
     if (p.xq) pf = pfq;
     if (pl.w8) pf = p.xq ? (ih * ((pl.iw_t + 6) / 4) + 127) / 128 : (max_pix + 511) / 512;   // 512 lanes
   }
   // PF = 3 keeps 96 prefetch registers live next to the accumulators: only with one pixel block per wave
   // (one workgroup per CU has 512 registers per lane: PF = 3 next to two pixel blocks fits there)
   // (the unpipelined fallback copies its weight groups in 512-vector passes: any tg of the plan works)
-  const bool pipe = !nopipe && p.ntaps > 0 && fast_src_ok(&p.x, p.cin) && fast_dst_ok(&p.y, p.cout) &&
+  const bool pipe = !nopipe && p.ntaps > 0 && (p.x.rec || fast_src_ok(&p.x, p.cin)) && fast_dst_ok(&p.y, p.cout) &&
                     (pf <= 2 || (pf == 3 && !pl.w8 && (pl.npb == 1 || pl.fat)));
   {   // transposed epilogue: its LDS scratch (4 waves x [32][32*npb] fp32 + the partial-sum slots) aliases the
       // X / W slabs and must end in front of the tap table behind them
@@ -390,6 +399,7 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
       }
     }
   }
+  if (p.xr && !pipe) PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "igemm: record sources need the pipelined kernel for this geometry");
   if (p.red_a && !(pipe && pl.te))
     PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv2d_dgrad_bnred: this geometry does not run on the transposed-epilogue kernel");
   return x3 ? igemm_dispatch_x3(p, pl, co_blks, pf, pipe, s) : igemm_dispatch_bf16(p, pl, co_blks, pf, pipe, s);

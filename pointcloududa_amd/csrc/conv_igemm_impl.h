@@ -4,6 +4,7 @@
 #include "conv_device.h"
 #include "conv_host.h"
 #include "variants.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------
 // forward / dgrad kernel.  256 threads = 4 waves; tile = CO_TILE rows x (128*NPB) logical pixels;
@@ -297,8 +298,9 @@ __device__ __forceinline__ TileGeom tile_decode(const IgemmParams& p, int L) {
 // inside its MFMA phase.
 // STATS: 0 none, 1 BatchNorm partial sums of the stored values (forward), 2 BatchNorm-BACKWARD reduce partials of the
 // stored gradient against the saved activation (dgrad of a block's second convolution; transposed epilogue only)
-template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ, int STATS, bool TE>
+template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ, int STATS, bool TE, bool XR = false>
 __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const IgemmParams p, const int x_cap, const int total) {
+  static_assert(!XR || (X3 && !XQ), "record staging: bf16x3 records, instead of the quad path");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CO_TILE = 32 * CO_BLKS;
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
   }
 
   f32x16 acc[CO_BLKS][NPB];
-  XFast<PF> pre;
+  typename std::conditional<XR, XRec<PF>, XFast<PF>>::type pre;
   DBG_CLK_DECL
 
   int L = lo + slot, chunk = 0;
@@ -355,7 +357,8 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
   TileGeom g;
   if (have) {
     g = tile_decode<CLAMP, NPB>(p, L);
-    if (XQ) xq_issue<PF>(pre, p.x, g.n, p.cin, 0, p.in_h, p.in_w, g.oy0, g.ox0, g.th, g.tw, tid);
+    if constexpr (XR) xr_issue<PF>(pre, p.x, g.n, 0, p.in_h, p.in_w, p.in_shift, p.in_row, g.oy0, g.ox0, g.tw, g.npix, tid);
+    else if constexpr (XQ) xq_issue<PF>(pre, p.x, g.n, p.cin, 0, p.in_h, p.in_w, g.oy0, g.ox0, g.th, g.tw, tid);
     else xfast_issue<PF>(pre, p.x, g.n, p.cin, 0, p.in_h, p.in_w, p.in_shift, p.in_row, g.oy0, g.ox0, g.tw, g.npix,
                          (min(32, p.cin) + 7) >> 3, tid);
   }
@@ -365,10 +368,19 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
     DBG_CLK(7)
     __syncthreads();   // every wave is done with the previous stage's X / W / reduction scratch
     DBG_CLK(0)
-    if (XQ) xq_commit<X3, PF, 256, REC>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.ox0, g.th, g.tw, nks * 2, tid);
+    if constexpr (XR) xr_commit<PF, 256, REC>(pre, Xhi, g.npix, tid);
+    else if constexpr (XQ) xq_commit<X3, PF, 256, REC>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.ox0, g.th, g.tw, nks * 2, tid);
     else xfast_commit<X3, PF, 256, REC>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.npix, (cvalid + 7) >> 3, nks * 2, tid);
     DBG_CLK(1)
-    if (CLAMP && tid < RECV) *(uint4*)(Xhi + (size_t)g.npix * REC + tid * 16) = make_uint4(0, 0, 0, 0);
+    if (CLAMP && tid < RECV) {   // the record that out-of-image taps read: zeros, or the source's pad record
+      uint4 z = make_uint4(0, 0, 0, 0);
+      if constexpr (XR) {
+        const bool f1 = chunk * 32 < p.x.c1;
+        const char* pp = (const char*)(f1 ? p.x.pad1 : p.x.pad2) + (((f1 ? chunk * 32 : chunk * 32 - p.x.c1) >> 5) * 128);
+        if (tid < 8) z = *(const uint4*)(pp + tid * 16);
+      }
+      *(uint4*)(Xhi + (size_t)g.npix * REC + tid * 16) = z;
+    }
     // bias of this tile's rows (consumed by the epilogue after the last chunk): fetched here, in front of the
     // stage's other loads, so its wait never drains them
     float bias_r = 0.f;
@@ -424,7 +436,9 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
     if (nhave && nL != L) ng = tile_decode<CLAMP, NPB>(p, nL);
     // unconditional (no stage left: zero pixels, every lane out of range -> no memory traffic)
     auto issue_next = [&]() {
-      if (XQ) xq_issue<PF>(pre, p.x, ng.n, p.cin, nhave ? nchunk : 0, p.in_h, p.in_w, ng.oy0, ng.ox0, nhave ? ng.th : 0,
+      if constexpr (XR) xr_issue<PF>(pre, p.x, ng.n, nhave ? nchunk : 0, p.in_h, p.in_w, p.in_shift, p.in_row, ng.oy0, ng.ox0,
+                                     ng.tw, nhave ? ng.npix : 0, tid);
+      else if constexpr (XQ) xq_issue<PF>(pre, p.x, ng.n, p.cin, nhave ? nchunk : 0, p.in_h, p.in_w, ng.oy0, ng.ox0, nhave ? ng.th : 0,
                              ng.tw, tid);
       else xfast_issue<PF>(pre, p.x, ng.n, p.cin, nhave ? nchunk : 0, p.in_h, p.in_w, p.in_shift, p.in_row, ng.oy0,
                            ng.ox0, ng.tw, nhave ? ng.npix : 0, 4, tid);
@@ -1052,15 +1066,15 @@ static int launch_igemm_c(const IgemmParams& p, const IgemmPlan& pl, hipStream_t
                      : launch_igemm_t<X3, CO_BLKS, false, 1>(p, pl.x_cap, pl.lds, s);
 }
 
-template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ, int STATS, bool TE>
+template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ, int STATS, bool TE, bool XR = false>
 static int launch_pipe_s(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
-  constexpr unsigned vkey = pipe_key(X3, CO_BLKS, CLAMP, NPB, PF, XQ, STATS, TE);
+  constexpr unsigned vkey = pipe_key(X3, CO_BLKS, CLAMP, NPB, PF, XQ, STATS, TE) | (XR ? 1u << 10 : 0u);
   variant_log("pipe", vkey);
   if constexpr (!pipe_built(vkey)) {
     variant_fallback_note("igemm_pipe_kernel", vkey);
     return PCUDA_E_NOTBUILT;
   } else {
-  auto kern = igemm_pipe_kernel<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, STATS, TE>;
+  auto kern = igemm_pipe_kernel<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, STATS, TE, XR>;
   static DeviceOnce lds_opt;
   if (const unsigned long long devbit = pl.lds > 32 * 1024 ? lds_opt.pending() : 0ull) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HARD);
@@ -1090,6 +1104,19 @@ static int launch_pipe_s(const IgemmParams& p, const IgemmPlan& pl, hipStream_t 
 
 template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ>
 static int launch_pipe_t(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
+  if constexpr (X3 && !XQ && !CLAMP && NPB == 2 && PF <= 2) {   // (the record-staging instantiations: the aligned 3x3 plans)
+    if (p.xr) {   // record sources (pcuda_src::rec)
+      if (pl.te) {
+        if (p.stats && p.red_a) return launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, false, 2, true, true>(p, pl, s);
+        return p.stats ? launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, false, 1, true, true>(p, pl, s)
+                       : launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, false, 0, true, true>(p, pl, s);
+      }
+      if (p.red_a) PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "igemm: the fused BatchNorm-backward reduce needs the transposed epilogue");
+      return p.stats ? launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, false, 1, false, true>(p, pl, s)
+                     : launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, false, 0, false, true>(p, pl, s);
+    }
+  }
+  if (p.xr) PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "igemm: no record-staging instantiation for this plan (clamp %d, %d pixel blocks, %d slots)", (int)CLAMP, NPB, PF);
   if (pl.te) {
     if (p.stats && p.red_a) return launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, 2, true>(p, pl, s);
     return p.stats ? launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, 1, true>(p, pl, s)

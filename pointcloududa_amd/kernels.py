@@ -70,12 +70,48 @@ class TA:
         self.t, self.scale, self.shift = t, scale, shift
 
 
-def _as_ta(x) -> TA:
-    return x if isinstance(x, TA) else TA(x)
+class Rec:
+    """A record tensor (csrc/conv_rec.hip): uint8 [N, C/32, H, W, 128] = per pixel and 32-channel chunk bf16 hi x 32 | lo x 32.
+    ``pad``: [C/32, 128] uint8, the record a convolution reads outside the image (None: zeros)."""
+    __slots__ = ("t", "c", "pad")
+
+    def __init__(self, t, c=None, pad=None):
+        self.t, self.c, self.pad = t, (t.shape[1] * 32 if c is None else c), pad
+
+    @property
+    def shape(self):
+        n, cb, h, w, _ = self.t.shape
+        return (n, self.c, h, w)
+
+
+_zero_pads = {}
+
+
+def _zero_pad(dev, cb):
+    k = (dev, cb)
+    if k not in _zero_pads:
+        _zero_pads[k] = torch.zeros((cb, 128), dtype=torch.uint8, device=dev)
+    return _zero_pads[k]
+
+
+def _as_ta(x):
+    return x if isinstance(x, (TA, Rec)) else TA(x)
 
 
 def make_src(a, b=None) -> Src:
     a = _as_ta(a)
+    if isinstance(a, Rec):
+        s = Src()
+        n, cb, h, w, _ = a.t.shape
+        s.p1, s.sn1, s.sc1, s.c1, s.rec = a.t.data_ptr(), cb * h * w * 32, h * w * 32, cb * 32, 1
+        s.pad1 = (a.pad if a.pad is not None else _zero_pad(a.t.device, cb)).data_ptr()
+        if b is not None:
+            if not isinstance(b, Rec):
+                raise TypeError("a record source takes a record second source")
+            n2, cb2, h2, w2, _ = b.t.shape
+            s.p2, s.sn2, s.sc2 = b.t.data_ptr(), cb2 * h2 * w2 * 32, h2 * w2 * 32
+            s.pad2 = (b.pad if b.pad is not None else _zero_pad(b.t.device, cb2)).data_ptr()
+        return s
     _, c1, _, sn1, sc1 = _planes(a.t)
     s = Src()
     s.p1, s.sn1, s.sc1, s.scale1, s.shift1, s.c1 = a.t.data_ptr(), sn1, sc1, _ptr(a.scale), _ptr(a.shift), c1
@@ -190,7 +226,7 @@ class ConvOp:
         n = dy.shape[0]
         g = self.geom(n, in_h, in_w)
         if dx is None:
-            dx = torch.empty((n, self.cin, in_h, in_w), dtype=torch.float32, device=dy.device)
+            dx = torch.empty((n, self.cin, in_h, in_w), dtype=torch.float32, device=(dy.t if isinstance(dy, Rec) else dy).device)
         pk = self._packed("dgrad", w, g)
         src, dst = make_src(dy), make_dst(dx, dx2)
         if bnred is not None:

@@ -7,7 +7,7 @@ import torch
 from pointcloududa_amd import kernels as K
 dev = torch.device("cuda", 0)
 CASES = {"g32": (32, 32, 32, 256, 256), "g64": (32, 64, 64, 128, 128), "c64_32": (32, 64, 32, 256, 256),
-         "g32_224": (32, 32, 32, 224, 224)}
+         "g32_224": (32, 32, 32, 224, 224), "g128": (32, 128, 128, 64, 64), "g256": (32, 256, 256, 32, 32)}
 def t(fn, reps=20):
     fn(); fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(reps): fn()
@@ -24,6 +24,12 @@ for name in (sys.argv[1:] or list(CASES)):
     t_new = t(lambda: K.rconv3_forward(xr, wp, b, 0.01, cout, pad_records=pad, want_stats=True))
     t_nos = t(lambda: K.rconv3_forward(xr, wp, b, 0.01, cout, pad_records=pad, want_stats=False))
     t_cv = t(lambda: K.rec_from_nchw(x))
+    # the shipped NCHW kernel fed from a record source (record staging in igemm_pipe_kernel, its own epilogue)
+    t_xr = t(lambda: op.forward(K.Rec(xr), wt, b, 0.01, h, w, want_stats=True))
+    gz = torch.randn(n, cout, h, w, device=dev); gzr = K.rec_from_nchw(gz)
+    t_dg = t(lambda: op.dgrad(gz, wt, h, w)); t_dgr = t(lambda: op.dgrad(K.Rec(gzr), wt, h, w))
+    print("%-8s igemm_pipe forward: NCHW source %7.3f ms | record source %7.3f ms (%.2fx);  dgrad: %7.3f | %7.3f ms (%.2fx)"
+          % (name, t_old * 1e3, t_xr * 1e3, t_xr / t_old, t_dg * 1e3, t_dgr * 1e3, t_dgr / t_dg), flush=True)
     if os.environ.get("PCUDA_RC_DBG") == "1":
         import ctypes
         buf = (ctypes.c_ulonglong * 12)()
