@@ -1104,7 +1104,12 @@ static int launch_pipe_s(const IgemmParams& p, const IgemmPlan& pl, hipStream_t 
 
 template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ>
 static int launch_pipe_t(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
-  if constexpr (X3 && !XQ && !CLAMP && NPB == 2 && PF <= 2) {   // (the record-staging instantiations: the aligned 3x3 plans)
+#ifdef PCUDA_XR_ALL   // (make XFLAGS=-DPCUDA_XR_ALL: every unclamped plan, for the stride-2 cases of scripts/micro/rconv_micro.py)
+  constexpr bool xr_inst = X3 && !XQ && !CLAMP;
+#else
+  constexpr bool xr_inst = X3 && !XQ && !CLAMP && NPB == 2 && PF <= 2;   // the aligned 3x3 plans
+#endif
+  if constexpr (xr_inst) {   // (the record-staging instantiations)
     if (p.xr) {   // record sources (pcuda_src::rec)
       if (pl.te) {
         if (p.stats && p.red_a) return launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, false, 2, true, true>(p, pl, s);

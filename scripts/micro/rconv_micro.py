@@ -12,7 +12,23 @@ def t(fn, reps=20):
     fn(); fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(reps): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps
-for name in (sys.argv[1:] or list(CASES)):
+# stride-2 4x4 layers of the discriminators (GAN.py:97-105) through the production kernel: NCHW source against record source
+DCASES = {"d2": (32, 64, 128, 129), "d3": (32, 128, 256, 65), "d4": (32, 256, 512, 33)}
+for name in [a for a in sys.argv[1:] if a in DCASES]:
+    n, cin, cout, hw = DCASES[name]
+    op = K.ConvOp(cin, cout, 4, stride=2, pad=2)
+    x = torch.randn(n, cin, hw, hw, device=dev); wt = torch.randn(cout, cin, 4, 4, device=dev) * 0.05
+    oh, ow = op.out_hw(hw, hw)
+    gz = torch.randn(n, cout, oh, ow, device=dev)
+    xr, gzr = K.rec_from_nchw(x), K.rec_from_nchw(gz)
+    fl = 2.0 * n * oh * ow * cout * cin * 16
+    tf0 = t(lambda: op.forward(x, wt, None, 0.2, hw, hw)); tf1 = t(lambda: op.forward(K.Rec(xr), wt, None, 0.2, hw, hw))
+    td0 = t(lambda: op.dgrad(gz, wt, hw, hw)); td1 = t(lambda: op.dgrad(K.Rec(gzr), wt, hw, hw))
+    y0, _, _ = op.forward(x, wt, None, 0.2, hw, hw); y1, _, _ = op.forward(K.Rec(xr), wt, None, 0.2, hw, hw)
+    e = float((y0 - y1).abs().max() / y0.abs().max())
+    print("%-4s forward: NCHW source %7.3f ms %6.1f TF | record source %7.3f ms %6.1f TF (%.2fx; max diff %.1e);  dgrad: %7.3f | %7.3f ms (%.2fx)"
+          % (name, tf0 * 1e3, fl / tf0 / 1e12, tf1 * 1e3, fl / tf1 / 1e12, tf1 / tf0, e, td0 * 1e3, td1 * 1e3, td1 / td0), flush=True)
+for name in ([a for a in sys.argv[1:] if a not in DCASES] or ([] if sys.argv[1:] else list(CASES))):
     n, cin, cout, h, w = CASES[name]
     x = torch.randn(n, cin, h, w, device=dev); wt = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
     b = torch.randn(cout, device=dev) * 0.1
