@@ -154,6 +154,14 @@ int pcuda_conv2d_dgrad_tiles(const pcuda_conv_geom* g, int prec);
 int pcuda_conv2d_dgrad_bnred(const pcuda_conv_geom* g, int prec, const pcuda_src* dy, const void* packed_w_dgrad,
                              const pcuda_dst* dx, int accumulate, const float* a, long long a_sn, long long a_sc,
                              const float* mean, const float* invstd, float* red_partials, pcuda_stream_t s);
+/* The data gradient of a layer behind the nearest-x2 fold (g->in_up: the decoder's up-convolutions, unet.py:111-112) written at
+ * the STORED, half resolution: dx_half[n][cin][in_h/2][in_w/2] = the 2x2 block sums of the logical gradient (what
+ * pcuda_upsample2_bwd computes from pcuda_conv2d_dgrad's output, without that 4x larger tensor going through HBM).  a != NULL:
+ * the BatchNorm-backward reduce of the layer that produced the stored tensor rides along as in pcuda_conv2d_dgrad_bnred
+ * (red_partials[pcuda_conv2d_dgrad_tiles()][cin][2]).  PCUDA_E_UNSUPPORTED for plans off the 32 x 8-tile transposed epilogue. */
+int pcuda_conv2d_dgrad_fold(const pcuda_conv_geom* g, int prec, const pcuda_src* dy, const void* packed_w_dgrad,
+                            const pcuda_dst* dx_half, const float* a, long long a_sn, long long a_sc, const float* mean,
+                            const float* invstd, float* red_partials, pcuda_stream_t s);
 /* dw (+)= sum over batch and space of dy (x) x ; db (+)= sum dy (db may be NULL).
  * workspace: pcuda_conv2d_wgrad_workspace_size() bytes. */
 size_t pcuda_conv2d_wgrad_workspace_size(const pcuda_conv_geom* g);

@@ -56,6 +56,8 @@ struct IgemmParams {
   unsigned long long* dbg_clk;   // PCUDA_DBG bit 128: 8 per-phase cycle sums
   int xq;                  // 1: quad (float4) input staging (in_w % 4 == 0, no upsampling fold)
   int xr;                  // 1: record input staging (pcuda_src::rec: the sources are record tensors; bf16x3 only)
+  int fold;                // 1: the epilogue sums 2x2 blocks of the logical output (the data gradient of a nearest-x2-folded
+                           // input, unet.py:111): y is the half-resolution tensor, out_w its row length
   // paired column classes of a stride-2 data gradient (dword-store epilogues): row 2c + rx of the launch is channel c,
   // column parity rx -- one wave stores both halves of every 8 bytes of a destination line back to back.  lw = columns
   // of the even class, lw2 = of the odd one; ox_off = 0, ox_mul = 2.

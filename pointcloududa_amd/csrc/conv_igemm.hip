@@ -386,8 +386,12 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
       // X / W slabs and must end in front of the tap table behind them
     static int note = -1;
     if (note < 0) { const char* e = getenv("PCUDA_NOTE"); note = e ? atoi(e) : 0; }
+    // (2x2 fold: y is the half-resolution tensor, stored 8 bytes at a time: even rows, 8-byte aligned planes)
+    const bool fold_ok = p.fold && p.ox_mul == 1 && p.ox_off == 0 && !(pl.tw & 3) && !(p.lw & 3) && !(p.out_w & 1) &&
+                         !((uintptr_t)p.y.p1 & 7) && !(p.y.sc1 & 1) && !(p.y.sn1 & 1) &&
+                         (p.y.c1 >= p.cout || (!((uintptr_t)p.y.p2 & 7) && !(p.y.sc2 & 1) && !(p.y.sn2 & 1)));
     pl.te = (pipe && !pl.w8 && !note &&
-             te_dst_ok(&p.y, p.cout, p.out_w, p.lw, pl.tw, p.ox_mul, p.ox_off)) ? 1 : 0;
+             (p.fold ? fold_ok : te_dst_ok(&p.y, p.cout, p.out_w, p.lw, pl.tw, p.ox_mul, p.ox_off))) ? 1 : 0;
     if (pl.te) {
       const size_t rec = ig_rec_bytes(x3), wtap = (size_t)co_tile * rec;
       const size_t need = (size_t)16384 * pl.npb + (size_t)co_tile * 32;
@@ -399,6 +403,8 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
       }
     }
   }
+  if (p.fold && !(pipe && pl.te && !pl.w8 && pl.npb == 2 && pl.tw == 32 && pl.th == 8 && !pl.clamp && !p.xr && !p.accumulate && !p.pair))
+    PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv2d_dgrad_fold: this geometry does not run on the 32 x 8-tile transposed-epilogue kernel");
   if (p.xr && !pipe) PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "igemm: record sources need the pipelined kernel for this geometry");
   if (p.red_a && !(pipe && pl.te))
     PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv2d_dgrad_bnred: this geometry does not run on the transposed-epilogue kernel");
@@ -650,6 +656,43 @@ extern "C" int pcuda_conv2d_dgrad_bnred(const pcuda_conv_geom* g, int prec, cons
   p.bias = nullptr; p.slope = 1.f; p.accumulate = accumulate;
   p.stats = red_partials;
   p.red_a = a; p.red_sn = a_sn; p.red_sc = a_sc; p.red_mean = mean; p.red_invstd = invstd;
+  p.n = g->n;
+  return launch_igemm(p, prec, t, (hipStream_t)s);
+}
+
+// ------------------------------------------------------------------------------------------
+// dgrad of a layer whose input was read through the nearest-x2 fold (g->in_up), written at the STORED (half) resolution:
+// the 2x2 sum that upsample2_bwd_kernel applied to the logical gradient happens in the epilogue.  a != NULL: the
+// BatchNorm-backward reduce of the layer that produced the stored tensor rides along (red_partials[tiles][cin][2], tiles =
+// pcuda_conv2d_dgrad_tiles).  PCUDA_E_UNSUPPORTED where the plan is not the 32 x 8-tile transposed-epilogue one (the caller
+// then runs pcuda_conv2d_dgrad + pcuda_upsample2_bwd).
+// ------------------------------------------------------------------------------------------
+extern "C" int pcuda_conv2d_dgrad_fold(const pcuda_conv_geom* g, int prec, const pcuda_src* dy, const void* packed_w_dgrad,
+                                       const pcuda_dst* dx_half, const float* a, long long a_sn, long long a_sc,
+                                       const float* mean, const float* invstd, float* red_partials, pcuda_stream_t s) {
+  if (!geom_ok(g)) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_dgrad_fold: inconsistent geometry");
+  if (!src_ok(dy, g->cout) || !dst_ok(dx_half, g->cin) || !packed_w_dgrad) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_dgrad_fold: bad tensors");
+  if (prec != PCUDA_PREC_BF16X3 && prec != PCUDA_PREC_BF16) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_dgrad_fold: bad precision");
+  if (a && (!mean || !invstd || !red_partials)) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_dgrad_fold: reduce operands missing");
+  if (!g->in_up || g->stride != 1 || (g->in_h & 1) || (g->in_w & 3) || direct_dgrad_tiles(g) ||
+      (a && ((((uintptr_t)a) & 7) || (a_sn & 1) || (a_sc & 1))))
+    PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv2d_dgrad_fold: stride-1 MFMA layers behind a nearest-x2 fold, rows of 4k logical pixels");
+  TapSet t = dgrad_taps(g, 0, 0);
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = *dy; p.cin = g->cout;
+  p.in_h = g->out_h; p.in_w = g->out_w; p.in_shift = 0; p.in_row = g->out_w;
+  p.y = *dx_half; p.cout = g->cin; p.out_w = g->in_w >> 1;
+  p.lh = g->in_h; p.lw = g->in_w;
+  p.oy_mul = p.ox_mul = 1; p.oy_off = p.ox_off = 0;
+  p.in_step = 1;
+  p.wpack = (const uint16_t*)packed_w_dgrad; p.w_lo_off = 0;
+  p.bias = nullptr; p.slope = 1.f; p.accumulate = 0;
+  p.fold = 1;
+  if (a) {
+    p.stats = red_partials;
+    p.red_a = a; p.red_sn = a_sn; p.red_sc = a_sc; p.red_mean = mean; p.red_invstd = invstd;
+  }
   p.n = g->n;
   return launch_igemm(p, prec, t, (hipStream_t)s);
 }

@@ -298,9 +298,10 @@ __device__ __forceinline__ TileGeom tile_decode(const IgemmParams& p, int L) {
 // inside its MFMA phase.
 // STATS: 0 none, 1 BatchNorm partial sums of the stored values (forward), 2 BatchNorm-BACKWARD reduce partials of the
 // stored gradient against the saved activation (dgrad of a block's second convolution; transposed epilogue only)
-template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ, int STATS, bool TE, bool XR = false>
+template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ, int STATS, bool TE, bool XR = false, bool FOLD = false>
 __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const IgemmParams p, const int x_cap, const int total) {
   static_assert(!XR || (X3 && !XQ), "record staging: bf16x3 records, instead of the quad path");
+  static_assert(!FOLD || (TE && NPB == 2 && STATS != 1), "2x2 fold: transposed-epilogue plans with two pixel blocks (tile rows 2 w, 2 w + 1)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CO_TILE = 32 * CO_BLKS;
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -567,7 +568,77 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
         if (STATS == 2) { smean[tid] = mean_r; sinv[tid] = inv_r; }
       }
       __syncthreads();   // sbias visible; sred aliases the X tile: every wave's last fragment reads are done
-      if constexpr (TE) {
+      if constexpr (FOLD) {
+        // 2x2 fold (the data gradient of a layer whose input was read through nearest x2, unet.py:111-112: the gradient of the
+        // STORED half-resolution tensor is the sum over each 2x2 block of the logical one).  Tiles are 32 pixels wide, so a
+        // wave's two pixel blocks are the tile rows 2 w and 2 w + 1: the vertical pair is one add per accumulator register;
+        // the row of sums goes through the wave's LDS scratch ([32 channels][32 pixels]) so that a lane holds 4 consecutive
+        // pixels of one channel, whose two horizontal pairs it stores as 8 bytes.  The 4x larger logical gradient never
+        // reaches HBM (it was written by this kernel and read back by upsample2_bwd_kernel: 1 GB per pass at 256x256), and
+        // with STATS == 2 the BatchNorm-backward reduce of the layer in front rides along as in the unfolded epilogue.
+        float* const tsc = (float*)smem + w * (32 * 32);
+        float* const sred2 = (float*)smem + 4 * 32 * 32;
+        const int q = lane & 7, cs = lane >> 3;
+        const int ly = g.y0 + 2 * w, lx = g.x0 + 4 * q;
+        const bool pokq = (2 * w < p.th) & (ly + 1 < p.lh) & (lx + 3 < p.lw);
+        const unsigned pixq = (unsigned)((ly >> 1) * p.out_w + (lx >> 1)) * 4u;
+        const int c1 = min(p.y.c1, p.cout);
+        char* const yb1 = (char*)(p.y.p1 + (long long)g.n * p.y.sn1);
+        char* const yb2 = (char*)(p.y.p2 + (long long)g.n * p.y.sn2);
+        const unsigned pl1 = (unsigned)p.y.sc1 * 4u, pl2 = (unsigned)p.y.sc2 * 4u;
+#pragma unroll
+        for (int cb = 0; cb < CO_BLKS; ++cb) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            tsc[((i & 3) + 8 * (i >> 2) + 4 * h) * 32 + r] = acc[cb][0][i] + acc[cb][1][i];
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const f32x4 v = *(const f32x4*)(tsc + (it * 8 + cs) * 32 + 4 * q);
+            const float o0 = v[0] + v[1], o1 = v[2] + v[3];
+            const int cu = co0 + cb * 32 + it * 8;                     // uniform; the 8 channels lie in one destination
+            const bool first = cu < c1;
+            char* const base = first ? yb1 + (long long)cu * pl1 : yb2 + (long long)(cu - c1) * pl2;
+            char* const dptr = base + (size_t)((unsigned)cs * (first ? pl1 : pl2) + pixq);
+            const bool ok = pokq & (cu + cs < p.cout);
+            float a0 = 0.f, a1 = 0.f;
+            if (STATS == 2 && ok) {
+              const float2 av = *(const float2*)((const char*)(p.red_a + (long long)g.n * p.red_sn) + ((long long)(cu + cs) * p.red_sc) * 4 + pixq);
+              a0 = av.x; a1 = av.y;
+            }
+            if (ok) *(float2*)dptr = make_float2(o0, o1);
+            if (STATS == 2) {
+              const int rr = cb * 32 + it * 8 + cs;
+              const float m = smean[rr], is = sinv[rr];
+              float s1 = ok ? o0 + o1 : 0.f;
+              float s2 = ok ? o0 * ((a0 - m) * is) + o1 * ((a1 - m) * is) : 0.f;
+              s1 = row_sum<8>(s1);
+              s2 = row_sum<8>(s2);
+              if (q == 0) {
+                sred2[(w * CO_TILE + rr) * 2 + 0] = s1;
+                sred2[(w * CO_TILE + rr) * 2 + 1] = s2;
+              }
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        if (STATS == 2) {
+          __syncthreads();
+          if (tid < CO_TILE) {
+            const int co = g.cot * CO_TILE + tid;
+            if (co < p.cout) {
+              float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+              for (int ww = 0; ww < 4; ++ww) {
+                s1 += sred2[(ww * CO_TILE + tid) * 2 + 0];
+                s2 += sred2[(ww * CO_TILE + tid) * 2 + 1];
+              }
+              p.stats[((long long)g.pt * p.cout + co) * 2 + 0] = s1;
+              p.stats[((long long)g.pt * p.cout + co) * 2 + 1] = s2;
+            }
+          }
+        }
+      } else if constexpr (TE) {
         // Transposed epilogue (rows of 4k pixels, unit x stride): every wave turns its [32 rows][WPIX pixels]
         // accumulator block through its own LDS scratch so that a lane holds 4 consecutive pixels of one channel:
         // one 16-byte store per lane, a wave instruction writes whole 128-B row segments of CPI channels
@@ -1066,15 +1137,15 @@ static int launch_igemm_c(const IgemmParams& p, const IgemmPlan& pl, hipStream_t
                      : launch_igemm_t<X3, CO_BLKS, false, 1>(p, pl.x_cap, pl.lds, s);
 }
 
-template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ, int STATS, bool TE, bool XR = false>
+template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ, int STATS, bool TE, bool XR = false, bool FOLD = false>
 static int launch_pipe_s(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
-  constexpr unsigned vkey = pipe_key(X3, CO_BLKS, CLAMP, NPB, PF, XQ, STATS, TE) | (XR ? 1u << 10 : 0u);
+  constexpr unsigned vkey = pipe_key(X3, CO_BLKS, CLAMP, NPB, PF, XQ, STATS, TE) | (XR ? 1u << 10 : 0u) | (FOLD ? 1u << 11 : 0u);
   variant_log("pipe", vkey);
   if constexpr (!pipe_built(vkey)) {
     variant_fallback_note("igemm_pipe_kernel", vkey);
     return PCUDA_E_NOTBUILT;
   } else {
-  auto kern = igemm_pipe_kernel<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, STATS, TE, XR>;
+  auto kern = igemm_pipe_kernel<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, STATS, TE, XR, FOLD>;
   static DeviceOnce lds_opt;
   if (const unsigned long long devbit = pl.lds > 32 * 1024 ? lds_opt.pending() : 0ull) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HARD);
@@ -1121,6 +1192,13 @@ static int launch_pipe_t(const IgemmParams& p, const IgemmPlan& pl, hipStream_t 
                      : launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, false, 0, false, true>(p, pl, s);
     }
   }
+  if constexpr (NPB == 2 && !CLAMP) {
+    if (p.fold) {   // 2x2-folding epilogue (pcuda_conv2d_dgrad_fold): the caller checked the plan (transposed epilogue, 32 x 8 tiles)
+      return (p.stats && p.red_a) ? launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, 2, true, false, true>(p, pl, s)
+                                  : launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, 0, true, false, true>(p, pl, s);
+    }
+  }
+  if (p.fold) PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "igemm: no 2x2-fold instantiation for this plan");
   if (p.xr) PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "igemm: no record-staging instantiation for this plan (clamp %d, %d pixel blocks, %d slots)", (int)CLAMP, NPB, PF);
   if (pl.te) {
     if (p.stats && p.red_a) return launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, 2, true>(p, pl, s);

@@ -138,6 +138,13 @@ def make_dst(a: torch.Tensor, b: Optional[torch.Tensor] = None) -> Dst:
 # PCUDA_BNRED=0: the BatchNorm-backward reduce of a block's first BatchNorm as its own kernel instead of riding in the
 # epilogue of the second convolution's dgrad (A/B switch)
 _fuse_bnred = os.environ.get("PCUDA_BNRED", "1") != "0"
+# PCUDA_FOLD_DGRAD=0: the 2x2 fold behind an up-convolution's data gradient as its own kernel (upsample2_bwd) again (A/B switch)
+_fold_dgrad = os.environ.get("PCUDA_FOLD_DGRAD", "1") != "0"
+
+
+def upsample_red_only(dx, bnred):
+    """(dx, None): the caller computes the BatchNorm-backward reduce of ``dx`` itself (bn_backward without ``red``)"""
+    return dx, None
 
 
 _conv_ops = weakref.WeakSet()      # every ConvOp alive (repack_owner finds a network's layers through their ``owner``)
@@ -249,6 +256,39 @@ class ConvOp:
         check(L.lib().pcuda_conv2d_dgrad(C.byref(g), _precision, C.byref(src), pk.data_ptr(), C.byref(dst),
                                          1 if accumulate else 0, _stream()), "conv2d_dgrad")
         return dx
+
+    def dgrad_fold(self, dy, w, in_h, in_w, bnred=None):
+        """The data gradient of an ``in_up`` layer at the STORED (half) resolution: dgrad + the 2x2 fold of the nearest-x2
+        backward in one kernel (pcuda_conv2d_dgrad_fold); ``bnred=(a, BNState)`` as in ``dgrad``.  Returns (dx_half, (partials,
+        ntiles) | None) like ``upsample2_bwd(dgrad(...), bnred)``, which it falls back to where the plan does not fold."""
+        assert self.in_up
+        n = dy.shape[0]
+        g = self.geom(n, in_h, in_w)
+        lib = L.lib()
+        if _fold_dgrad and in_h % 2 == 0 and in_w % 4 == 0:
+            pk = self._packed("dgrad", w, g)
+            dx = torch.empty((n, self.cin, in_h // 2, in_w // 2), dtype=torch.float32, device=dy.device)
+            src, dst = make_src(dy), make_dst(dx)
+            a_p = m_p = i_p = r_p = None
+            asn = asc = 0
+            red, nt = None, 0
+            if bnred is not None and _fuse_bnred:
+                a, st = bnred
+                nt = lib.pcuda_conv2d_dgrad_tiles(C.byref(g), _precision)
+                if nt > 0:
+                    _, _, _, asn, asc = _planes(a)
+                    red = torch.empty((nt, self.cin, 2), dtype=torch.float32, device=dy.device)
+                    a_p, m_p, i_p, r_p = a.data_ptr(), st.mean.data_ptr(), st.invstd.data_ptr(), red.data_ptr()
+            rc = lib.pcuda_conv2d_dgrad_fold(C.byref(g), _precision, C.byref(src), pk.data_ptr(), C.byref(dst), a_p, asn, asc,
+                                             m_p, i_p, r_p, _stream())
+            if rc == 0:
+                if bnred is None:
+                    return dx
+                return (dx, (red, nt)) if red is not None else upsample_red_only(dx, bnred)
+            if rc != L.PCUDA_E_UNSUPPORTED:
+                check(rc, "conv2d_dgrad_fold")
+        d_up = self.dgrad(dy, w, in_h, in_w)
+        return upsample2_bwd(d_up, bnred=bnred)
 
     def wgrad(self, x, dy, dw, db, in_h, in_w, x2=None, accumulate=True):
         xa = _as_ta(x)

@@ -229,11 +229,12 @@ class _SegEngine:
                 up = "decoder.decoder1_%d.1" % (i + 1)
                 if G(up + ".weight") is not None:
                     self.ops[up].wgrad(S[up], d_u, G(up + ".weight"), G(up + ".bias"), oh, ow)
-                d_up = self.ops[up].dgrad(d_u, P[up + ".weight"], oh, ow)
+                # the up-convolution's data gradient at the STORED resolution: the 2x2 fold of the nearest-x2 backward (and the
+                # next block's BatchNorm-backward reduce) ride in the dgrad kernel's epilogue where the plan allows
                 if i + 1 < nb and self.bn:
-                    d_cur, red = K.upsample2_bwd(d_up, bnred=bn_of(i + 1))
+                    d_cur, red = self.ops[up].dgrad_fold(d_u, P[up + ".weight"], oh, ow, bnred=bn_of(i + 1))
                 else:
-                    d_cur, red = K.upsample2_bwd(d_up), None
+                    d_cur, red = self.ops[up].dgrad_fold(d_u, P[up + ".weight"], oh, ow), None
             d_bsum = d_cur
         h, w = H >> nb, W >> nb
         if self.feature_dis and d_out2 is not None:

@@ -354,3 +354,39 @@ def test_pruned_build_falls_back_to_the_generic_kernels(dev):
     op.wgrad(x.to(dev), gz.to(dev), dw, None, h, w_, accumulate=False)
     assert rel_err(y, z) < 1e-4 and rel_err(dx, xr.grad) < 1e-4 and rel_err(dw, wr.grad) < 1e-4
     print("fallback launches for this geometry:", lib.pcuda_fallback_count() - before)
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("n,cin,cout,h,w", [(8, 64, 32, 128, 128), (4, 128, 64, 64, 96), (3, 256, 128, 32, 64), (2, 16, 8, 20, 24)])
+def test_dgrad_with_the_2x2_fold_in_its_epilogue(dev, prec, n, cin, cout, h, w):
+    """The data gradient of an up-convolution (nearest x2 folded into the forward's addressing, unet.py:111-112) written at
+    the stored resolution -- dgrad + upsample2_bwd in one kernel -- against the two-kernel form and the CPU reference, with
+    and without the BatchNorm-backward reduce riding along; the last geometry has no folding plan (fallback)."""
+    from pointcloududa_amd import kernels as K
+    K.set_precision(prec)
+    try:
+        rng = np.random.default_rng(cin + h)
+        wt = torch.from_numpy(rng.normal(0, 0.1, (cout, cin, 3, 3)).astype(np.float32))
+        gz = torch.from_numpy(rng.normal(0, 1, (n, cout, h, w)).astype(np.float32))
+        x = torch.zeros(n, cin, h // 2, w // 2, requires_grad=True)
+        F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), wt, None, padding=1).backward(gz)
+        op = K.ConvOp(cin, cout, 3, pad=1, in_up=True)
+        got = op.dgrad_fold(gz.to(dev), wt.to(dev), h, w)
+        two = K.upsample2_bwd(op.dgrad(gz.to(dev), wt.to(dev), h, w))
+        assert rel_err(got, x.grad) < TOL[prec] and rel_err(got, two) < 1e-5
+        # with the reduce: partial sums of (g, g * a_hat) over the folded gradient
+        a = torch.from_numpy(rng.normal(0, 1, (n, cin, h // 2, w // 2)).astype(np.float32)).to(dev)
+        st = K.BNState()
+        st.mean = torch.from_numpy(rng.normal(0, 0.3, (cin,)).astype(np.float32)).to(dev)
+        st.invstd = torch.from_numpy(rng.uniform(0.5, 2.0, (cin,)).astype(np.float32)).to(dev)
+        got2, red = op.dgrad_fold(gz.to(dev), wt.to(dev), h, w, bnred=(a, st))
+        assert torch.equal(got2, got)
+        gd = got.double()
+        want1 = gd.sum((0, 2, 3))
+        want2 = (gd * ((a.double() - st.mean.double()[None, :, None, None]) * st.invstd.double()[None, :, None, None])).sum((0, 2, 3))
+        if red is not None:
+            part, nt = red
+            tot = part[:nt].double().sum(0)
+            assert rel_err(tot[:, 0], want1) < 1e-4 and rel_err(tot[:, 1], want2) < 1e-4
+    finally:
+        K.set_precision("bf16x3")
