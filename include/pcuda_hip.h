@@ -244,6 +244,25 @@ int pcuda_maxpool2_fwd(const float* x, long long x_sn, long long x_sc, const flo
 int pcuda_maxpool2_bwd(const float* dy, long long dy_sn, long long dy_sc, const float* dy2, long long dy2_sn,
                        long long dy2_sc, const uint8_t* idx, float* dx, long long dx_sn, long long dx_sc,
                        int accumulate, int n, int c, int h, int w, pcuda_stream_t s);
+/* The backward kernels behind a max-pool, with the pool's scatter read IN PLACE (round 4): the gradient of element (y, x) is
+ * g[y/2][x/2] (+ g2) where idx[y/2][x/2] == 2 (y & 1) + (x & 1), else 0 -- what pcuda_maxpool2_bwd would have written into a
+ * 4x larger tensor for these kernels to read back (unet.py:48 going back into :27-36 / the residual convolution).  `dy` is an
+ * optional full-resolution addend (the skip connection's gradient); results equal the two-kernel form bit for bit. */
+typedef struct pcuda_pooled {
+  const float* g; long long g_sn, g_sc;     /* gradient at the pooled resolution [n][c][h/2][w/2] (strided planes) */
+  const float* g2; long long g2_sn, g2_sc;  /* optional second share, summed (NULL: none) */
+  const uint8_t* idx;                       /* dense [n][c][h/2][w/2], from pcuda_maxpool2_fwd */
+  int h, w;                                 /* the FULL-resolution plane, both even */
+} pcuda_pooled;
+int pcuda_bn_bwd_reduce_pooled(const pcuda_pooled* pool, const float* dy, long long dy_sn, long long dy_sc, const float* a,
+                               long long a_sn, long long a_sc, const float* mean, const float* invstd, int n, int c,
+                               float* red, int* ntiles, pcuda_stream_t s);
+int pcuda_bn_bwd_apply_pooled(const pcuda_pooled* pool, const float* dy, long long dy_sn, long long dy_sc, const float* a,
+                              long long a_sn, long long a_sc, const float* coef, float act_slope, float* dz, long long dz_sn,
+                              long long dz_sc, int n, int c, pcuda_stream_t s);
+int pcuda_lrelu_bwd_pooled(const pcuda_pooled* pool, const float* dy, long long dy_sn, long long dy_sc, const float* a,
+                           long long a_sn, long long a_sc, float slope, float* dz, long long dz_sn, long long dz_sc, int n,
+                           int c, pcuda_stream_t s);
 /* dx[h][w] (+)= sum of the 2x2 block of dy[2h][2w] (nearest-upsample backward) */
 int pcuda_upsample2_bwd(const float* dy, long long dy_sn, long long dy_sc, float* dx, long long dx_sn,
                         long long dx_sc, int accumulate, int n, int c, int h, int w, pcuda_stream_t s);

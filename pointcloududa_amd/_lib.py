@@ -40,6 +40,11 @@ class Dst(C.Structure):
     _fields_ = [("p1", vp), ("sn1", i64), ("sc1", i64), ("p2", vp), ("sn2", i64), ("sc2", i64), ("c1", i32), ("rec", i32)]
 
 
+class Pooled(C.Structure):
+    _fields_ = [("g", vp), ("g_sn", i64), ("g_sc", i64), ("g2", vp), ("g2_sn", i64), ("g2_sc", i64), ("idx", vp),
+                ("h", i32), ("w", i32)]
+
+
 _PROTOS = {
     "pcuda_version": (i32, []),
     "pcuda_device_count": (i32, []),
@@ -92,6 +97,9 @@ _PROTOS = {
     "pcuda_channel_sum": (i32, [vp, i64, i64, i32, i32, i64, vp, i32, vp, sz, vp]),
     "pcuda_maxpool2_fwd": (i32, [vp, i64, i64, vp, vp, vp, i64, i64, vp, i32, i32, i32, i32, vp]),
     "pcuda_maxpool2_bwd": (i32, [vp, i64, i64, vp, i64, i64, vp, vp, i64, i64, i32, i32, i32, i32, i32, vp]),
+    "pcuda_bn_bwd_reduce_pooled": (i32, [C.POINTER(Pooled), vp, i64, i64, vp, i64, i64, vp, vp, i32, i32, vp, C.POINTER(i32), vp]),
+    "pcuda_bn_bwd_apply_pooled": (i32, [C.POINTER(Pooled), vp, i64, i64, vp, i64, i64, vp, f32, vp, i64, i64, i32, i32, vp]),
+    "pcuda_lrelu_bwd_pooled": (i32, [C.POINTER(Pooled), vp, i64, i64, vp, i64, i64, f32, vp, i64, i64, i32, i32, vp]),
     "pcuda_upsample2_bwd": (i32, [vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, i32, vp]),
     "pcuda_upsample2_bwd_bnred": (i32, [vp, i64, i64, vp, i64, i64, i32, vp, i64, i64, vp, vp, vp, C.POINTER(i32), i32, i32,
                                         i32, i32, vp]),

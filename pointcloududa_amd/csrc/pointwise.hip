@@ -139,15 +139,51 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------- backward
+// "Pooled" gradient source: the incoming gradient (or a share of it) is the scatter of a 2x2 max-pool's backward -- g (+ g2)
+// at the pooled resolution and the argmax index the forward kept (unet.py:48) -- read IN PLACE: element (y, x) of the plane
+// gets g[y/2][x/2] if idx[y/2][x/2] == 2 (y & 1) + (x & 1), else 0.  The kernels below then never see the 4x larger, three
+// quarters zero tensor that maxpool2_bwd_kernel wrote and they read back (round 4).
+struct PoolSrc {
+  const float* g; long long sn, sc;
+  const float* g2; long long sn2, sc2;
+  const uint8_t* idx;
+  int w, c;      // full-resolution row length (even; a multiple of 4 on the vector path); channels
+  long long ohw; // pooled plane size (idx is dense [n][c][h/2][w/2])
+};
 template <int VEC>
+__device__ __forceinline__ void pool_load(const PoolSrc& ps, int n, int ch, long long i, float (&out)[VEC]) {
+  const int w = ps.w, ow = w >> 1;
+  const int y = (int)(i / w), x = (int)(i - (long long)y * w);
+  const long long o = (long long)(y >> 1) * ow + (x >> 1);
+  const float* pg = ps.g + n * ps.sn + ch * ps.sc + o;
+  const float* pg2 = ps.g2 ? ps.g2 + n * ps.sn2 + ch * ps.sc2 + o : nullptr;
+  const uint8_t* pi = ps.idx + ((long long)n * ps.c + ch) * ps.ohw + o;
+  const int krow = (y & 1) * 2;
+  if (VEC == 4) {
+    float2 gv = *(const float2*)pg;
+    if (pg2) { const float2 t = *(const float2*)pg2; gv.x += t.x; gv.y += t.y; }
+    const unsigned short kk = *(const unsigned short*)pi;
+    const int k0 = kk & 0xff, k1 = kk >> 8;
+    out[0] = k0 == krow ? gv.x : 0.f;
+    out[1] = k0 == krow + 1 ? gv.x : 0.f;
+    out[2] = k1 == krow ? gv.y : 0.f;
+    out[3] = k1 == krow + 1 ? gv.y : 0.f;
+  } else {
+    float gv = *pg;
+    if (pg2) gv += *pg2;
+    out[0] = (int)*pi == krow + (x & 1) ? gv : 0.f;
+  }
+}
+
+template <int VEC, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float* __restrict__ dy, long long dy_sn, long long dy_sc, const float* __restrict__ dy2, long long dy2_sn,
     long long dy2_sc, const float* __restrict__ a, long long a_sn, long long a_sc, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ scale, const float* __restrict__ shift, int post_relu,
-    long long hw, int c, float* __restrict__ red) {
+    long long hw, int c, float* __restrict__ red, PoolSrc ps) {
   __shared__ float sh[4];
   const int ch = blockIdx.y, n = blockIdx.z;
-  const float* pd = dy + n * dy_sn + ch * dy_sc;
+  const float* pd = dy ? dy + n * dy_sn + ch * dy_sc : nullptr;     // (POOL: the full-resolution share is optional)
   const float* pd2 = dy2 ? dy2 + n * dy2_sn + ch * dy2_sc : nullptr;
   const float* pa = a + n * a_sn + ch * a_sc;
   const float m = mean[ch], is = invstd[ch];
@@ -157,7 +193,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
   for (long long i = i0 + threadIdx.x * VEC; i < i1; i += 256 * VEC) {
     float av[VEC], g[VEC], g2[VEC];
     vload<VEC>(pa + i, av);
-    vload<VEC>(pd + i, g);
+    if (POOL) {
+      pool_load<VEC>(ps, n, ch, i, g);
+      if (pd) {
+        vload<VEC>(pd + i, g2);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) g[e] += g2[e];
+      }
+    } else {
+      vload<VEC>(pd + i, g);
+    }
     if (pd2) vload<VEC>(pd2 + i, g2);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
@@ -209,14 +254,14 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   }
 }
 
-template <int VEC>
+template <int VEC, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ dy, long long dy_sn, long long dy_sc, const float* __restrict__ dy2, long long dy2_sn,
     long long dy2_sc, const float* __restrict__ a, long long a_sn, long long a_sc, const float* __restrict__ coef,
     const float* __restrict__ scale, const float* __restrict__ shift, int post_relu, float act_slope,
-    float* __restrict__ dz, long long dz_sn, long long dz_sc, long long hw) {
+    float* __restrict__ dz, long long dz_sn, long long dz_sc, long long hw, PoolSrc ps) {
   const int ch = blockIdx.y, n = blockIdx.z;
-  const float* pd = dy + n * dy_sn + ch * dy_sc;
+  const float* pd = dy ? dy + n * dy_sn + ch * dy_sc : nullptr;
   const float* pd2 = dy2 ? dy2 + n * dy2_sn + ch * dy2_sc : nullptr;
   const float* pa = a + n * a_sn + ch * a_sc;
   float* pz = dz + n * dz_sn + ch * dz_sc;
@@ -226,7 +271,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
   for (long long i = i0 + threadIdx.x * VEC; i < i1; i += 256 * VEC) {
     float av[VEC], g[VEC], g2[VEC], out[VEC];
     vload<VEC>(pa + i, av);
-    vload<VEC>(pd + i, g);
+    if (POOL) {
+      pool_load<VEC>(ps, n, ch, i, g);
+      if (pd) {
+        vload<VEC>(pd + i, g2);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) g[e] += g2[e];
+      }
+    } else {
+      vload<VEC>(pd + i, g);
+    }
     if (pd2) vload<VEC>(pd2 + i, g2);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
@@ -242,14 +296,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
   }
 }
 
-template <int VEC>
+template <int VEC, bool POOL = false>
 __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* __restrict__ dy, long long dy_sn, long long dy_sc,
                                                         const float* __restrict__ dy2, long long dy2_sn,
                                                         long long dy2_sc, const float* __restrict__ a, long long a_sn,
                                                         long long a_sc, float slope, float* __restrict__ dz,
-                                                        long long dz_sn, long long dz_sc, long long hw) {
+                                                        long long dz_sn, long long dz_sc, long long hw, PoolSrc ps) {
   const int ch = blockIdx.y, n = blockIdx.z;
-  const float* pd = dy + n * dy_sn + ch * dy_sc;
+  const float* pd = dy ? dy + n * dy_sn + ch * dy_sc : nullptr;
   const float* pd2 = dy2 ? dy2 + n * dy2_sn + ch * dy2_sc : nullptr;
   const float* pa = a + n * a_sn + ch * a_sc;
   float* pz = dz + n * dz_sn + ch * dz_sc;
@@ -257,7 +311,16 @@ __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* __restrict_
   for (long long i = i0 + threadIdx.x * VEC; i < i1; i += 256 * VEC) {
     float av[VEC], g[VEC], g2[VEC], out[VEC];
     vload<VEC>(pa + i, av);
-    vload<VEC>(pd + i, g);
+    if (POOL) {
+      pool_load<VEC>(ps, n, ch, i, g);
+      if (pd) {
+        vload<VEC>(pd + i, g2);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) g[e] += g2[e];
+      }
+    } else {
+      vload<VEC>(pd + i, g);
+    }
     if (pd2) vload<VEC>(pd2 + i, g2);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
@@ -552,10 +615,10 @@ extern "C" int pcuda_bn_bwd_reduce(const float* dy, long long dy_sn, long long d
   ProfScope prof(PCUDA_FAM_POINTWISE, (dy2 ? 12.0 : 8.0) * n * c * (double)hw, (hipStream_t)s);
   if (vec_ok(dy, dy_sn, dy_sc, hw) && vec_ok(dy2, dy2_sn, dy2_sc, hw) && vec_ok(a, a_sn, a_sc, hw))
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, dy, dy_sn, dy_sc,
-                       dy2, dy2_sn, dy2_sc, a, a_sn, a_sc, mean, invstd, scale, shift, post_relu, hw, c, red);
+                       dy2, dy2_sn, dy2_sc, a, a_sn, a_sc, mean, invstd, scale, shift, post_relu, hw, c, red, PoolSrc{});
   else
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, dy, dy_sn, dy_sc,
-                       dy2, dy2_sn, dy2_sc, a, a_sn, a_sc, mean, invstd, scale, shift, post_relu, hw, c, red);
+                       dy2, dy2_sn, dy2_sc, a, a_sn, a_sc, mean, invstd, scale, shift, post_relu, hw, c, red, PoolSrc{});
   PCUDA_CHECK_LAUNCH("bn_bwd_reduce_kernel");
   return PCUDA_OK;
 }
@@ -582,10 +645,10 @@ extern "C" int pcuda_bn_bwd_apply(const float* dy, long long dy_sn, long long dy
   if (vec_ok(dy, dy_sn, dy_sc, hw) && vec_ok(dy2, dy2_sn, dy2_sc, hw) && vec_ok(a, a_sn, a_sc, hw) &&
       vec_ok(dz, dz_sn, dz_sc, hw))
     hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, dy, dy_sn, dy_sc,
-                       dy2, dy2_sn, dy2_sc, a, a_sn, a_sc, coef, scale, shift, post_relu, act_slope, dz, dz_sn, dz_sc, hw);
+                       dy2, dy2_sn, dy2_sc, a, a_sn, a_sc, coef, scale, shift, post_relu, act_slope, dz, dz_sn, dz_sc, hw, PoolSrc{});
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, dy, dy_sn, dy_sc,
-                       dy2, dy2_sn, dy2_sc, a, a_sn, a_sc, coef, scale, shift, post_relu, act_slope, dz, dz_sn, dz_sc, hw);
+                       dy2, dy2_sn, dy2_sc, a, a_sn, a_sc, coef, scale, shift, post_relu, act_slope, dz, dz_sn, dz_sc, hw, PoolSrc{});
   PCUDA_CHECK_LAUNCH("bn_bwd_apply_kernel");
   return PCUDA_OK;
 }
@@ -605,18 +668,95 @@ extern "C" int pcuda_lrelu_bwd(const float* dy, long long dy_sn, long long dy_sc
   if ((hw & 3) && (total & 3) == 0 && dense(dy, dy_sn, dy_sc) && dense(dy2, dy2_sn, dy2_sc) && dense(a, a_sn, a_sc) &&
       dense(dz, dz_sn, dz_sc)) {
     hipLaunchKernelGGL(lrelu_bwd_kernel<4>, plane_grid(1, 1, total), dim3(256), 0, (hipStream_t)s, dy, total, total, dy2,
-                       total, total, a, total, total, slope, dz, total, total, total);
+                       total, total, a, total, total, slope, dz, total, total, total, PoolSrc{});
     PCUDA_CHECK_LAUNCH("lrelu_bwd_kernel");
     return PCUDA_OK;
   }
   if (vec_ok(dy, dy_sn, dy_sc, hw) && vec_ok(dy2, dy2_sn, dy2_sc, hw) && vec_ok(a, a_sn, a_sc, hw) &&
       vec_ok(dz, dz_sn, dz_sc, hw))
     hipLaunchKernelGGL(lrelu_bwd_kernel<4>, plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, dy, dy_sn, dy_sc, dy2,
-                       dy2_sn, dy2_sc, a, a_sn, a_sc, slope, dz, dz_sn, dz_sc, hw);
+                       dy2_sn, dy2_sc, a, a_sn, a_sc, slope, dz, dz_sn, dz_sc, hw, PoolSrc{});
   else
     hipLaunchKernelGGL(lrelu_bwd_kernel<1>, plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, dy, dy_sn, dy_sc, dy2,
-                       dy2_sn, dy2_sc, a, a_sn, a_sc, slope, dz, dz_sn, dz_sc, hw);
+                       dy2_sn, dy2_sc, a, a_sn, a_sc, slope, dz, dz_sn, dz_sc, hw, PoolSrc{});
   PCUDA_CHECK_LAUNCH("lrelu_bwd_kernel");
+  return PCUDA_OK;
+}
+
+// ---- the same three kernels with the gradient arriving through a 2x2 max-pool (PoolSrc above): `dy` here is the OPTIONAL
+// full-resolution share added to the scattered one (the encoder's skip gradient)
+static int pool_src(const pcuda_pooled* p, int n, int c, PoolSrc& ps, const char* who) {
+  if (!p || !p->g || !p->idx || p->h <= 0 || p->w <= 0 || (p->h & 1) || (p->w & 1) || !dims_ok(n, c, (long long)p->h * p->w))
+    PCUDA_FAIL(PCUDA_E_BADARG, "%s: bad pooled source (even plane, g and idx required)", who);
+  ps.g = p->g; ps.sn = p->g_sn; ps.sc = p->g_sc;
+  ps.g2 = p->g2; ps.sn2 = p->g2_sn; ps.sc2 = p->g2_sc;
+  ps.idx = p->idx; ps.w = p->w; ps.c = c; ps.ohw = (long long)(p->h >> 1) * (p->w >> 1);
+  return PCUDA_OK;
+}
+// float2 reads of g / g2 and 2-byte reads of idx at even pooled offsets: rows a multiple of 4 wide, even strides, aligned bases
+static bool pool_vec_ok(const pcuda_pooled* p) {
+  auto ok = [](const void* q, long long sn, long long sc) { return q == nullptr || (((uintptr_t)q & 7) == 0 && ((sn | sc) & 1) == 0); };
+  return (p->w & 3) == 0 && ok(p->g, p->g_sn, p->g_sc) && ok(p->g2, p->g2_sn, p->g2_sc) && ((uintptr_t)p->idx & 1) == 0 &&
+         ((((long long)(p->h >> 1) * (p->w >> 1)) & 1) == 0);
+}
+
+extern "C" int pcuda_bn_bwd_reduce_pooled(const pcuda_pooled* pool, const float* dy, long long dy_sn, long long dy_sc,
+                                          const float* a, long long a_sn, long long a_sc, const float* mean,
+                                          const float* invstd, int n, int c, float* red, int* ntiles, pcuda_stream_t s) {
+  if (!pool) PCUDA_FAIL(PCUDA_E_BADARG, "bn_bwd_reduce_pooled: null pooled source");
+  const long long hw = (long long)pool->h * pool->w;
+  if (!dims_ok(n, c, hw)) PCUDA_FAIL(PCUDA_E_BADARG, "bn_bwd_reduce_pooled: bad dims");
+  const int nt = n * cdiv(hw, PCH);
+  if (ntiles) *ntiles = nt;
+  if (!red) return PCUDA_OK;
+  PoolSrc ps{};
+  if (int rc = pool_src(pool, n, c, ps, "bn_bwd_reduce_pooled")) return rc;
+  if (!a || !mean || !invstd) PCUDA_FAIL(PCUDA_E_BADARG, "bn_bwd_reduce_pooled: null pointer");
+  ProfScope prof(PCUDA_FAM_POINTWISE, ((dy ? 8.0 : 4.0) + (pool->g2 ? 2.25 : 1.25)) * n * c * (double)hw, (hipStream_t)s);
+  if (pool_vec_ok(pool) && vec_ok(dy, dy_sn, dy_sc, hw) && vec_ok(a, a_sn, a_sc, hw))
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, true>), plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, nullptr, 0, 0,
+                       dy, dy_sn, dy_sc, a, a_sn, a_sc, mean, invstd, nullptr, nullptr, 0, hw, c, red, ps);
+  else
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<1, true>), plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, nullptr, 0, 0,
+                       dy, dy_sn, dy_sc, a, a_sn, a_sc, mean, invstd, nullptr, nullptr, 0, hw, c, red, ps);
+  PCUDA_CHECK_LAUNCH("bn_bwd_reduce_kernel<pooled>");
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_bn_bwd_apply_pooled(const pcuda_pooled* pool, const float* dy, long long dy_sn, long long dy_sc,
+                                         const float* a, long long a_sn, long long a_sc, const float* coef,
+                                         float act_slope, float* dz, long long dz_sn, long long dz_sc, int n, int c,
+                                         pcuda_stream_t s) {
+  PoolSrc ps{};
+  if (int rc = pool_src(pool, n, c, ps, "bn_bwd_apply_pooled")) return rc;
+  if (!a || !coef || !dz) PCUDA_FAIL(PCUDA_E_BADARG, "bn_bwd_apply_pooled: null pointer");
+  const long long hw = (long long)pool->h * pool->w;
+  ProfScope prof(PCUDA_FAM_POINTWISE, ((dy ? 12.0 : 8.0) + (pool->g2 ? 2.25 : 1.25)) * n * c * (double)hw, (hipStream_t)s);
+  if (pool_vec_ok(pool) && vec_ok(dy, dy_sn, dy_sc, hw) && vec_ok(a, a_sn, a_sc, hw) && vec_ok(dz, dz_sn, dz_sc, hw))
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<4, true>), plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, nullptr, 0, 0, dy,
+                       dy_sn, dy_sc, a, a_sn, a_sc, coef, nullptr, nullptr, 0, act_slope, dz, dz_sn, dz_sc, hw, ps);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<1, true>), plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, nullptr, 0, 0, dy,
+                       dy_sn, dy_sc, a, a_sn, a_sc, coef, nullptr, nullptr, 0, act_slope, dz, dz_sn, dz_sc, hw, ps);
+  PCUDA_CHECK_LAUNCH("bn_bwd_apply_kernel<pooled>");
+  return PCUDA_OK;
+}
+
+extern "C" int pcuda_lrelu_bwd_pooled(const pcuda_pooled* pool, const float* dy, long long dy_sn, long long dy_sc,
+                                      const float* a, long long a_sn, long long a_sc, float slope, float* dz,
+                                      long long dz_sn, long long dz_sc, int n, int c, pcuda_stream_t s) {
+  PoolSrc ps{};
+  if (int rc = pool_src(pool, n, c, ps, "lrelu_bwd_pooled")) return rc;
+  if (!a || !dz) PCUDA_FAIL(PCUDA_E_BADARG, "lrelu_bwd_pooled: null pointer");
+  const long long hw = (long long)pool->h * pool->w;
+  ProfScope prof(PCUDA_FAM_POINTWISE, ((dy ? 12.0 : 8.0) + (pool->g2 ? 2.25 : 1.25)) * n * c * (double)hw, (hipStream_t)s);
+  if (pool_vec_ok(pool) && vec_ok(dy, dy_sn, dy_sc, hw) && vec_ok(a, a_sn, a_sc, hw) && vec_ok(dz, dz_sn, dz_sc, hw))
+    hipLaunchKernelGGL((lrelu_bwd_kernel<4, true>), plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, nullptr, 0, 0, dy,
+                       dy_sn, dy_sc, a, a_sn, a_sc, slope, dz, dz_sn, dz_sc, hw, ps);
+  else
+    hipLaunchKernelGGL((lrelu_bwd_kernel<1, true>), plane_grid(n, c, hw), dim3(256), 0, (hipStream_t)s, nullptr, 0, 0, dy,
+                       dy_sn, dy_sc, a, a_sn, a_sc, slope, dz, dz_sn, dz_sc, hw, ps);
+  PCUDA_CHECK_LAUNCH("lrelu_bwd_kernel<pooled>");
   return PCUDA_OK;
 }
 

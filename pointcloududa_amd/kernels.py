@@ -484,6 +484,72 @@ def bn_backward(dy, a, st: BNState, gamma, dgamma, dbeta, dy2=None, post_relu=Fa
     return dz
 
 
+def make_pooled(g, idx, h, w, g2=None):
+    """gradient arriving through a 2x2 max-pool, read in place by the kernel that consumes it (pcuda_pooled)"""
+    _, _, _, gsn, gsc = _planes(g)
+    p = L.Pooled()
+    p.g, p.g_sn, p.g_sc = g.data_ptr(), gsn, gsc
+    if g2 is not None:
+        _, _, _, g2sn, g2sc = _planes(g2)
+        p.g2, p.g2_sn, p.g2_sc = g2.data_ptr(), g2sn, g2sc
+    assert idx.is_contiguous() and idx.dtype == torch.uint8
+    p.idx, p.h, p.w = idx.data_ptr(), h, w
+    return p
+
+
+_fuse_pool = os.environ.get("PCUDA_FUSE_POOL_BWD", "1") != "0"
+
+
+def lrelu_bwd_pooled(g, idx, a, slope, g2=None, dy=None):
+    """lrelu_bwd(maxpool2_bwd(g (+ g2), idx), a, dy2=dy) without the full-resolution intermediate"""
+    n, c, hw, asn, asc = _planes(a)
+    h, w = a.shape[2], a.shape[3]
+    if not _fuse_pool:
+        return lrelu_bwd(maxpool2_bwd(g, idx, h, w, dy2=g2), a, slope, dy2=dy)
+    dp, dsn, dsc = None, 0, 0
+    if dy is not None:
+        _, _, _, dsn, dsc = _planes(dy)
+        dp = dy.data_ptr()
+    dz = torch.empty(a.shape, dtype=torch.float32, device=a.device)
+    _, _, _, zsn, zsc = _planes(dz)
+    pool = make_pooled(g, idx, h, w, g2)
+    check(L.lib().pcuda_lrelu_bwd_pooled(C.byref(pool), dp, dsn, dsc, a.data_ptr(), asn, asc, float(slope), dz.data_ptr(),
+                                         zsn, zsc, n, c, _stream()), "lrelu_bwd_pooled")
+    return dz
+
+
+def bn_backward_pooled(g, idx, a, st: BNState, gamma, dgamma, dbeta, g2=None, dy=None, act_slope=1.0, accumulate=True,
+                       frozen=False):
+    """bn_backward(maxpool2_bwd(g (+ g2), idx), a, ..., dy2=dy) without the full-resolution intermediate"""
+    n, c, hw, asn, asc = _planes(a)
+    h, w = a.shape[2], a.shape[3]
+    if not _fuse_pool:
+        return bn_backward(maxpool2_bwd(g, idx, h, w, dy2=g2), a, st, gamma, dgamma, dbeta, dy2=dy, act_slope=act_slope,
+                           accumulate=accumulate, frozen=frozen)
+    dp, dsn, dsc = None, 0, 0
+    if dy is not None:
+        _, _, _, dsn, dsc = _planes(dy)
+        dp = dy.data_ptr()
+    lib = L.lib()
+    pool = make_pooled(g, idx, h, w, g2)
+    nt = C.c_int(0)
+    check(lib.pcuda_bn_bwd_reduce_pooled(C.byref(pool), None, 0, 0, None, 0, 0, None, None, n, c, None, C.byref(nt),
+                                         _stream()), "bn_bwd_reduce_pooled(query)")
+    red = torch.empty((nt.value, c, 2), dtype=torch.float32, device=a.device)
+    check(lib.pcuda_bn_bwd_reduce_pooled(C.byref(pool), dp, dsn, dsc, a.data_ptr(), asn, asc, st.mean.data_ptr(),
+                                         st.invstd.data_ptr(), n, c, red.data_ptr(), C.byref(nt), _stream()),
+          "bn_bwd_reduce_pooled")
+    coef = torch.empty((c, 3), dtype=torch.float32, device=a.device)
+    check(lib.pcuda_bn_bwd_finalize(red.data_ptr(), nt.value, c, -(n * hw) if frozen else n * hw, _ptr(gamma),
+                                    st.invstd.data_ptr(), st.mean.data_ptr(), _ptr(dgamma), _ptr(dbeta),
+                                    1 if accumulate else 0, coef.data_ptr(), _stream()), "bn_bwd_finalize")
+    dz = torch.empty(a.shape, dtype=torch.float32, device=a.device)
+    _, _, _, zsn, zsc = _planes(dz)
+    check(lib.pcuda_bn_bwd_apply_pooled(C.byref(pool), dp, dsn, dsc, a.data_ptr(), asn, asc, coef.data_ptr(),
+                                        float(act_slope), dz.data_ptr(), zsn, zsc, n, c, _stream()), "bn_bwd_apply_pooled")
+    return dz
+
+
 def lrelu_bwd(dy, a, slope, dy2=None):
     n, c, hw, asn, asc = _planes(a)
     _, _, _, dsn, dsc = _planes(dy)

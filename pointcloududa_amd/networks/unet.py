@@ -99,19 +99,28 @@ class _SegEngine:
         S[blk] = (x, x2, a0, st0, a1, st1)
         return TA(a1, st1.scale, st1.shift)
 
-    def _dc_bwd(self, P, G, blk, dy, dy2, h, w, S, need_dx, red=None):
+    def _dc_bwd(self, P, G, blk, dy, dy2, h, w, S, need_dx, red=None, pooled=None):
         """``red``: the second BatchNorm's backward-reduce partials where the kernel that produced ``dy`` already
-        computed them (decoder blocks: the classifier's dgrad, the 2x2 fold behind an up-convolution)"""
+        computed them (decoder blocks: the classifier's dgrad, the 2x2 fold behind an up-convolution).
+        ``pooled=(g, g2, idx)`` instead of ``dy``: the gradient arrives through the max-pool behind this block
+        (unet.py:48) and the first backward kernels read its scatter in place (encoder block 1)"""
         x, x2, a0, st0, a1, st1 = S[blk]
         if not self.bn:
-            dz1 = K.lrelu_bwd(dy, a1, SLOPE, dy2=dy2)
+            if pooled is not None:
+                dz1 = K.lrelu_bwd_pooled(pooled[0], pooled[2], a1, SLOPE, g2=pooled[1], dy=dy2)
+            else:
+                dz1 = K.lrelu_bwd(dy, a1, SLOPE, dy2=dy2)
             if G(blk + ".2.weight") is not None:
                 self.ops[blk + ".2"].wgrad(a0, dz1, G(blk + ".2.weight"), G(blk + ".2.bias"), h, w)
             dz0 = K.lrelu_bwd(self.ops[blk + ".2"].dgrad(dz1, P[blk + ".2.weight"], h, w), a0, SLOPE)
             return self._dc_bwd_first(P, G, blk, x, x2, dz0, h, w, need_dx)
         frozen = not S["training"]      # eval-mode BatchNorm (running statistics): a fixed affine in the backward pass
-        dz1 = K.bn_backward(dy, a1, st1, P[blk + ".5.weight"], G(blk + ".5.weight"), G(blk + ".5.bias"), dy2=dy2,
-                            act_slope=SLOPE, red=red if dy2 is None else None, frozen=frozen)
+        if pooled is not None:
+            dz1 = K.bn_backward_pooled(pooled[0], pooled[2], a1, st1, P[blk + ".5.weight"], G(blk + ".5.weight"),
+                                       G(blk + ".5.bias"), g2=pooled[1], dy=dy2, act_slope=SLOPE, frozen=frozen)
+        else:
+            dz1 = K.bn_backward(dy, a1, st1, P[blk + ".5.weight"], G(blk + ".5.weight"), G(blk + ".5.bias"), dy2=dy2,
+                                act_slope=SLOPE, red=red if dy2 is None else None, frozen=frozen)
         if G(blk + ".3.weight") is not None:
             self.ops[blk + ".3"].wgrad(TA(a0, st0.scale, st0.shift), dz1, G(blk + ".3.weight"), G(blk + ".3.bias"), h, w)
         # the second convolution's data gradient IS the first BatchNorm's incoming gradient: its reduce (sum g,
@@ -288,17 +297,18 @@ class _SegEngine:
             if i > 0:
                 c1 = "encoder.conv1_%d.0" % (i + 1)
                 y, res_prev, t = S[c1]
-                d_t = K.maxpool2_bwd(dA, idx, hi, wi, dy2=dB)
-                dzc = K.lrelu_bwd(d_t, t, SLOPE)
+                # the pool's scatter is read in place: no full-resolution d_t (three quarters zeros) is written
+                dzc = K.lrelu_bwd_pooled(dA, idx, t, SLOPE, g2=dB)
                 if G(c1 + ".weight") is not None:
                     self.ops[c1].wgrad(y, dzc, G(c1 + ".weight"), G(c1 + ".bias"), hi, wi, x2=res_prev)
                 d_y = torch.empty((y.t if isinstance(y, TA) else y).shape, dtype=torch.float32, device=dzc.device)
                 dB = torch.empty(res_prev.shape, dtype=torch.float32, device=dzc.device)
                 self.ops[c1].dgrad(dzc, P[c1 + ".weight"], hi, wi, dx=d_y, dx2=dB)
+                pooled = None
             else:
-                d_y = K.maxpool2_bwd(dA, idx, hi, wi, dy2=dB)
-                dB = None
-            dA, _ = self._dc_bwd(P, G, "encoder.encoder%d" % (i + 1), d_y, d_skips[i], hi, wi, S, i > 0 or need_dx)
+                d_y, pooled, dB = None, (dA, dB, idx), None
+            dA, _ = self._dc_bwd(P, G, "encoder.encoder%d" % (i + 1), d_y, d_skips[i], hi, wi, S, i > 0 or need_dx,
+                                 pooled=pooled)
         return dA
 
 

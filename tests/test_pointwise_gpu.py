@@ -87,6 +87,45 @@ def test_maxpool_upsample_add(dev):
     assert rel_err(db, gy.sum((0, 2, 3))) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 32, 48), (3, 5, 22, 18), (2, 32, 112, 112), (1, 3, 6, 10)])
+@pytest.mark.parametrize("shares", [(False, False), (True, False), (True, True)])
+def test_backward_kernels_read_the_pool_scatter_in_place(dev, shape, shares):
+    """lrelu_bwd / bn_backward with the gradient arriving through a 2x2 max-pool (pcuda_*_pooled) equal
+    maxpool2_bwd followed by the plain kernel BIT FOR BIT: the same sums in the same order, the 4x tensor never written;
+    rows that are no multiple of 4 wide take the scalar kernels"""
+    from pointcloududa_amd import kernels as K
+    two, skip = shares
+    n, c, h, w = shape
+    rng = np.random.default_rng(40 + h)
+    a = _rand(rng, n, c, h, w).to(dev)
+    _, idx = K.maxpool2_fwd(_rand(rng, n, c, h, w).to(dev))
+    g = _rand(rng, n, c, h // 2, w // 2).to(dev)
+    g2 = _rand(rng, n, c, h // 2, w // 2).to(dev) if two else None
+    dy = _rand(rng, n, c, h, w).to(dev) if skip else None
+    scat = K.maxpool2_bwd(g, idx, h, w, dy2=g2)
+    ref = K.lrelu_bwd(scat, a, 0.2, dy2=dy)
+    got = K.lrelu_bwd_pooled(g, idx, a, 0.2, g2=g2, dy=dy)
+    assert torch.equal(got, ref)
+    # (against the definition as well, not only against the sibling kernel)
+    want = F.max_unpool2d((g + g2 if two else g).cpu(), (idx.cpu().long() // 2 + 2 * torch.arange(h // 2)[:, None]) * w +
+                          idx.cpu().long() % 2 + 2 * torch.arange(w // 2)[None, :], 2, output_size=(h, w))
+    want = want + dy.cpu() if skip else want
+    assert rel_err(got, torch.where(a.cpu() > 0, want, 0.2 * want)) < 1e-6
+    part, nt, cnt = K.bn_stats(a)
+    gamma = (_rand(rng, c) * 0.2 + 1).to(dev)
+    st = K.bn_finalize(part, nt, cnt, gamma, torch.zeros(c, device=dev), torch.zeros(c, device=dev), torch.ones(c, device=dev))
+    out = []
+    for pooled in (False, True):
+        dg, db = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
+        if pooled:
+            dz = K.bn_backward_pooled(g, idx, a, st, gamma, dg, db, g2=g2, dy=dy, act_slope=0.2, accumulate=False)
+        else:
+            dz = K.bn_backward(scat, a, st, gamma, dg, db, dy2=dy, act_slope=0.2, accumulate=False)
+        out.append((dz, dg, db))
+    for x, y in zip(*out):      # (the scalar kernels add a plane's elements in another order than the float4 ones)
+        assert torch.equal(x, y) if w % 4 == 0 else rel_err(x, y) < 1e-5
+
+
 def test_dense_ops(dev):
     from pointcloududa_amd import kernels as K
     rng = np.random.default_rng(3)
