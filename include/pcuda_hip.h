@@ -154,6 +154,14 @@ int pcuda_conv2d_dgrad_tiles(const pcuda_conv_geom* g, int prec);
 int pcuda_conv2d_dgrad_bnred(const pcuda_conv_geom* g, int prec, const pcuda_src* dy, const void* packed_w_dgrad,
                              const pcuda_dst* dx, int accumulate, const float* a, long long a_sn, long long a_sc,
                              const float* mean, const float* invstd, float* red_partials, pcuda_stream_t s);
+/* dx = pcuda_conv2d_dgrad(dy) * (a > 0 ? 1 : slope): the LeakyReLU backward of the layer in FRONT of this convolution
+ * (GAN.py:97-108, conv -> LeakyReLU(0.2) -> conv going back) in the data-gradient kernel's epilogue; the gradient with respect
+ * to the activation is never stored.  a: the saved activation [n][cin][in_h][in_w], plane stride a_sc == dx->sc1, one
+ * destination.  PCUDA_E_UNSUPPORTED where a launch of the layer takes the transposed (16-byte store) epilogue: the caller runs
+ * pcuda_conv2d_dgrad + pcuda_lrelu_bwd instead (a partly written dx is overwritten by them). */
+int pcuda_conv2d_dgrad_lrelu(const pcuda_conv_geom* g, int prec, const pcuda_src* dy, const void* packed_w_dgrad,
+                             const pcuda_dst* dx, const float* a, long long a_sn, long long a_sc, float slope,
+                             pcuda_stream_t s);
 /* The data gradient of a layer behind the nearest-x2 fold (g->in_up: the decoder's up-convolutions, unet.py:111-112) written at
  * the STORED, half resolution: dx_half[n][cin][in_h/2][in_w/2] = the 2x2 block sums of the logical gradient (what
  * pcuda_upsample2_bwd computes from pcuda_conv2d_dgrad's output, without that 4x larger tensor going through HBM).  a != NULL:

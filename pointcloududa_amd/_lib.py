@@ -80,6 +80,7 @@ _PROTOS = {
     "pcuda_conv2d_dgrad_bnred": (i32, [C.POINTER(ConvGeom), i32, C.POINTER(Src), vp, C.POINTER(Dst), i32, vp, i64, i64, vp,
                                        vp, vp, vp]),
     "pcuda_conv2d_dgrad_fold": (i32, [C.POINTER(ConvGeom), i32, C.POINTER(Src), vp, C.POINTER(Dst), vp, i64, i64, vp, vp, vp, vp]),
+    "pcuda_conv2d_dgrad_lrelu": (i32, [C.POINTER(ConvGeom), i32, C.POINTER(Src), vp, C.POINTER(Dst), vp, i64, i64, f32, vp]),
     "pcuda_conv2d_wgrad_workspace_size": (sz, [C.POINTER(ConvGeom)]),
     "pcuda_conv2d_wgrad": (i32, [C.POINTER(ConvGeom), i32, C.POINTER(Src), vp, i64, i64, vp, vp, i32, vp, sz, vp]),
     "pcuda_conv2d_wgrad_partial": (i32, [C.POINTER(ConvGeom), i32, C.POINTER(Src), vp, i64, i64, vp, vp, i32, vp, sz,

@@ -48,6 +48,10 @@ struct IgemmParams {
   // per tile and row (sum of the stored gradient g, sum of g * (a - mean) * invstd) -- what bn_bwd_reduce computes
   const float* red_a; long long red_sn, red_sc;
   const float* red_mean; const float* red_invstd;
+  // LeakyReLU backward of the layer in FRONT fused into a dgrad launch (plain epilogues only): the stored gradient is
+  // multiplied by (a > 0 ? 1 : mask_slope), a = the saved activation, laid out like the (single) destination: plane
+  // stride y.sc1, image stride mask_sn.  No bias / accumulate / stats with it.
+  const float* mask_a; long long mask_sn; float mask_slope;
   int tw, th, tmagic;      // output tile TW x TH (TW*TH <= 128*NPB slots, any TW <= 256); tmagic = 65536/TW + 1
   int tiles_x, tiles_y, n;
   int n_co_tiles;

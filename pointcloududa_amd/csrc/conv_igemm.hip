@@ -406,6 +406,8 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
   if (p.fold && !(pipe && pl.te && !pl.w8 && pl.npb == 2 && pl.tw == 32 && pl.th == 8 && !pl.clamp && !p.xr && !p.accumulate && !p.pair))
     PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv2d_dgrad_fold: this geometry does not run on the 32 x 8-tile transposed-epilogue kernel");
   if (p.xr && !pipe) PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "igemm: record sources need the pipelined kernel for this geometry");
+  if (p.mask_a && (pl.te || p.accumulate || p.stats || p.bias || p.fold || p.y.c1 < (p.cout >> p.pair)))
+    PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv2d_dgrad_lrelu: this geometry does not run on a plain-epilogue kernel");
   if (p.red_a && !(pipe && pl.te))
     PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv2d_dgrad_bnred: this geometry does not run on the transposed-epilogue kernel");
   return x3 ? igemm_dispatch_x3(p, pl, co_blks, pf, pipe, s) : igemm_dispatch_bf16(p, pl, co_blks, pf, pipe, s);
@@ -543,12 +545,14 @@ extern "C" int pcuda_conv2d_forward(const pcuda_conv_geom* g, int prec, const pc
   return launch_igemm(p, prec, t, (hipStream_t)s);
 }
 
-extern "C" int pcuda_conv2d_dgrad(const pcuda_conv_geom* g, int prec, const pcuda_src* dy, const void* packed_w_dgrad,
-                                  const pcuda_dst* dx, int accumulate, pcuda_stream_t s) {
+// mask_a != NULL: the LeakyReLU backward of the layer in front rides in the epilogue (pcuda_conv2d_dgrad_lrelu)
+static int dgrad_impl(const pcuda_conv_geom* g, int prec, const pcuda_src* dy, const void* packed_w_dgrad,
+                      const pcuda_dst* dx, int accumulate, const float* mask_a, long long mask_sn, float mask_slope,
+                      pcuda_stream_t s) {
   if (!geom_ok(g)) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_dgrad: inconsistent geometry");
   if (!src_ok(dy, g->cout) || !dst_ok(dx, g->cin) || !packed_w_dgrad) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_dgrad: bad tensors");
   if (prec != PCUDA_PREC_BF16X3 && prec != PCUDA_PREC_BF16) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_dgrad: bad precision");
-  {
+  if (!mask_a) {
     int rc;
     if (direct_dgrad(g, prec, dy, packed_w_dgrad, dx, accumulate, (hipStream_t)s, &rc)) return rc;
     if (direct_d1_dgrad(g, prec, dy, packed_w_dgrad, dx, accumulate, packed_elems(g->cin, g->cout, 4, prec), (hipStream_t)s, &rc))
@@ -571,6 +575,7 @@ extern "C" int pcuda_conv2d_dgrad(const pcuda_conv_geom* g, int prec, const pcud
         p.in_step = 1;
         p.wpack = wp; p.w_lo_off = 0;
         p.bias = nullptr; p.slope = 1.f; p.accumulate = accumulate; p.stats = nullptr;
+        p.mask_a = mask_a; p.mask_sn = mask_sn; p.mask_slope = mask_slope;
         p.n = g->n;
         int rc = launch_igemm(p, prec, t, (hipStream_t)s);
         if (rc) return rc;
@@ -595,6 +600,7 @@ extern "C" int pcuda_conv2d_dgrad(const pcuda_conv_geom* g, int prec, const pcud
         p.in_step = 1;
         p.wpack = wp; p.w_lo_off = 0;
         p.bias = nullptr; p.slope = 1.f; p.accumulate = accumulate; p.stats = nullptr;
+        p.mask_a = mask_a; p.mask_sn = mask_sn; p.mask_slope = mask_slope;
         p.n = g->n;
         int rc = launch_igemm(p, prec, t, (hipStream_t)s);
         if (rc) return rc;
@@ -602,6 +608,25 @@ extern "C" int pcuda_conv2d_dgrad(const pcuda_conv_geom* g, int prec, const pcud
       wp += plane;
     }
   return PCUDA_OK;
+}
+
+extern "C" int pcuda_conv2d_dgrad(const pcuda_conv_geom* g, int prec, const pcuda_src* dy, const void* packed_w_dgrad,
+                                  const pcuda_dst* dx, int accumulate, pcuda_stream_t s) {
+  return dgrad_impl(g, prec, dy, packed_w_dgrad, dx, accumulate, nullptr, 0, 1.f, s);
+}
+
+// dx = dgrad(dy) * (a > 0 ? 1 : slope): the LeakyReLU backward of the layer in FRONT of this convolution (GAN.py:97-108:
+// conv -> LeakyReLU(0.2) -> conv, going back) in the epilogue of the data-gradient kernel -- the gradient with respect to
+// the activation is never stored and read back by pcuda_lrelu_bwd.  a: the saved activation [n][cin][in_h][in_w] with the
+// plane stride of dx (one destination).  PCUDA_E_UNSUPPORTED where a launch of the layer would not run on a plain-epilogue
+// kernel (the caller then runs pcuda_conv2d_dgrad + pcuda_lrelu_bwd; a partly written dx is overwritten).
+extern "C" int pcuda_conv2d_dgrad_lrelu(const pcuda_conv_geom* g, int prec, const pcuda_src* dy, const void* packed_w_dgrad,
+                                        const pcuda_dst* dx, const float* a, long long a_sn, long long a_sc, float slope,
+                                        pcuda_stream_t s) {
+  if (!a || !dx) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_dgrad_lrelu: bad tensors");
+  if (dx->c1 < g->cin || a_sc != dx->sc1 || dx->rec || dy->rec || g->in_up)
+    PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv2d_dgrad_lrelu: one NCHW destination with the activation's plane stride");
+  return dgrad_impl(g, prec, dy, packed_w_dgrad, dx, 0, a, a_sn, slope, s);
 }
 
 // timing experiments (PCUDA_DBG bit 128): per-phase cycle sums of igemm_pipe_kernel, read and reset

@@ -187,6 +187,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p, const i
         float* dst = plane + poff[pb] + (odd ? 1 : 0);
         if (cok & (odd ? pok1[pb] : pok[pb])) {
           if (p.accumulate) v += *dst;
+          if (p.mask_a) {   // (uniform) LeakyReLU backward of the layer in front: same element of the saved activation
+            const float av = *(p.mask_a + (long long)n * p.mask_sn + (dst - yb1));
+            v = av > 0.f ? v : v * p.mask_slope;
+          }
           *dst = v;
           s1 += v;
           s2 += v * v;
@@ -783,6 +787,39 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
       float* const yb1 = p.y.p1 + (long long)g.n * p.y.sn1;
       float* const yb2 = p.y.p2 + (long long)g.n * p.y.sn2;
       const unsigned pl1 = (unsigned)p.y.sc1 * 4u, pl2 = (unsigned)p.y.sc2 * 4u;
+      if (STATS == 0 && p.mask_a) {   // (uniform) its own loop: the plain one below keeps its code and registers
+        // LeakyReLU backward of the layer in front (GAN.py:97-108 going back): the saved activation has the destination's
+        // layout, so one buffer resource per image and the store's own offsets read it.  A row block's 16 x NPB values are
+        // requested together, in front of its stores (vmcnt retires in order: a load behind a store waits for that store).
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.mask_a + (long long)g.n * p.mask_sn), 0, (int)(nch * pl1), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)yb1, 0, (int)(nch * pl1), 0x00020000);
+#pragma unroll
+        for (int cb = 0; cb < CO_BLKS; ++cb) {
+          float av[16][NPB];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const unsigned soff = (unsigned)((co0 + cb * 32 + (i & 3) + 8 * (i >> 2)) >> p.pair) * pl1;
+            const unsigned hoff = h ? (4u >> p.pair) * pl1 : 0u;
+            const bool odd = (i & 1) & p.pair;
+#pragma unroll
+            for (int pb = 0; pb < NPB; ++pb)
+              av[i][pb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, (odd ? pixo1[pb] : pixo[pb]) + hoff, soff, 0));
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const unsigned soff = (unsigned)((co0 + cb * 32 + (i & 3) + 8 * (i >> 2)) >> p.pair) * pl1;
+            const unsigned hoff = h ? (4u >> p.pair) * pl1 : 0u;
+            const bool odd = (i & 1) & p.pair;
+#pragma unroll
+            for (int pb = 0; pb < NPB; ++pb) {
+              float v = acc[cb][pb][i];
+              v = av[i][pb] > 0.f ? v : v * p.mask_slope;
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, (odd ? pixo1[pb] : pixo[pb]) + hoff, soff, 0);
+            }
+          }
+        }
+      } else {
 #pragma unroll
       for (int cb = 0; cb < CO_BLKS; ++cb) {
 #pragma unroll
@@ -821,6 +858,7 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
             }
           }
         }
+      }
       }
       if (STATS) {
         __syncthreads();
@@ -1019,6 +1057,29 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
       float* const yb1 = p.y.p1 + (long long)g.n * p.y.sn1;
       float* const yb2 = p.y.p2 + (long long)g.n * p.y.sn2;
       const unsigned pl1 = (unsigned)p.y.sc1 * 4u, pl2 = (unsigned)p.y.sc2 * 4u;
+      if (STATS == 0 && p.mask_a) {   // (uniform) LeakyReLU backward of the layer in front: see igemm_pipe_kernel
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.mask_a + (long long)g.n * p.mask_sn), 0, (int)(nch * pl1), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)yb1, 0, (int)(nch * pl1), 0x00020000);
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb) {
+          float av[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const unsigned soff = (unsigned)((co0 + (cb0 + cb) * 32 + (i & 3) + 8 * (i >> 2)) >> p.pair) * pl1;
+            const unsigned vo = (((i & 1) & p.pair) ? pixo1 : pixo) + (h ? (4u >> p.pair) * pl1 : 0u);
+            av[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, vo, soff, 0));
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const unsigned soff = (unsigned)((co0 + (cb0 + cb) * 32 + (i & 3) + 8 * (i >> 2)) >> p.pair) * pl1;
+            const unsigned vo = (((i & 1) & p.pair) ? pixo1 : pixo) + (h ? (4u >> p.pair) * pl1 : 0u);
+            float v = acc[cb][i];
+            v = av[i] > 0.f ? v : v * p.mask_slope;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, vo, soff, 0);
+          }
+        }
+      } else {
 #pragma unroll
       for (int cb = 0; cb < CBW; ++cb) {
 #pragma unroll
@@ -1045,6 +1106,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
             }
           }
         }
+      }
       }
       if (STATS) {
         __syncthreads();

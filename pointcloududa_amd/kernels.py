@@ -257,6 +257,24 @@ class ConvOp:
                                          1 if accumulate else 0, _stream()), "conv2d_dgrad")
         return dx
 
+    def dgrad_lrelu(self, dy, w, in_h, in_w, a, slope):
+        """lrelu_bwd(dgrad(dy), a, slope) in one kernel where the plan allows it (pcuda_conv2d_dgrad_lrelu): the LeakyReLU
+        backward of the layer in front rides in the data-gradient epilogue (GAN.py:97-108 going back)"""
+        if _fuse_lrelu_dgrad and self.k > 1 and a.is_contiguous():
+            n = dy.shape[0]
+            g = self.geom(n, in_h, in_w)
+            dz = torch.empty((n, self.cin, in_h, in_w), dtype=torch.float32, device=dy.device)
+            pk = self._packed("dgrad", w, g)
+            src, dst = make_src(dy), make_dst(dz)
+            _, _, _, asn, asc = _planes(a)
+            rc = L.lib().pcuda_conv2d_dgrad_lrelu(C.byref(g), _precision, C.byref(src), pk.data_ptr(), C.byref(dst),
+                                                  a.data_ptr(), asn, asc, float(slope), _stream())
+            if rc == 0:
+                return dz
+            if rc != L.PCUDA_E_UNSUPPORTED:
+                check(rc, "conv2d_dgrad_lrelu")
+        return lrelu_bwd(self.dgrad(dy, w, in_h, in_w), a, slope)
+
     def dgrad_fold(self, dy, w, in_h, in_w, bnred=None):
         """The data gradient of an ``in_up`` layer at the STORED (half) resolution: dgrad + the 2x2 fold of the nearest-x2
         backward in one kernel (pcuda_conv2d_dgrad_fold); ``bnred=(a, BNState)`` as in ``dgrad``.  Returns (dx_half, (partials,
@@ -498,6 +516,7 @@ def make_pooled(g, idx, h, w, g2=None):
 
 
 _fuse_pool = os.environ.get("PCUDA_FUSE_POOL_BWD", "1") != "0"
+_fuse_lrelu_dgrad = os.environ.get("PCUDA_FUSE_LRELU_DGRAD", "1") != "0"
 
 
 def lrelu_bwd_pooled(g, idx, a, slope, g2=None, dy=None):

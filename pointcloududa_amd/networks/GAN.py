@@ -134,8 +134,8 @@ def _chain_backward(ctx, d_out):
                 else:
                     op.wgrad(acts[li], dz, dw, db, h, w)
             if li > 0:
-                d_a = op.dgrad(dz, wt, h, w)
-                dz = K.lrelu_bwd(d_a, acts[li], module._slope)
+                # (the LeakyReLU backward of the layer in front rides in the data gradient's epilogue)
+                dz = op.dgrad_lrelu(dz, wt, h, w, acts[li], module._slope)
             elif ctx.needs_input_grad[1]:
                 dx = op.dgrad(dz, wt, h, w)
     ctx.acts = None

@@ -390,3 +390,50 @@ def test_dgrad_with_the_2x2_fold_in_its_epilogue(dev, prec, n, cin, cout, h, w):
             assert rel_err(tot[:, 0], want1) < 1e-4 and rel_err(tot[:, 1], want2) < 1e-4
     finally:
         K.set_precision("bf16x3")
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("n,cin,cout,h,w,k,stride,pad,fused", [
+    (4, 64, 128, 129, 129, 4, 2, 2, True),      # the discriminators' layers (GAN.py:97-108), odd maps, paired column classes
+    (3, 128, 256, 65, 65, 4, 2, 2, True),
+    (2, 256, 512, 33, 33, 4, 2, 2, True),
+    (2, 64, 128, 113, 113, 4, 2, 2, True),      # the 224 x 224 input's second layer
+    (2, 32, 48, 40, 36, 4, 2, 1, True),         # even maps, another padding
+    (2, 40, 24, 21, 19, 3, 1, 1, True),         # stride 1 on rows that are no multiple of 4: plain epilogue
+    (2, 64, 64, 32, 32, 3, 1, 1, True),         # few tiles: the eight-wave kernel (plain epilogue)
+    (88, 64, 64, 32, 32, 3, 1, 1, False),       # transposed-epilogue plan: not taken, the two-kernel form runs
+])
+def test_dgrad_with_the_leaky_relu_backward_in_its_epilogue(dev, prec, n, cin, cout, h, w, k, stride, pad, fused):
+    """dgrad * (a > 0 ? 1 : slope) in one kernel (pcuda_conv2d_dgrad_lrelu) equals pcuda_conv2d_dgrad followed by
+    pcuda_lrelu_bwd BIT FOR BIT (the same accumulators, one more multiply) and the CPU reference within the precision's
+    tolerance; plans the fused epilogue does not cover report UNSUPPORTED and the wrapper runs the two kernels."""
+    import ctypes as C
+    from pointcloududa_amd import _lib as L, kernels as K
+    K.set_precision(prec)
+    try:
+        rng = np.random.default_rng(cin + h + k)
+        oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+        wt = torch.from_numpy(rng.normal(0, 0.1, (cout, cin, k, k)).astype(np.float32))
+        gz = torch.from_numpy(rng.normal(0, 1, (n, cout, oh, ow)).astype(np.float32))
+        a = torch.from_numpy(rng.normal(0, 1, (n, cin, h, w)).astype(np.float32))
+        x = torch.zeros(n, cin, h, w, requires_grad=True)
+        F.conv2d(x, wt, None, stride=stride, padding=pad).backward(gz)
+        want = torch.where(a > 0, x.grad, 0.2 * x.grad)
+        op = K.ConvOp(cin, cout, k, stride=stride, pad=pad)
+        two = K.lrelu_bwd(op.dgrad(gz.to(dev), wt.to(dev), h, w), a.to(dev), 0.2)
+        got = op.dgrad_lrelu(gz.to(dev), wt.to(dev), h, w, a.to(dev), 0.2)
+        assert torch.equal(got, two)
+        assert rel_err(got, want) < TOL[prec]
+        # which path ran: the entry itself on the same operands
+        g = op.geom(n, h, w)
+        dz = torch.empty(n, cin, h, w, device=dev)
+        ad, gd = a.to(dev), gz.to(dev)
+        pk = op._packed("dgrad", wt.to(dev), g)
+        src, dst = K.make_src(gd), K.make_dst(dz)
+        rc = L.lib().pcuda_conv2d_dgrad_lrelu(C.byref(g), K._precision, C.byref(src), pk.data_ptr(), C.byref(dst), ad.data_ptr(),
+                                              ad.stride(0), ad.stride(1), 0.2, K._stream())
+        assert rc == (0 if fused else L.PCUDA_E_UNSUPPORTED)
+        if fused:
+            assert torch.equal(dz, two)
+    finally:
+        K.set_precision("bf16x3")
