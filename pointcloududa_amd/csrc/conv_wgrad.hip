@@ -218,6 +218,8 @@ extern "C" size_t pcuda_conv2d_wgrad_workspace_size(const pcuda_conv_geom* g) {
   if (d1need > dneed) dneed = d1need;
   const size_t w3need = wgrad3_workspace(g);
   if (w3need > dneed) dneed = w3need;
+  const size_t w1need = wgrad1_workspace(g);
+  if (w1need > dneed) dneed = w1need;
   return need > dneed ? need : dneed;
 }
 
@@ -260,6 +262,8 @@ static int wgrad_impl(const pcuda_conv_geom* g, int prec, const pcuda_src* x, co
     if (direct_d1_wgrad(g, x, dy, dy_sn, dy_sc, dw, db, accumulate, workspace, s, &rc)) return rc;
     // aligned 3x3 / stride-1 layers: the fixed-geometry kernel (conv_wgrad3.hip)
     if (wgrad3_try(g, prec, x, dy, dy_sn, dy_sc, dw, db, accumulate, workspace, s, defer, &rc)) return rc;
+    // 1x1 / stride-1 layers on whole 16-pixel steps: NT GEMM over pixels, operands straight from global memory (conv_wgrad1.hip)
+    if (wgrad1_try(g, prec, x, dy, dy_sn, dy_sc, dw, db, accumulate, workspace, s, defer, &rc)) return rc;
   }
   const bool x3 = prec == PCUDA_PREC_BF16X3;
   WgradPlan w = plan_wgrad(g);

@@ -173,6 +173,7 @@ __device__ __forceinline__ void pool_load(const PoolSrc& ps, int n, int ch, long
     if (pg2) gv += *pg2;
     out[0] = (int)*pi == krow + (x & 1) ? gv : 0.f;
   }
+  PCUDA_KEEP(pg); PCUDA_KEEP(pg2); PCUDA_KEEP(pi);      // (VMEM address rule, common.h)
 }
 
 template <int VEC, bool POOL = false>
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
       s1 += gg;
       s2 += gg * ((av[e] - m) * is);
     }
+    if (POOL) { PCUDA_KEEP(pa + i); PCUDA_KEEP(pd2 + i); }
   }
   s1 = block_sum(s1, sh);
   s2 = block_sum(s2, sh);
@@ -293,6 +295,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
       }
     }
     vstore<VEC>(pz + i, out);
+    if (POOL) { PCUDA_KEEP(pa + i); PCUDA_KEEP(pd2 + i); }
   }
 }
 
@@ -328,6 +331,7 @@ __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* __restrict_
       out[e] = av[e] > 0.f ? gg : gg * slope;
     }
     vstore<VEC>(pz + i, out);
+    if (POOL) { PCUDA_KEEP(pa + i); PCUDA_KEEP(pd2 + i); }
   }
 }
 

@@ -26,6 +26,11 @@ CASES = {  # name: (n, cin, cout, h, w, k, s, p, d, up)
     "mb512": (32, 512, 512, 14, 14, 3, 1, 1, 1, False), "mb512d8": (32, 512, 512, 14, 14, 3, 1, 8, 8, False),
     "md2": (32, 64, 128, 113, 113, 4, 2, 2, 1, False), "md3": (32, 128, 256, 57, 57, 4, 2, 2, 1, False),
     "md4": (32, 256, 512, 29, 29, 4, 2, 2, 1, False),
+    # the residual 1x1 convolutions behind the concatenation (unet.py:41-47) and the classifier: p* (p = pointwise)
+    "p96": (32, 96, 64, 128, 128, 1, 1, 0, 1, False), "p192": (32, 192, 128, 64, 64, 1, 1, 0, 1, False),
+    "p384": (32, 384, 256, 32, 32, 1, 1, 0, 1, False), "pcls": (32, 32, 4, 256, 256, 1, 1, 0, 1, False),
+    "mp96": (32, 96, 64, 112, 112, 1, 1, 0, 1, False), "mp192": (32, 192, 128, 56, 56, 1, 1, 0, 1, False),
+    "mp384": (32, 384, 256, 28, 28, 1, 1, 0, 1, False),
 }
 which = sys.argv[1:] or list(CASES)
 for name in which:
@@ -34,7 +39,7 @@ for name in which:
     # LeakyReLU(0.01) and BatchNorm partial sums -- the bottleneck (b*/mb*) no BatchNorm; the discriminators' stride-2 layers
     # (d*/md*) no bias, LeakyReLU(0.2), no statistics
     disc, bott = name.lstrip("m").startswith("d"), name.lstrip("m").startswith("b")
-    stats, slope = not (disc or bott), (0.2 if disc else 0.01)
+    stats, slope = not (disc or bott or name.lstrip("m").startswith("p")), (0.2 if disc else 0.01)
     if os.environ.get("MICRO_NOSTATS") == "1": stats = False
     op = K.ConvOp(cin, cout, k, stride=s, pad=p, dil=d, in_up=up)
     x = torch.randn(n, cin, h, w, device=dev); wt = torch.randn(cout, cin, k, k, device=dev) * 0.05

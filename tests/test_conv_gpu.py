@@ -437,3 +437,48 @@ def test_dgrad_with_the_leaky_relu_backward_in_its_epilogue(dev, prec, n, cin, c
             assert torch.equal(dz, two)
     finally:
         K.set_precision("bf16x3")
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("n,c1,c2,cout,h,w", [
+    (2, 64, 32, 64, 32, 32),        # encoder conv1_2: cat(y, res_prev) -> 1x1 (unet.py:41-47), three 32-channel blocks
+    (3, 128, 64, 128, 16, 16),      # two co tiles x two ci tiles
+    (2, 48, 32, 40, 12, 8),         # ragged on both sides: 80 input channels (source boundary inside a block), 40 outputs
+    (4, 32, 0, 4, 64, 64),          # the classifier: 4 output rows of a 32-row block
+    (1, 20, 0, 24, 4, 4),           # one 16-pixel step in all
+])
+def test_pointwise_layer_weight_gradient_from_global_rows(dev, prec, n, c1, c2, cout, h, w):
+    """1x1 / stride-1 layers on whole 16-pixel steps take the NT-GEMM-over-pixels kernel (csrc/conv_wgrad1.hip: operand fragments
+    straight from global memory): against the CPU reference with two sources, the lazy-BatchNorm affine on the first one,
+    the bias gradient, and accumulate semantics"""
+    from pointcloududa_amd import kernels as K
+    from pointcloududa_amd.kernels import TA
+    K.set_precision(prec)
+    try:
+        rng = np.random.default_rng(c1 + cout + h)
+        cin = c1 + c2
+        a = torch.from_numpy(rng.normal(0, 1, (n, c1, h, w)).astype(np.float32))
+        b = torch.from_numpy(rng.normal(0, 1, (n, c2, h, w)).astype(np.float32)) if c2 else None
+        sc = torch.from_numpy(rng.normal(1, 0.2, (c1,)).astype(np.float32))
+        sf = torch.from_numpy(rng.normal(0, 0.2, (c1,)).astype(np.float32))
+        wt = torch.from_numpy(rng.normal(0, 0.1, (cout, cin, 1, 1)).astype(np.float32)).requires_grad_(True)
+        bias = torch.zeros(cout, requires_grad=True)
+        xa = a * sc[None, :, None, None] + sf[None, :, None, None]
+        xin = torch.cat([xa, b], 1) if c2 else xa
+        z = F.conv2d(xin, wt, bias)
+        gz = torch.from_numpy(rng.normal(0, 1, z.shape).astype(np.float32))
+        z.backward(gz)
+        op = K.ConvOp(cin, cout, 1)
+        dw, db = torch.zeros(cout, cin, 1, 1, device=dev), torch.zeros(cout, device=dev)
+        src = TA(a.to(dev), sc.to(dev), sf.to(dev))
+        op.wgrad(src, gz.to(dev), dw, db, h, w, x2=b.to(dev) if c2 else None, accumulate=False)
+        assert rel_err(dw, wt.grad) < TOL[prec] and rel_err(db, bias.grad) < 1e-4
+        op.wgrad(src, gz.to(dev), dw, db, h, w, x2=b.to(dev) if c2 else None, accumulate=True)
+        assert rel_err(dw, 2 * wt.grad) < TOL[prec] and rel_err(db, 2 * bias.grad) < 1e-4
+        # the same bits on a second run (fixed summation order)
+        dw2, db2 = torch.zeros_like(dw), torch.zeros_like(db)
+        op.wgrad(src, gz.to(dev), dw2, db2, h, w, x2=b.to(dev) if c2 else None, accumulate=False)
+        op.wgrad(src, gz.to(dev), dw2, db2, h, w, x2=b.to(dev) if c2 else None, accumulate=True)
+        assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    finally:
+        K.set_precision("bf16x3")

@@ -28,7 +28,9 @@ def test_direct_kernels_keep_load_addresses_alive():
 # loads of that form the compiler still emits in the LDS-free kernel families (one process per GPU never showed a wrong
 # result from them; a GPU shared by two processes is an unsupported deployment: INTEGRATION.md section 4).  The counts
 # are an allow-list: a compiler upgrade or a new kernel that ADDS such loads fails this test instead of going unnoticed.
-ALLOWED = {"pointwise.s": 11, "losses.s": 15, "dense.s": 20, "sampler.s": 56, "conv1d_f32.s": 4, "optim.s": 0}
+# (pointwise.s: 11 until round 4; + 9 in the three pooled-source kernels, whose float2 loads of the pooled gradient keep the
+# form although their addresses are held with PCUDA_KEEP)
+ALLOWED = {"pointwise.s": 20, "losses.s": 15, "dense.s": 20, "sampler.s": 56, "conv1d_f32.s": 4, "optim.s": 0}
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc (cross-compiles without a GPU)")
