@@ -335,7 +335,7 @@ int pcuda_bce_const_fwd(const float* x, long long numel, float label, float* los
 int pcuda_bce_const_bwd(const float* x, long long numel, float label, const float* gout, float gscale, float* dx,
                         pcuda_stream_t s);
 /* batch_NN_loss (loss.py:40-76): x,y [b][npts][3]; loss scalar; workspaces: idx_ws int32 [2][b][npts],
- * val_ws float [2][b][npts] + [2][b] (per-direction, per-item means) */
+ * val_ws float [2][b][npts] + [2][b][ceil(npts / 64)] (partial sums of the minima per block of 64 points) */
 int pcuda_nn_loss_fwd(const float* x, const float* y, int b, int npts, float* loss, int* idx_ws, float* val_ws,
                       pcuda_stream_t s);
 int pcuda_nn_loss_bwd(const float* x, const float* y, int b, int npts, const int* idx_ws, const float* val_ws,

@@ -477,14 +477,19 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
         int baddr[NPB];
         if (CLAMP) {
           const int dy = (tcur << 16) >> 16, dx = tcur >> 16;
+          bool any = false;
 #pragma unroll
           for (int pb = 0; pb < NPB; ++pb) {
             const int gy = (g.y0 + pty[pb]) * p.in_step + dy;
             const int gxx = (g.x0 + ptx[pb]) * p.in_step + dx;
             const bool ok = ((unsigned)gy < (unsigned)p.in_h) & ((unsigned)gxx < (unsigned)p.in_w);
+            any |= ok;
             const int idx = ok ? (gy - g.oy0) * g.tw + (gxx - g.ox0) : g.npix;
             baddr[pb] = idx * REC + h * 16;
           }
+          // (a tap whose reads all fall outside the image for this wave's pixel blocks multiplies the zero record: skipped)
+          // (record sources read a pad record that need not be zero: never skipped)
+          if (!XR && __builtin_amdgcn_ballot_w64(any) == 0) continue;
         } else {
 #pragma unroll
           for (int pb = 0; pb < NPB; ++pb) baddr[pb] = bbase[pb] + tcur;
@@ -1011,6 +1016,9 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
           const int gy = (g.y0 + pty) * p.in_step + dy;
           const int gxx = (g.x0 + ptx) * p.in_step + dx;
           const bool ok = ((unsigned)gy < (unsigned)p.in_h) & ((unsigned)gxx < (unsigned)p.in_w);
+          // (dilation 8 on a 16x16 map: a wave's two tile rows read outside the image for a third of the taps -- products
+          // with the zero record, skipped whole: same sums, the zeros contributed nothing)
+          if (__builtin_amdgcn_ballot_w64(ok) == 0) continue;
           const int idx = ok ? (gy - g.oy0) * g.tw + (gxx - g.ox0) : g.npix;
           baddr = idx * REC + h * 16;
         } else {

@@ -813,7 +813,7 @@ def nn_loss_fwd(x, y):
     x, y = x.contiguous(), y.contiguous()
     b, npts = x.shape[0], x.shape[1]
     idx = torch.empty((2, b, npts), dtype=torch.int32, device=x.device)
-    val = torch.empty(2 * b * npts + 2 * b, dtype=torch.float32, device=x.device)
+    val = torch.empty(2 * b * npts + 2 * b * ((npts + 63) // 64), dtype=torch.float32, device=x.device)
     loss = torch.empty((), dtype=torch.float32, device=x.device)
     check(L.lib().pcuda_nn_loss_fwd(x.data_ptr(), y.data_ptr(), b, npts, loss.data_ptr(), idx.data_ptr(),
                                     val.data_ptr(), _stream()), "nn_loss_fwd")

@@ -448,7 +448,9 @@ class AdversarialTrainer:
                 graph = torch.cuda.CUDAGraph()
                 self._segment = "compute" if coll else None
                 try:
-                    with torch.cuda.graph(graph):   # records only: nothing executes during capture
+                    # (thread-local capture mode: in a process group, RCCL's watchdog thread polls the events of earlier
+                    # collectives while this thread records; in the default global mode its calls fail or invalidate the capture)
+                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # records only: nothing executes
                         self._gout = self.step(*self._gin)
                 finally:
                     self._segment = None
@@ -457,7 +459,7 @@ class AdversarialTrainer:
                     import torch.distributed as dist
                     scale = 1.0 / dist.get_world_size(self.group)
                     gb = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gb):
+                    with torch.cuda.graph(gb, capture_error_mode="thread_local"):
                         self.apply_updates(scale)
                     self._graph_b = gb
                 self._graph = graph

@@ -117,3 +117,26 @@ def test_losses_against_oracle_large(dev):
     d_ref = OM.dice_coef_multilabel(onehot.numpy(), hard, c)
     d = K.dice_metric(logits.to(dev), onehot.to(dev))
     assert abs(float(d) - d_ref) < 1e-6
+
+
+@pytest.mark.parametrize("b,npts", [(3, 300), (2, 37), (1, 1), (2, 64), (1, 1024)])
+def test_nearest_neighbour_loss_blocks_of_points(dev, b, npts):
+    """batch_NN_loss (loss.py:40-76) with the search spread over blocks of 64 points and four lanes per point: values,
+    nearest indices and gradient against the dense torch form, for clouds that are no multiple of the block (and of 4)"""
+    from pointcloududa_amd import kernels as K
+    from pointcloududa_amd.utils import loss as L
+    rng = np.random.default_rng(b * 1000 + npts)
+    x = torch.from_numpy(rng.normal(0, 1, (b, npts, 3)).astype(np.float32))
+    y = torch.from_numpy(rng.normal(0, 1, (b, npts, 3)).astype(np.float32))
+    xr = x.clone().requires_grad_(True)
+    r_x, r_y = (xr * xr).sum(2), (y * y).sum(2)
+    P = r_x[:, :, None] + r_y[:, None, :] - 2 * torch.bmm(xr, y.transpose(1, 2))
+    D = torch.sqrt(P + 0.00001)
+    want = (D.min(2)[0].mean(1) + D.min(1)[0].mean(1)).mean()
+    want.backward()
+    loss, idx, val = K.nn_loss_fwd(x.to(dev), y.to(dev))
+    assert abs(float(loss) - float(want)) < 1e-5 * max(1.0, abs(float(want)))
+    assert torch.equal(idx[0].cpu().long(), D.detach().argmin(2)) and torch.equal(idx[1].cpu().long(), D.detach().argmin(1))
+    xd = x.to(dev).requires_grad_(True)
+    L.batch_NN_loss(xd, y.to(dev)).backward()
+    assert rel_err(xd.grad, xr.grad) < 1e-3

@@ -566,6 +566,7 @@ def test_graph_replay_with_rccl_collectives_in_a_one_rank_group(dev, monkeypatch
         # two eager steps (two buckets each); the capture issues none; each of the three replays one whole-buffer all-reduce
         assert calls == [(tr_g.opt_gen.split_after("encoder."), None), (0, tr_g.opt_gen.split_after("encoder."))] * 2 + [(0, None)] * 3, calls
     finally:
+        torch.cuda.synchronize()
         dist.destroy_process_group()
     he, hg = tr_e.to_host(out_e, tr_e.cfg), tr_g.to_host(out_g, tr_g.cfg)
     for k in ("seg_loss", "adv_loss"):
