@@ -456,13 +456,14 @@ def main():
                    "parallelism": "dp%d" % world, "ranks_in_group": ranks_in_group,
                    "collective": ("%s all-reduce of the flat gradient buffers (G: 2 buckets, D: 1 each)" % (
                        "RCCL" if os.environ.get("PCUDA_DIST_BACKEND", "nccl") == "nccl" else os.environ["PCUDA_DIST_BACKEND"] + " (REHEARSAL, ranks share one GPU)"))
-                                 if world > 1 else "none",
+                                 if world > 1 else ("RCCL all-reduce in a one-rank group (PCUDA_FORCE_COLLECTIVES=1: the N > 1 code path on one GPU)"
+                                                    if dist is not None else "none"),
                    "algorithmic_gflop_per_pair": wl["gflop_per_pair"],
                    # the SURVEY 8d convention counts 8 passes per discriminator; with the target forward of d1 / d2
                    # replayed from the adversarial pass, 7 of them execute for those two networks
                    "executed_gflop_per_pair": round(wl["gflop_per_pair"] - (2 * wl.get("d_gflop", 3.60 * (wl.get("hw", 256) / 256.0) ** 2)
                                                     * (int(wl["d1"]) + int(wl["d2"])) / 2.0 if tr.d_reuse else 0.0), 1),
-                   "box_to_box": "641-688 img/s measured for this command across MI355X boxes in round 3 (boxes of the pool differ by up to 10 % on one binary)",
+                   "box_to_box": "638-690 img/s measured for the default command across MI355X boxes in rounds 3-4 (boxes of the pool differ by up to 10 % on one binary)",
                    "streams": "discriminators concurrent" if tr.d_streams else "single",
                    # d1 / d2 see the target batch twice per step with the same weights and the same input values
                    # (adversarial pass, then their own update): the second forward is replayed from the first's
