@@ -309,6 +309,20 @@ class ConvOp:
         return upsample2_bwd(d_up, bnred=bnred)
 
     def wgrad(self, x, dy, dw, db, in_h, in_w, x2=None, accumulate=True):
+        side = getattr(_wg_side, "stream", None)
+        if side is None:
+            return self._wgrad_now(x, dy, dw, db, in_h, in_w, x2, accumulate)
+        # inside ``wgrad_side_stream``: nothing in the backward pass waits for a weight gradient, so it is issued on a
+        # second stream behind the tensors it reads and fills the compute units the data-gradient chain leaves idle
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._wgrad_now(x, dy, dw, db, in_h, in_w, x2, accumulate)
+        xa = _as_ta(x)
+        for t in (xa.t, xa.scale, xa.shift, dy, x2):      # (the allocator may hand these out again only behind the side stream)
+            if t is not None:
+                t.record_stream(side)
+
+    def _wgrad_now(self, x, dy, dw, db, in_h, in_w, x2=None, accumulate=True):
         xa = _as_ta(x)
         n = xa.t.shape[0]
         g = self.geom(n, in_h, in_w)
@@ -333,6 +347,31 @@ class ConvOp:
         check(lib.pcuda_conv2d_wgrad(C.byref(g), _precision, C.byref(src), dy.data_ptr(), sn, sc, dw.data_ptr(),
                                      _ptr(db), 1 if accumulate else 0, ws.data_ptr(), ws_bytes, _stream()),
               "conv2d_wgrad")
+
+
+_wg_side = threading.local()
+
+
+class wgrad_side_stream:
+    """``with wgrad_side_stream(stream):`` every ``ConvOp.wgrad`` of this thread goes to ``stream`` (forked behind the
+    caller's stream at each call); ``join()`` / leaving the block makes the caller's stream wait for them."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def __enter__(self):
+        self.outer = getattr(_wg_side, "stream", None)
+        _wg_side.stream = self.stream
+        return self
+
+    def join(self):
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+    def __exit__(self, *exc):
+        _wg_side.stream = self.outer
+        self.join()
+        return False
 
 
 # PCUDA_BATCH_REDUCE=1: the split-K reduces of a backward pass in one launch per 56 layers instead of one per layer.
