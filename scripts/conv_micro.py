@@ -27,6 +27,10 @@ CASES = {  # name: (n, cin, cout, h, w, k, s, p, d, up)
     "mb512": (32, 512, 512, 14, 14, 3, 1, 1, 1, False), "mb512d8": (32, 512, 512, 14, 14, 3, 1, 8, 8, False),
     "md2": (32, 64, 128, 113, 113, 4, 2, 2, 1, False), "md3": (32, 128, 256, 57, 57, 4, 2, 2, 1, False),
     "md4": (32, 256, 512, 29, 29, 4, 2, 2, 1, False),
+    # the discriminators' stride-2 4x4 layers written as 2x2 / stride-1 layers over a space-to-depth input (4 cin channels at
+    # half resolution): what the same MACs cost in that form on today's kernels (s2d* = d2 / d3 / d4)
+    "s2d2": (32, 256, 128, 67, 67, 2, 1, 0, 1, False), "s2d3": (32, 512, 256, 35, 35, 2, 1, 0, 1, False),
+    "s2d4": (32, 1024, 512, 19, 19, 2, 1, 0, 1, False),
     # the residual 1x1 convolutions behind the concatenation (unet.py:41-47) and the classifier: p* (p = pointwise)
     "p96": (32, 96, 64, 128, 128, 1, 1, 0, 1, False), "p192": (32, 192, 128, 64, 64, 1, 1, 0, 1, False),
     "p384": (32, 384, 256, 32, 32, 1, 1, 0, 1, False), "pcls": (32, 32, 4, 256, 256, 1, 1, 0, 1, False),
@@ -39,7 +43,7 @@ for name in which:
     # the variants the NETWORKS launch (and the default build holds, csrc/variants.h): the segmenter's 3x3 layers have a bias,
     # LeakyReLU(0.01) and BatchNorm partial sums -- the bottleneck (b*/mb*) no BatchNorm; the discriminators' stride-2 layers
     # (d*/md*) no bias, LeakyReLU(0.2), no statistics
-    disc, bott = name.lstrip("m").startswith("d"), name.lstrip("m").startswith("b")
+    disc, bott = name.lstrip("m").startswith("d") or name.startswith("s2d"), name.lstrip("m").startswith("b")
     stats, slope = not (disc or bott or name.lstrip("m").startswith("p")), (0.2 if disc else 0.01)
     if os.environ.get("MICRO_NOSTATS") == "1": stats = False
     op = K.ConvOp(cin, cout, k, stride=s, pad=p, dil=d, in_up=up)
