@@ -184,6 +184,9 @@ int direct_d1_wgrad(const pcuda_conv_geom* g, const pcuda_src* x, const float* d
                     float* db, int accumulate, void* workspace, hipStream_t s, int* rc);
 int launch_wgrad_reduce_taps(const float* partial, long long numel, int ksplit, float* dw, int accumulate, int ntaps,
                              const float* db_partial, long long nb, float* db, hipStream_t s);
+size_t wgrad3r_workspace(const pcuda_conv_geom* g);
+int wgrad3r_try(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const float* dy, long long dy_sn, long long dy_sc,
+                float* dw, float* db, int accumulate, void* workspace, hipStream_t s, pcuda_reduce_job* defer, int* rc);
 size_t wgrad1_workspace(const pcuda_conv_geom* g);
 int wgrad1_try(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const float* dy, long long dy_sn, long long dy_sc,
                float* dw, float* db, int accumulate, void* workspace, hipStream_t s, pcuda_reduce_job* defer, int* rc);

@@ -220,6 +220,8 @@ extern "C" size_t pcuda_conv2d_wgrad_workspace_size(const pcuda_conv_geom* g) {
   if (w3need > dneed) dneed = w3need;
   const size_t w1need = wgrad1_workspace(g);
   if (w1need > dneed) dneed = w1need;
+  const size_t w3rneed = wgrad3r_workspace(g);
+  if (w3rneed > dneed) dneed = w3rneed;
   return need > dneed ? need : dneed;
 }
 
@@ -260,6 +262,8 @@ static int wgrad_impl(const pcuda_conv_geom* g, int prec, const pcuda_src* x, co
     int rc;
     if (direct_wgrad(g, x, dy, dy_sn, dy_sc, dw, db, accumulate, workspace, s, &rc)) return rc;
     if (direct_d1_wgrad(g, x, dy, dy_sn, dy_sc, dw, db, accumulate, workspace, s, &rc)) return rc;
+    // (experiment, PCUDA_WGRAD3R=1: 3x3 layers with few channels on large maps without LDS staging, conv_wgrad3r.hip)
+    if (wgrad3r_try(g, prec, x, dy, dy_sn, dy_sc, dw, db, accumulate, workspace, s, defer, &rc)) return rc;
     // aligned 3x3 / stride-1 layers: the fixed-geometry kernel (conv_wgrad3.hip)
     if (wgrad3_try(g, prec, x, dy, dy_sn, dy_sc, dw, db, accumulate, workspace, s, defer, &rc)) return rc;
     // 1x1 / stride-1 layers on whole 16-pixel steps: NT GEMM over pixels, operands straight from global memory (conv_wgrad1.hip)

@@ -9,6 +9,8 @@ K.set_precision(os.environ.get("PREC", "bf16x3"))
 CASES = {  # name: (n, cin, cout, h, w, k, s, p, d, up)
     "g32": (32, 32, 32, 256, 256, 3, 1, 1, 1, False),
     "g64": (32, 64, 64, 128, 128, 3, 1, 1, 1, False),
+    "g6432": (32, 64, 32, 256, 256, 3, 1, 1, 1, False), "g12864": (32, 128, 64, 128, 128, 3, 1, 1, 1, False),
+    "g3264": (32, 32, 64, 128, 128, 3, 1, 1, 1, False),
     "g128": (32, 128, 128, 64, 64, 3, 1, 1, 1, False),
     "g256": (32, 256, 256, 32, 32, 3, 1, 1, 1, False),
     "b512": (32, 512, 512, 16, 16, 3, 1, 1, 1, False),

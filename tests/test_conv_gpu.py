@@ -482,3 +482,47 @@ def test_pointwise_layer_weight_gradient_from_global_rows(dev, prec, n, c1, c2, 
         assert torch.equal(dw, dw2) and torch.equal(db, db2)
     finally:
         K.set_precision("bf16x3")
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("n,c1,c2,cout,h,w", [
+    (2, 32, 32, 32, 64, 64),        # decoder block 1: cat(skip, up) 64 -> 32 (unet.py:116), the shape the kernel runs by default
+    (2, 32, 0, 64, 64, 32),         # encoder block 2: 32 -> 64; one 32-pixel strip
+    (3, 16, 8, 40, 68, 96),         # ragged channel blocks, rows that do not divide by the unroll of 4, three strips
+])
+def test_register_window_weight_gradient(dev, prec, n, c1, c2, cout, h, w):
+    """3x3 layers with unequal channel counts <= 64 on maps of >= 64 rows take the LDS-free weight-gradient kernel
+    (csrc/conv_wgrad3r.hip: operand rows straight from global memory, the nine taps as register shifts of a three-row window):
+    against the CPU reference with two sources, the lazy-BatchNorm affine (zero padding AFTER the affine: borders matter),
+    bias gradient, accumulate semantics, and bit-reproducibility"""
+    from pointcloududa_amd import kernels as K
+    from pointcloududa_amd.kernels import TA
+    K.set_precision(prec)
+    try:
+        rng = np.random.default_rng(c1 + cout + h)
+        cin = c1 + c2
+        a = torch.from_numpy(rng.normal(0, 1, (n, c1, h, w)).astype(np.float32))
+        b = torch.from_numpy(rng.normal(0, 1, (n, c2, h, w)).astype(np.float32)) if c2 else None
+        sc = torch.from_numpy(rng.normal(1, 0.2, (c1,)).astype(np.float32))
+        sf = torch.from_numpy(rng.normal(0.5, 0.2, (c1,)).astype(np.float32))        # a shift far from 0: padding must stay 0
+        wt = torch.from_numpy(rng.normal(0, 0.1, (cout, cin, 3, 3)).astype(np.float32)).requires_grad_(True)
+        bias = torch.zeros(cout, requires_grad=True)
+        xa = a * sc[None, :, None, None] + sf[None, :, None, None]
+        xin = torch.cat([xa, b], 1) if c2 else xa
+        z = F.conv2d(xin, wt, bias, padding=1)
+        gz = torch.from_numpy(rng.normal(0, 1, z.shape).astype(np.float32))
+        z.backward(gz)
+        op = K.ConvOp(cin, cout, 3, pad=1)
+        dw, db = torch.zeros(cout, cin, 3, 3, device=dev), torch.zeros(cout, device=dev)
+        src = TA(a.to(dev), sc.to(dev), sf.to(dev))
+        x2 = b.to(dev) if c2 else None
+        op.wgrad(src, gz.to(dev), dw, db, h, w, x2=x2, accumulate=False)
+        assert rel_err(dw, wt.grad) < TOL[prec] and rel_err(db, bias.grad) < 1e-4
+        op.wgrad(src, gz.to(dev), dw, db, h, w, x2=x2, accumulate=True)
+        assert rel_err(dw, 2 * wt.grad) < TOL[prec] and rel_err(db, 2 * bias.grad) < 1e-4
+        dw2, db2 = torch.zeros_like(dw), torch.zeros_like(db)
+        op.wgrad(src, gz.to(dev), dw2, db2, h, w, x2=x2, accumulate=False)
+        op.wgrad(src, gz.to(dev), dw2, db2, h, w, x2=x2, accumulate=True)
+        assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    finally:
+        K.set_precision("bf16x3")
