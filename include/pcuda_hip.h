@@ -131,6 +131,10 @@ int pcuda_conv2d_pack_jobs_fill(const pcuda_conv_geom* g, int prec, const float*
                                 void* host_jobs, int max_jobs, int* job_blocks);
 int pcuda_conv2d_pack_table(const void* dev_jobs, const int* dev_first_block, int njobs, int total_blocks, pcuda_stream_t s);
 
+/* 1: pcuda_conv2d_forward takes this geometry (the discriminators' first layer, GAN.py:97: k = 4, stride 2, pad 2, <= 5
+ * input channels, 64 outputs) on the direct MFMA kernel that reads the 4x4 taps straight from the image -- the caller then
+ * skips the unfold (pcuda_unfold_taps) + 1x1 form of the layer */
+int pcuda_conv2d_d1_forward_ok(const pcuda_conv_geom* g);
 /* y = lrelu(conv(x) + bias, slope)   (slope = 1 -> no activation; bias may be NULL)
  * bn_partials (optional): per-tile partial sums [ntiles][cout][2] (sum, sum of squares) of the
  * activated output, for the BatchNorm that follows (unet.py:26,30); ntiles from

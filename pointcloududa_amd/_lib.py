@@ -75,6 +75,7 @@ _PROTOS = {
     "pcuda_conv2d_pack_table": (i32, [vp, vp, i32, i32, vp]),
     "pcuda_conv2d_fwd_tiles": (i32, [C.POINTER(ConvGeom), i32]),
     "pcuda_conv2d_forward": (i32, [C.POINTER(ConvGeom), i32, C.POINTER(Src), vp, vp, f32, C.POINTER(Dst), vp, vp]),
+    "pcuda_conv2d_d1_forward_ok": (i32, [C.POINTER(ConvGeom)]),
     "pcuda_conv2d_dgrad": (i32, [C.POINTER(ConvGeom), i32, C.POINTER(Src), vp, C.POINTER(Dst), i32, vp]),
     "pcuda_conv2d_dgrad_tiles": (i32, [C.POINTER(ConvGeom), i32]),
     "pcuda_conv2d_dgrad_bnred": (i32, [C.POINTER(ConvGeom), i32, C.POINTER(Src), vp, C.POINTER(Dst), i32, vp, i64, i64, vp,

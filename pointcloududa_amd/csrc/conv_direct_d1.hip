@@ -424,6 +424,194 @@ bool d5_geom(const pcuda_conv_geom* g) {
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------
+// Forward of the discriminators' first layer on the matrix cores WITHOUT the unfolded tensor (round 4).  The layer ran as
+// unfold_taps_kernel (the 16 taps of the <= 5 input channels written out as 64 channels at 129x129: 136 MB per pass) + a
+// 1x1 convolution over that tensor: 66 + 87 us for a layer that reads 33 MB and writes 136 MB.  Here the reduction index is
+// (channel, tap): one MFMA k-step per input channel, its 16 values the 4x4 taps.  A lane (output pixel r, k-half h) needs
+// the taps ky in {2h, 2h + 1}, kx = 0 .. 3 of its pixel: two runs of four consecutive input floats -- read straight from
+// global memory (neighbouring lanes' runs overlap by half: coalesced), split, fed to the MFMA.  The 64 x 16 CIN weights sit
+// in registers as fragments for the whole kernel.  No LDS tile, no unfolded tensor; bias + LeakyReLU in the epilogue.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct D1FParams {
+  const float* x; long long x_sn, x_sc;
+  float* y; long long y_sn, y_sc;
+  const uint16_t* wpack; int rec;      // forward layout: [16 taps][64 rows][rec], lo plane at + 32 (bf16x3)
+  const float* bias; float slope;
+  int n, h, w, oh, ow;
+  int tiles_per_image, tiles;
+};
+
+template <bool X3, int CIN>
+__global__ __launch_bounds__(256) void d1_fwd_kernel(const D1FParams p) {
+  __shared__ uint4 wfrag[2][CIN * 2 * 64];      // [plane][(k-step, row block) x lane]: the A fragments, built once per workgroup
+  __shared__ float sbias[64];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {
+    uint16_t* const wf = (uint16_t*)&wfrag[0][0];
+    for (int e = tid; e < CIN * 2 * 64 * 8; e += 256) {
+      const int j = e & 7, ln = (e >> 3) & 63, cb = (e >> 9) & 1, ks = e >> 10;
+      const int tap = 8 * (ln >> 5) + j, co = cb * 32 + (ln & 31);
+      const uint16_t* wq = p.wpack + ((long long)tap * 64 + co) * p.rec + ks;
+      wf[e] = wq[0];
+      if (X3) wf[CIN * 2 * 64 * 8 + e] = wq[32];
+      PCUDA_KEEP(wq);      // (VMEM address rule, common.h)
+    }
+  }
+  if (tid < 64) {
+    const float* bq = p.bias ? p.bias + tid : nullptr;
+    sbias[tid] = bq ? *bq : 0.f;
+    PCUDA_KEEP(bq);
+  }
+  __syncthreads();
+  bf16x8 ah[CIN][2], al[CIN][2];
+#pragma unroll
+  for (int ks = 0; ks < CIN; ++ks)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      ah[ks][cb] = __builtin_bit_cast(bf16x8, wfrag[0][(ks * 2 + cb) * 64 + lane]);
+      al[ks][cb] = ah[ks][cb];
+      if (X3) al[ks][cb] = __builtin_bit_cast(bf16x8, wfrag[1][(ks * 2 + cb) * 64 + lane]);
+    }
+
+  const int opix = p.oh * p.ow;
+  for (int tile = blockIdx.x * 4 + w; tile < p.tiles; tile += gridDim.x * 4) {
+    const int img = tile / p.tiles_per_image, pix = (tile - img * p.tiles_per_image) * 32 + r;
+    const bool pv = pix < opix;
+    const int pc = min(pix, opix - 1);
+    const int oy = pc / p.ow, ox = pc - oy * p.ow;
+    // this lane's two input rows (ky = 2 h, 2 h + 1) and its run of four columns (kx = 0 .. 3), two float2 pieces
+    const int ix0 = 2 * ox - 2;
+    const bool cv0 = (unsigned)ix0 < (unsigned)p.w, cv1 = (unsigned)(ix0 + 2) < (unsigned)p.w;      // (w even: a piece is in or out whole)
+    const int cx0 = cv0 ? ix0 : 0, cx1 = cv1 ? ix0 + 2 : 0;
+    int rowo[2];
+    bool rv[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int iy = 2 * oy - 2 + 2 * h + q;
+      rv[q] = (unsigned)iy < (unsigned)p.h;
+      rowo[q] = (rv[q] ? iy : 0) * p.w;
+    }
+    const float* xp = p.x + (long long)img * p.x_sn;
+    f32x16 acc[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
+    float2 v[CIN][2][2];
+    const float* pa[CIN][2][2];      // (kept alive behind the loads: VMEM address rule, common.h)
+#pragma unroll
+    for (int ks = 0; ks < CIN; ++ks)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float* rp = xp + (long long)ks * p.x_sc + rowo[q];
+        pa[ks][q][0] = rp + cx0;
+        pa[ks][q][1] = rp + cx1;
+        v[ks][q][0] = *(const float2*)pa[ks][q][0];
+        v[ks][q][1] = *(const float2*)pa[ks][q][1];
+      }
+#pragma unroll
+    for (int ks = 0; ks < CIN; ++ks) {
+      float t[8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        t[4 * q + 0] = (rv[q] & cv0) ? v[ks][q][0].x : 0.f; t[4 * q + 1] = (rv[q] & cv0) ? v[ks][q][0].y : 0.f;
+        t[4 * q + 2] = (rv[q] & cv1) ? v[ks][q][1].x : 0.f; t[4 * q + 3] = (rv[q] & cv1) ? v[ks][q][1].y : 0.f;
+      }
+      uint4 hi, lo = make_uint4(0, 0, 0, 0);
+      if (X3) {
+        split2(t[0], t[1], hi.x, lo.x); split2(t[2], t[3], hi.y, lo.y);
+        split2(t[4], t[5], hi.z, lo.z); split2(t[6], t[7], hi.w, lo.w);
+      } else {
+        hi.x = pack_bf16x2(t[0], t[1]); hi.y = pack_bf16x2(t[2], t[3]);
+        hi.z = pack_bf16x2(t[4], t[5]); hi.w = pack_bf16x2(t[6], t[7]);
+      }
+      const bf16x8 bh = __builtin_bit_cast(bf16x8, hi), bl = __builtin_bit_cast(bf16x8, lo);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        if (X3) {
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][cb], bh, acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][cb], bl, acc[cb], 0, 0, 0);
+        }
+        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][cb], bh, acc[cb], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < CIN; ++ks)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) { PCUDA_KEEP(pa[ks][q][0]); PCUDA_KEEP(pa[ks][q][1]); }
+    // epilogue: register i of row block cb = output channel cb 32 + (i & 3) + 8 (i >> 2) + 4 h, the lane = the pixel:
+    // 32 lanes store 128 contiguous bytes of one channel plane
+    float* yp = p.y + (long long)img * p.y_sn + pc;
+    if (pv) {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int co = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          float o = acc[cb][i] + sbias[co];
+          o = o > 0.f ? o : o * p.slope;
+          yp[(long long)co * p.y_sc] = o;
+        }
+    }
+  }
+}
+
+}  // namespace
+
+static bool d1_fwd_on(const pcuda_conv_geom* g) {
+  static int off = -1;
+  if (off < 0) { const char* e = getenv("PCUDA_NO_D1FWD"); off = (e && atoi(e)) ? 1 : 0; }
+  return !off && direct_enabled(16) && d1_geom(g) && g->cout == 64;
+}
+
+// 1: pcuda_conv2d_forward runs this geometry on d1_fwd_kernel (given plain NCHW fp32 tensors, 8-byte aligned planes): the
+// caller then skips the unfold + 1x1 form of the layer (GAN.py's first layer)
+extern "C" int pcuda_conv2d_d1_forward_ok(const pcuda_conv_geom* g) { return (g && d1_fwd_on(g)) ? 1 : 0; }
+
+// returns 1 when it took the launch (*rc = status)
+int direct_d1_forward(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const void* packed_w, const float* bias,
+                      float slope, const pcuda_dst* y, float* bn_partials, hipStream_t s, int* rc) {
+  *rc = PCUDA_OK;
+  if (!d1_fwd_on(g) || bn_partials || x->scale1 || x->rec || y->rec ||
+      x->c1 < g->cin || y->c1 < g->cout)
+    return 0;
+  if ((((uintptr_t)x->p1) & 7) || (x->sn1 & 1) || (x->sc1 & 1)) return 0;      // (float2 pieces at even columns)
+  const bool x3 = prec == PCUDA_PREC_BF16X3;
+  D1FParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = x->p1; p.x_sn = x->sn1; p.x_sc = x->sc1;
+  p.y = y->p1; p.y_sn = y->sn1; p.y_sc = y->sc1;
+  p.wpack = (const uint16_t*)packed_w; p.rec = ig_rec_bytes(x3) / 2;
+  p.bias = bias; p.slope = slope;
+  p.n = g->n; p.h = g->in_h; p.w = g->in_w; p.oh = g->out_h; p.ow = g->out_w;
+  p.tiles_per_image = (g->out_h * g->out_w + 31) / 32;
+  p.tiles = p.tiles_per_image * g->n;
+  const double flops = 2.0 * g->n * (double)g->out_h * g->out_w * g->cout * (double)g->cin * 16;
+  char tag[96];
+  snprintf(tag, sizeof(tag), "direct d1 fwd (mfma) n%d cin%d cout%d %dx%d", g->n, g->cin, g->cout, g->in_h, g->in_w);
+  ProfScope prof(PCUDA_FAM_CONV_FWD, flops, s, tag);
+  int grid = (p.tiles + 3) / 4;
+  if (grid > 2048) grid = 2048;
+#define D1F(X3_, C_) hipLaunchKernelGGL((d1_fwd_kernel<X3_, C_>), dim3(grid), dim3(256), 0, s, p)
+#define D1F_C(X3_)                                                                                           \
+  do {                                                                                                        \
+    switch (g->cin) {                                                                                         \
+      case 1: D1F(X3_, 1); break; case 2: D1F(X3_, 2); break; case 3: D1F(X3_, 3); break;                    \
+      case 4: D1F(X3_, 4); break; default: D1F(X3_, 5); break;                                                \
+    }                                                                                                         \
+  } while (0)
+  if (x3) D1F_C(true); else D1F_C(false);
+#undef D1F_C
+#undef D1F
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { pcuda_set_error("d1_fwd_kernel: %s", hipGetErrorString(e)); *rc = PCUDA_E_LAUNCH; }
+  return 1;
+}
+
 int direct_d5_forward(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const void* packed_w, const float* bias,
                       float slope, const pcuda_dst* y, float* bn_partials, hipStream_t s, int* rc) {
   *rc = PCUDA_OK;

@@ -195,5 +195,7 @@ int wgrad3_try(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const flo
                float* dw, float* db, int accumulate, void* workspace, hipStream_t s, pcuda_reduce_job* defer, int* rc);
 int launch_wgrad_reduce(const float* partial, long long numel, int ksplit, float* dw, int accumulate, const float* db_partial,
                         long long nb, float* db, hipStream_t s);
+int direct_d1_forward(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const void* packed_w, const float* bias,
+                      float slope, const pcuda_dst* y, float* bn_partials, hipStream_t s, int* rc);
 int direct_d5_forward(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const void* packed_w, const float* bias,
                       float slope, const pcuda_dst* y, float* bn_partials, hipStream_t s, int* rc);

@@ -528,6 +528,7 @@ extern "C" int pcuda_conv2d_forward(const pcuda_conv_geom* g, int prec, const pc
                        bn_partials, (hipStream_t)s, &rc))
       return rc;
     if (direct_d5_forward(g, prec, x, packed_w, bias, slope, y, bn_partials, (hipStream_t)s, &rc)) return rc;
+    if (direct_d1_forward(g, prec, x, packed_w, bias, slope, y, bn_partials, (hipStream_t)s, &rc)) return rc;
   }
   IgemmParams p;
   memset(&p, 0, sizeof(p));

@@ -697,6 +697,12 @@ def bilinear_bwd(dy, h, w):
     return dx
 
 
+def d1_forward_direct(op, n, h, w):
+    """True where ``op.forward`` runs on the direct first-layer kernel (pcuda_conv2d_d1_forward_ok): no unfolded tensor"""
+    g = op.geom(n, h, w)
+    return bool(L.lib().pcuda_conv2d_d1_forward_ok(C.byref(g)))
+
+
 def unfold_taps(x, k, stride, pad, dil=1):
     """[n,c,h,w] -> [n,c*k*k,oh,ow]: every tap of a k x k window as its own channel (zero outside the image)"""
     n, c, _, xsn, xsc = _planes(x)

@@ -31,7 +31,7 @@ def _chain_forward(module, x, weights, biases, outs=None):
         sizes.append((h, w))
         wt = weights[li].view(op.cout, op.cin, op.k, op.k)
         dst = None if outs is None else outs[li]
-        if li == 0 and module._fold1 is not None:
+        if li == 0 and module._fold1 is not None and not (cur.is_contiguous() and K.d1_forward_direct(op, cur.shape[0], h, w)):
             # a handful of input channels: unfold the taps into channels and run the layer as a 1x1 convolution
             # whose 32-deep reduction chunks are full (16 taps x 4 of 32 channels otherwise)
             unfolded = K.unfold_taps(cur, op.k, op.stride, op.pad, op.dil)

@@ -15,6 +15,7 @@ CASES = {  # name: (n, cin, cout, h, w, k, s, p, d, up)
     "g256": (32, 256, 256, 32, 32, 3, 1, 1, 1, False),
     "b512": (32, 512, 512, 16, 16, 3, 1, 1, 1, False),
     "b512d4": (32, 512, 512, 16, 16, 3, 1, 4, 4, False), "b512d8": (32, 512, 512, 16, 16, 3, 1, 8, 8, False),
+    "d1": (32, 4, 64, 256, 256, 4, 2, 2, 1, False), "md1": (32, 4, 64, 224, 224, 4, 2, 2, 1, False),
     "d2": (32, 64, 128, 129, 129, 4, 2, 2, 1, False),
     "d3": (32, 128, 256, 65, 65, 4, 2, 2, 1, False),
     # even-sized twins of the discriminator layers ("Round 3" item 10: what they measure is tile fit)
