@@ -295,7 +295,12 @@ int plan_igemm_mode(int rows, int lh, int lw, int in_h, int in_w, int in_step, c
       // in 1/64ths); then two pixel blocks per wave
       const long long slots = (long long)pl.tiles_x * pl.tiles_y * TP;
       const long long halo = (long long)pl.x_cap * 64 / TP;
-      const long long key = (slots << 24) + ((pl.tw & 31) ? (1ll << 20) : 0) + (halo << 8) + (npb == 1 ? 1 : 0);
+      // (then the number of weight groups per stage: every group is a copy and a barrier pair; the 224x224 network's 29x29
+      // discriminator maps took a 256-pixel tile whose halo left room for ONE tap of weights per group, 16 groups, over a
+      // 128-pixel tile with eight)
+      const long long groups = (taps.n + pl.tg - 1) / pl.tg;
+      const long long key = (slots << 28) + ((groups > 3 ? groups : 3) << 22) + ((pl.tw & 31) ? (1ll << 20) : 0) + (halo << 8) +
+                            (npb == 1 ? 1 : 0);
       if (best_key < 0 || key < best_key) { best_key = key; *best = pl; }
     }
   }
@@ -317,7 +322,9 @@ int plan_igemm(int rows, int red, int n, int lh, int lw, int in_h, int in_w, int
   const int rc8 = plan_igemm_mode(rows, lh, lw, in_h, in_w, in_step, taps, x3, 2, &p8);
   if (rc8 < 0 || !p8.w8) { *best = p0; return rc0; }
   if (rc0 < 0) { *best = p8; return rc8; }
-  const long long items = (long long)n * p0.tiles_x * p0.tiles_y * cdiv(rows, 32 * ig_co_blks(rows));
+  // (counted on the coarser of the two tilings: the four-wave plan may prefer 128-pixel tiles for their weight groups)
+  const long long t0 = (long long)p0.tiles_x * p0.tiles_y, t8 = (long long)p8.tiles_x * p8.tiles_y;
+  const long long items = (long long)n * (t0 < t8 ? t0 : t8) * cdiv(rows, 32 * ig_co_blks(rows));
   // (one chunk, one co-tile, every tap resident: the eight-wave kernel loads the weights once per workgroup)
   const bool wstay = rows <= 64 && taps.n <= p8.tg && single_chunk;
   const bool use8 = p0.lds > 81920 || items <= 320 || (wstay && ig_wstay_mode());

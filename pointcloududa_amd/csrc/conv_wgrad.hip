@@ -177,7 +177,13 @@ WgradPlan plan_wgrad(const pcuda_conv_geom* g) {
         const long long cap = halo < clipped ? halo : clipped;
         if (cap * IG_REC_BYTES * 2 + (long long)w.co_tile * WG_ZROW * 2 > (long long)LDS_HARD) continue;
       }
-      const long long key = ((long long)cdiv(g->out_w, tw) * cdiv(g->out_h, th) << 24) + ((tw & 31) ? (1ll << 20) : 0) + halo;
+      // (a staged tile of more than 768 pixels runs unpipelined -- no register prefetch, four waves: the 16-tap layers of the
+      // 224x224 network's 57-wide maps took tw = 64 over tw = 57 for its aligned rows and ran at half the rate)
+      const long long ih2 = (th - 1) * g->stride + span + 1, iw2 = (tw - 1) * g->stride + span + 1;
+      const long long clipped2 = (ih2 < g->in_h ? ih2 : g->in_h) * (iw2 < g->in_w ? iw2 : g->in_w) + 1;
+      const long long staged = (clipped2 * 2 <= halo) ? clipped2 : halo;
+      const long long key = ((long long)cdiv(g->out_w, tw) * cdiv(g->out_h, th) << 24) + (staged > 768 ? (1ll << 22) : 0) +
+                            ((tw & 31) ? (1ll << 20) : 0) + halo;
       if (best_key < 0 || key < best_key) { best_key = key; w.tw = tw; w.th = th; }
     }
   }
