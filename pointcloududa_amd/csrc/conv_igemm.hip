@@ -254,7 +254,7 @@ int plan_lds(bool x3, int co_tile, int x_cap, int ntaps, int mode, int* tg_out, 
 // Minimises the number of MFMA pixel slots (tiles x slots per tile); ties prefer 32-pixel-aligned rows
 // (128-B output segments), two pixel blocks per wave, wider tiles.
 int plan_igemm_mode(int rows, int lh, int lw, int in_h, int in_w, int in_step, const TapSet& taps, bool x3,
-                    int mode_env, IgemmPlan* best) {
+                    int mode_env, IgemmPlan* best, int n = 0) {
   const int co_tile = 32 * ig_co_blks(rows);
   long long best_key = -1;
   for (int npb = 2; npb >= 1; --npb) {
@@ -299,8 +299,14 @@ int plan_igemm_mode(int rows, int lh, int lw, int in_h, int in_w, int in_step, c
       // discriminator maps took a 256-pixel tile whose halo left room for ONE tap of weights per group, 16 groups, over a
       // 128-pixel tile with eight)
       const long long groups = (taps.n + pl.tg - 1) / pl.tg;
-      const long long key = (slots << 28) + ((groups > 3 ? groups : 3) << 22) + ((pl.tw & 31) ? (1ll << 20) : 0) + (halo << 8) +
-                            (npb == 1 ? 1 : 0);
+      // (eight-wave plans only: fewer (tile, co-tile) items than compute units -- the 16x16 maps at a per-rank batch of 16 --
+      // rank behind the 128-pixel tiling that doubles them)
+      const long long items = (long long)n * pl.tiles_x * pl.tiles_y * cdiv(rows, co_tile);
+      static int nofill = -1;      // PCUDA_NO_UNDERFILL=1: without this term (A/B)
+      if (nofill < 0) { const char* e = getenv("PCUDA_NO_UNDERFILL"); nofill = (e && atoi(e)) ? 1 : 0; }
+      const long long underfill = (!nofill && n > 0 && items < 256) ? (256 - items + 63) / 64 : 0;      // 0 .. 4, in quarters of the chip
+      const long long key = (slots << 28) + (underfill << 25) + ((groups > 3 ? groups : 3) << 22) + ((pl.tw & 31) ? (1ll << 20) : 0) +
+                            (halo << 8) + (npb == 1 ? 1 : 0);
       if (best_key < 0 || key < best_key) { best_key = key; *best = pl; }
     }
   }
@@ -319,7 +325,7 @@ int plan_igemm(int rows, int red, int n, int lh, int lw, int in_h, int in_w, int
   const int rc0 = plan_igemm_mode(rows, lh, lw, in_h, in_w, in_step, taps, x3, mode_env == 2 ? 0 : mode_env, &p0);
   if (mode_env != 2) { *best = p0; return rc0; }
   IgemmPlan p8;
-  const int rc8 = plan_igemm_mode(rows, lh, lw, in_h, in_w, in_step, taps, x3, 2, &p8);
+  const int rc8 = plan_igemm_mode(rows, lh, lw, in_h, in_w, in_step, taps, x3, 2, &p8, n);
   if (rc8 < 0 || !p8.w8) { *best = p0; return rc0; }
   if (rc0 < 0) { *best = p8; return rc8; }
   // (counted on the coarser of the two tilings: the four-wave plan may prefer 128-pixel tiles for their weight groups)
