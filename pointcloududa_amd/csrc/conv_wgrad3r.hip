@@ -31,7 +31,8 @@ struct W3RParams {
   float* db_partial;      // [slices][cout] or NULL
   int n_ci_tiles, tiles;  // 32 x 32 blocks of dW
   int strips;             // W / 32
-  int npairs;             // n * strips: (image, 32-pixel strip) pairs
+  int rsplit;             // row blocks per strip (small batches: more workgroups)
+  int npairs;             // n * strips * rsplit: (image, 32-pixel strip, row block) items
   int pairs_per_slice;
   int xcd;
   int dbg;                // PCUDA_W3RDBG (timing experiments): 1 loads only once per pair, 2 no MFMAs, 4 no conversion
@@ -99,12 +100,16 @@ __global__ __launch_bounds__(256, 1) void wgrad3r_kernel(const W3RParams p) {
   // a workgroup's four waves: the two 16-pixel halves of a 32-pixel strip (one 128-byte line of every row: both halves are
   // requested at about the same time, the line is fetched once) x the upper / lower half of the rows
   const int wx = w & 1, wy = w >> 1;
-  const int ya = (int)((long long)p.H * wy / 2), yb = (int)((long long)p.H * (wy + 1) / 2);
-  const int nrows = yb - ya;
 
   const int pair0 = slice * p.pairs_per_slice, pair1 = min(p.npairs, pair0 + p.pairs_per_slice);
   for (int pair = pair0; pair < pair1; ++pair) {
-    const int img = pair / p.strips, x0 = (pair - img * p.strips) * 32 + 16 * wx;
+    const int per = p.strips * p.rsplit;
+    const int img = pair / per, prem = pair - img * per, strip = prem / p.rsplit, rb = prem - strip * p.rsplit;
+    const int x0 = strip * 32 + 16 * wx;
+    // this wave's rows: the upper / lower half of the item's row block
+    const int y_lo = (int)((long long)p.H * rb / p.rsplit), y_hi = (int)((long long)p.H * (rb + 1) / p.rsplit);
+    const int ya = y_lo + (y_hi - y_lo) * wy / 2, yb = y_lo + (y_hi - y_lo) * (wy + 1) / 2;
+    const int nrows = yb - ya;
     const float* zrow = p.dz + (long long)img * p.dz_sn + (long long)co * p.dz_sc + x0 + 8 * h;
     const float* xrow = xbase + (long long)img * x_sn + (long long)cl * x_sc + x0 + 8 * h;
     // the pixel beside the strip: left of it for the lower half-wave, right of it for the upper one
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3r_kernel(const W3RParams p) {
 }
 
 struct W3RPlan {
-  int n_co_tiles, n_ci_tiles, strips, npairs, pairs_per_slice, slices;
+  int n_co_tiles, n_ci_tiles, strips, rsplit, npairs, pairs_per_slice, slices;
 };
 
 // PCUDA_WGRAD3R: 0 off, 1 (default) the layers it was measured faster on, 2 every eligible layer (tests, micro-benchmarks).
@@ -332,7 +337,10 @@ W3RPlan w3r_plan(const pcuda_conv_geom* g) {
   w.n_ci_tiles = cdiv(g->cin, 32);
   const int tiles = w.n_co_tiles * w.n_ci_tiles;
   w.strips = g->in_w / 32;
-  w.npairs = g->n * w.strips;
+  // (small batches: row blocks until there is a workgroup per compute unit, at least 16 rows per wave)
+  w.rsplit = 1;
+  while ((long long)g->n * w.strips * w.rsplit * tiles < 256 && g->in_h / (w.rsplit * 2) >= 32) w.rsplit *= 2;
+  w.npairs = g->n * w.strips * w.rsplit;
   // one workgroup per CU (four waves with 512 registers each): ~512 workgroups = two rounds; slabs below 32 MB
   static int tgt = -1;
   if (tgt < 0) { const char* e = getenv("PCUDA_W3R_BLOCKS"); tgt = e ? atoi(e) : 512; }
@@ -372,7 +380,7 @@ int wgrad3r_try(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const fl
   p.partial = (float*)workspace;
   p.db_partial = db ? (float*)workspace + (size_t)w.slices * welems : nullptr;
   p.n_ci_tiles = w.n_ci_tiles; p.tiles = w.n_co_tiles * w.n_ci_tiles;
-  p.strips = w.strips; p.npairs = w.npairs; p.pairs_per_slice = w.pairs_per_slice;
+  p.strips = w.strips; p.rsplit = w.rsplit; p.npairs = w.npairs; p.pairs_per_slice = w.pairs_per_slice;
   const long long nwg = (long long)p.tiles * w.slices;
   p.xcd = (nwg >= 16 && (nwg & 7) == 0) ? 1 : 0;
   {
