@@ -155,9 +155,8 @@ def test_dgrad_with_fused_bn_backward_reduce(dev, shape):
     dx = base.to(dev).clone() if acc else None
     dx, red = op.dgrad(gz.to(dev), w.to(dev), h, w_, dx=dx, accumulate=acc, bnred=(a.to(dev), st))
     assert rel_err(dx, g_ref.float()) < 1e-4
-    if h < 128:          # few tiles: the one-workgroup-per-CU kernel takes the layer and the caller reduces separately
-        assert red is None
-        return
+    if h < 128 and red is None:      # few tiles: where the one-workgroup-per-CU kernel takes the layer the caller reduces separately
+        return                       # (round 4's plan rules give this geometry to the transposed-epilogue kernel: checked below)
     assert red is not None, "this geometry runs on the transposed-epilogue kernel"
     part, nt = red
     got = part[:nt].double().sum(0).cpu()
