@@ -198,3 +198,28 @@ def test_decoder_reduce_fusions(dev):
     got = part[:nt].double().sum(0).cpu()
     assert rel_err(dx, g_ref.float()) < 1e-4
     assert rel_err(got[:, 0], g_ref.sum((0, 2, 3))) < 1e-4 and rel_err(got[:, 1], (g_ref * ahat).sum((0, 2, 3))) < 1e-4
+
+
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 1e-4), ("bf16", 2e-2)])
+@pytest.mark.parametrize("n,cin,h,w_", [(2, 4, 64, 64), (3, 5, 34, 72), (1, 1, 6, 8), (2, 3, 130, 256), (2, 2, 18, 40)])
+def test_discriminator_first_layer_forward_reads_taps_from_the_image(dev, prec, tol, n, cin, h, w_):
+    """GAN.py:97 (<= 5 maps -> 64 channels, 4x4 / stride 2 / pad 2, bias, LeakyReLU 0.2) on d1_fwd_kernel -- one MFMA k-step
+    per input channel, the 16 taps read straight from the image -- against the CPU reference: every channel count the
+    kernel is instantiated for, maps whose last 32-pixel tile is partial, borders on all four sides; and the library
+    says it takes these geometries (pcuda_conv2d_d1_forward_ok), so that no unfolded tensor is built for them"""
+    from pointcloududa_amd import kernels as K
+    K.set_precision(prec)
+    try:
+        rng = np.random.default_rng(cin * 100 + h)
+        x = torch.from_numpy(rng.normal(0, 1, (n, cin, h, w_)).astype(np.float32))
+        w = torch.from_numpy(rng.normal(0, 0.1, (64, cin, 4, 4)).astype(np.float32))
+        b = torch.from_numpy(rng.normal(0, 0.1, (64,)).astype(np.float32))
+        ref = F.leaky_relu(F.conv2d(x, w, b, stride=2, padding=2), 0.2)
+        op = K.ConvOp(cin, 64, 4, stride=2, pad=2)
+        assert K.d1_forward_direct(op, n, h, w_)
+        y, _, _ = op.forward(x.to(dev), w.to(dev), b.to(dev), 0.2, h, w_)
+        assert y.shape == ref.shape and rel_err(y, ref) < tol
+        y2, _, _ = op.forward(x.to(dev), w.to(dev), None, 1.0, h, w_)            # no bias, no activation
+        assert rel_err(y2, F.conv2d(x, w, None, stride=2, padding=2)) < tol
+    finally:
+        K.set_precision("bf16x3")
