@@ -15,6 +15,16 @@ for wl in unet_d2 mmwhs_uda uda_512 mscmrseg_224; do
   python3 bench.py --workload $wl --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_$wl.json; echo "$wl: $(cut -c1-160 gpurun_out/${TAG}_bench_$wl.json)"
 done
 python3 bench.py --precision bf16 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_full_uda_bf16.json; echo "bf16: $(cut -c1-160 gpurun_out/${TAG}_bench_full_uda_bf16.json)"
+python3 bench.py 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_line.json      # (the default command's line, with cpu_baseline and the traffic of THIS build)
+# the N > 1 code path on one GPU: RCCL all-reduces in a one-rank group (eager, then replayed from two hipGraphs), and the
+# control flow of --gpus 2 with two ranks sharing the GPU over gloo (a rehearsal, not a measurement)
+PCUDA_FORCE_COLLECTIVES=1 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_forced_collectives_1rank.json
+PCUDA_GRAPH=1 PCUDA_FORCE_COLLECTIVES=1 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_forced_collectives_1rank_graph.json
+PCUDA_SHARE_GPU=1 PCUDA_DIST_BACKEND=gloo timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 6 --warmup 2 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_rehearsal_2ranks_one_gpu_gloo.json
+# per-layer table of the 224x224 workload (the table that exposed round 4's plan rules)
+PCUDA_DSTREAMS=0 PCUDA_PROF_DUMP=gpurun_out/${TAG}_layers224.csv python3 bench.py --workload mscmrseg_224 --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python3 scripts/layer_table.py gpurun_out/${TAG}_layers224.csv 60 > gpurun_out/${TAG}_layer_table_224.txt
+PCUDA_TIMELINE=1 python3 scripts/step_timeline.py > gpurun_out/${TAG}_step_timeline.txt 2>&1
 CASES="g32 g64 g128 g256 b512 d2 d4" TAG=$TAG NSETS=2 bash scripts/pmc_conv.sh > gpurun_out/${TAG}_pmc_conv.log 2>&1; echo "pmc_conv rc=$?"
 python3 scripts/mfma_table.py gpurun_out/${TAG}_pmc_conv.csv gpurun_out/${TAG}_mfma_counters.csv > /dev/null; echo "mfma table rc=$?"
 TAG=$TAG bash scripts/pmc_layers.sh > gpurun_out/${TAG}_pmc_layers.log 2>&1; echo "pmc_layers rc=$?"
