@@ -46,6 +46,8 @@ class DeviceBatches:
         self.slots = [dict() for _ in range(self.depth + 1)]      # pinned buffers, reused round-robin
         self.free_ev = [None] * (self.depth + 1)
         self.queue, self.n = [], 0
+        self.done = False          # latched at the first StopIteration: the reference's generators START A NEW EPOCH when
+        #                            asked again (data_generator_mscmrseg.py:281-283 resets the count as it raises)
 
     @staticmethod
     def _as_tensor(a):
@@ -71,9 +73,12 @@ class DeviceBatches:
         return buf.to(self.dev, non_blocking=True)
 
     def _fetch(self) -> bool:
+        if self.done:
+            return False
         try:
             item = next(self.it)
         except StopIteration:
+            self.done = True
             return False
         i = self.n % len(self.slots)
         if self.free_ev[i] is not None:
@@ -252,11 +257,16 @@ def train_epoch(variant, args, model_gen, model_dis2, model_dis4, model_dis1=Non
                       (optim_gen, optim_dis1 if d1 else None, optim_dis2 if d2 else None, optim_dis4 if d4 else None),
                       args, variant)
     tr.train()
-    a_it, b_it = DeviceBatches(trainA_iterator, dev), DeviceBatches(trainB_iterator, dev)
+    # the reference walks zip(trainA_iterator, trainB_iterator): next(A), then next(B), until the first StopIteration.
+    # Read ahead over the PAIR, so that the callers' generators see exactly that sequence of next() calls (the one that
+    # runs out first is asked once and never again; the other one is not advanced past what zip would have taken)
+    pairs = DeviceBatches((tuple(a) + (b[0], None, b[2]) for a, b in zip(trainA_iterator, trainB_iterator)), dev)   # B's mask is never read (:219)
     acc: Dict[str, list] = {}
     steps = 0
-    for (img_a, mask_a, vert_a), b in zip(a_it, b_it):
-        img_b, vert_b = b[0], b[2]
+    for item in pairs:
+        if len(item) != 6:
+            raise ValueError("train_epoch: the iterators yield (image, mask, vertices) triples (data_generator_mscmrseg.py:319)")
+        img_a, mask_a, vert_a, img_b, _, vert_b = item
         if mask_a.dtype != torch.uint8:
             mask_a = mask_a.to(torch.uint8)
         out = tr.step(img_a, mask_a, vert_a, img_b, vert_b)

@@ -95,6 +95,53 @@ def test_device_batches_feed_numpy_generators_in_order():
         assert np.allclose(gz.numpy(), z.astype(np.float32))
 
 
+class _RefProtocolGenerator:
+    """The iterator protocol of the reference's data generators (data_generator_mscmrseg.py:270-319,
+    data_generator_mmwhs.py:213-274): ``__iter__`` resets the epoch count, ``__next__`` resets it AS IT RAISES
+    StopIteration -- so one more ``next()`` starts a new epoch -- and ``_index`` walks on modulo the data set."""
+
+    def __init__(self, n_batches, length=1000):
+        self.n, self.len = n_batches, length
+        self._totalcount = self._index = self.calls = 0
+
+    def __iter__(self):
+        self._totalcount = 0
+        return self
+
+    def __next__(self):
+        self.calls += 1
+        if self._totalcount >= self.n:
+            self._totalcount = 0
+            raise StopIteration
+        self._totalcount += 1
+        i, self._index = self._index, (self._index + 1) % self.len
+        return (np.full((2, 1, 4, 4), i, np.float32), np.zeros((2, 4, 4, 4), np.uint8), np.zeros((2, 300, 3), np.float32))
+
+
+def test_device_batches_stop_at_the_first_stopiteration_of_a_reference_style_generator():
+    from pointcloududa_amd._epoch import DeviceBatches
+    g = _RefProtocolGenerator(5)
+    got = [int(x[0, 0, 0, 0]) for x, _, _ in DeviceBatches(g, torch.device("cpu"))]
+    assert got == [0, 1, 2, 3, 4] and g.calls == 6             # five batches + the ONE call that raised
+    got = [int(x[0, 0, 0, 0]) for x, _, _ in DeviceBatches(g, torch.device("cpu"))]
+    assert got == [5, 6, 7, 8, 9] and g.calls == 12            # the next epoch continues where zip would have left it
+
+
+def test_paired_read_ahead_advances_the_generators_exactly_as_zip_does():
+    # train_epoch pairs the iterators as the reference's zip(trainA_iterator, trainB_iterator) does
+    from pointcloududa_amd._epoch import DeviceBatches
+    for na, nb in ((5, 7), (7, 5), (4, 4)):
+        a, b = _RefProtocolGenerator(na), _RefProtocolGenerator(nb)
+        ra, rb = _RefProtocolGenerator(na), _RefProtocolGenerator(nb)
+        for _epoch in range(3):
+            want = [(int(x[0][0, 0, 0, 0]), int(y[0][0, 0, 0, 0])) for x, y in zip(ra, rb)]
+            got = [(int(t[0][0, 0, 0, 0]), int(t[3][0, 0, 0, 0]))
+                   for t in DeviceBatches((tuple(x) + (y[0], None, y[2]) for x, y in zip(a, b)), torch.device("cpu"))]
+            assert got == want and len(got) == min(na, nb)
+            assert (a._index, a._totalcount, a.calls) == (ra._index, ra._totalcount, ra.calls)
+            assert (b._index, b._totalcount, b.calls) == (rb._index, rb._totalcount, rb.calls)
+
+
 def test_train_epoch_needs_args_like_the_reference_module_global():
     from pointcloududa_amd import train_mmwhs, train_mscmrseg
     for mod in (train_mscmrseg, train_mmwhs):

@@ -104,3 +104,47 @@ def test_valid_model_with_reference_signature(dev):
         os_ = [OV.valid_batch(ps[0], bt[0], bt[1], bt[2], cfg) for bt in batches]
         assert abs(res[key_l] - np.mean([o["loss"] for o in os_])) <= 1e-3 * abs(np.mean([o["loss"] for o in os_]))
         assert abs(res[key_d] - np.mean([o["dice"] for o in os_])) <= 1e-4
+
+
+class _RefGen:
+    """the reference generators' iterator protocol (data_generator_mscmrseg.py:270-283): the epoch count is reset AS
+    StopIteration is raised, so a consumer that asks once more starts another epoch"""
+
+    def __init__(self, batches, which):
+        self.items, self.calls, self._totalcount, self._index = list(_gen(batches, which)), 0, 0, 0
+
+    def __iter__(self):
+        self._totalcount = 0
+        return self
+
+    def __next__(self):
+        self.calls += 1
+        if self._totalcount >= len(self.items):
+            self._totalcount = 0
+            raise StopIteration
+        self._totalcount += 1
+        it = self.items[self._index % len(self.items)]
+        self._index += 1
+        return it
+
+
+def test_epoch_functions_end_with_reference_style_generators(dev):
+    """`train_epoch` / `valid_model` must consume ONE epoch of generators that restart when asked again"""
+    from oracle.synth import synth_batch
+    import pointcloududa_amd.train_mscmrseg as TM
+    cfg_kw = dict(filters=4, in_channels=1, n_class=4, pointnet=True, fc_inch=9)
+    cfg, ps, (gen, d1, d2, d4) = _nets(dev, cfg_kw, 2500)
+    og = torch.optim.Adam(gen.parameters(), lr=1e-3, betas=(0.9, 0.99))
+    mk = lambda m: torch.optim.SGD(m.parameters(), lr=2.5e-5, momentum=0.99, weight_decay=0.0005)
+    o1, o2, o4 = mk(d1), mk(d2), mk(d4)
+    TM.args = types.SimpleNamespace(d1=True, d2=True, d4=True, dr=0.01, wp=1.0)
+    batches = [synth_batch(4, 1, 4, 128, seed=2600 + i) for i in range(5)]
+    ga, gb = _RefGen(batches[:3], "A"), _RefGen(batches, "B")            # A runs out first: zip never asks B a fourth time
+    TM.train_epoch(gen, d2, d4, d1, og, o2, o4, o1, ga, gb)
+    assert int(float(next(iter(og.state_dict()["state"].values()))["step"])) == 3
+    assert (ga.calls, gb.calls) == (4, 3)
+    TM.train_epoch(gen, d2, d4, d1, og, o2, o4, o1, ga, gb)              # second epoch: B continues with its batches 3, 4, 0
+    assert (ga.calls, gb.calls, gb._index) == (8, 6, 6)
+    va, vb, vt = _RefGen(batches[:2], "A"), _RefGen(batches[:3], "A"), _RefGen(batches[:1], "A")
+    res = TM.valid_model(gen, va, vb, vt)
+    assert (va.calls, vb.calls, vt.calls) == (3, 4, 2) and np.isfinite(res["val_dice"])
