@@ -42,7 +42,16 @@ extern "C" {
 typedef void* pcuda_stream_t; /* hipStream_t */
 
 /* library / device ----------------------------------------------------------------- */
-int pcuda_version(void);                 /* ABI version of this header */
+/* ABI version of this header.  Bumped whenever an entry point's signature, a struct layout or a workspace contract
+ * changes (5, round 5: pcuda_src / pcuda_dst lost the record fields, the record-convolution entries left the library,
+ * pcuda_nn_loss_workspace_floats / pcuda_abi_struct_size / pcuda_last_kernel were added).  A binding must refuse a library
+ * whose pcuda_version() differs from the PCUDA_ABI_VERSION it was written against, and compare its own struct sizes
+ * with pcuda_abi_struct_size: the library reads these structs from caller memory. */
+#define PCUDA_ABI_VERSION 5
+int pcuda_version(void);
+/* sizeof() of an ABI struct as THIS library was compiled: 0 pcuda_conv_geom, 1 pcuda_src, 2 pcuda_dst, 3 pcuda_pooled,
+ * 4 pcuda_reduce_job; 0 for an unknown index */
+size_t pcuda_abi_struct_size(int which);
 int pcuda_device_count(void);            /* hipGetDeviceCount, 0 when no GPU */
 const char* pcuda_last_error(void);      /* text of the last failing call on this thread */
 const char* pcuda_build_hash(void);      /* sha256[:16] of the kernel sources the loaded library was compiled from */
@@ -50,6 +59,10 @@ long long pcuda_launch_count(int reset); /* kernel launches issued by this libra
 /* convolution launches that ran on a generic fallback kernel because the geometry's specialised template instantiation is
  * not in this build (csrc/variants.h: the default build holds the variants of the benchmark configurations and tests) */
 long long pcuda_fallback_count(void);
+/* "<shape tag> | <kernel>" of the most recent convolution launch issued by the calling thread (the tag a profile row
+ * carries, and which kernel family the dispatcher picked for it: igemm_pipe / igemm8 / igemm_generic / wgrad[+fallback] /
+ * wgrad3 / wgrad3r / wgrad1 / direct ...): lets a kernel-level test assert WHICH kernel produced the result it checks */
+const char* pcuda_last_kernel(void);
 
 /* kernel-family timing (HIP events recorded on the launch stream around every launch of
  * a family while enabled; used by bench.py for the live roofline figure) */
@@ -93,19 +106,11 @@ typedef struct pcuda_src {
   const float* p1; long long sn1, sc1; const float* scale1; const float* shift1;
   const float* p2; long long sn2, sc2; const float* scale2; const float* shift2;
   int c1;
-  /* record form (round 4; csrc/conv_rec.hip has the layout): rec != 0 marks BOTH sources as record tensors
-   * [N][C/32][H][W][bf16 hi x 32 | lo x 32]: p = the tensor, sn = floats (4-byte units) per image, sc = floats per 32-CHANNEL
-   * plane (32 x H x W); the channel counts are multiples of 32 and no affine is applied on load (a BatchNorm in front is
-   * folded into the packed weights and the bias); pad1 / pad2: [C/32][128 B], the record read outside the image (zeros, or
-   * -shift / scale of a folded BatchNorm); never NULL when rec is set */
-  int rec;
-  const void* pad1; const void* pad2;
 } pcuda_src;
 typedef struct pcuda_dst {
   float* p1; long long sn1, sc1;
   float* p2; long long sn2, sc2;
   int c1;
-  int rec;      /* both destinations are record tensors (sn / sc as in pcuda_src) */
 } pcuda_dst;
 
 /* packed-weight sizes (bytes) for a given geometry / precision */
@@ -339,7 +344,9 @@ int pcuda_bce_const_fwd(const float* x, long long numel, float label, float* los
 int pcuda_bce_const_bwd(const float* x, long long numel, float label, const float* gout, float gscale, float* dx,
                         pcuda_stream_t s);
 /* batch_NN_loss (loss.py:40-76): x,y [b][npts][3]; loss scalar; workspaces: idx_ws int32 [2][b][npts],
- * val_ws float [2][b][npts] + [2][b][ceil(npts / 64)] (partial sums of the minima per block of 64 points) */
+ * val_ws float [pcuda_nn_loss_workspace_floats(b, npts)] = [2][b][npts] + [2][b][ceil(npts / 64)] (partial sums of the
+ * minima per block of 64 points; ABI 5: ask the library instead of sizing it by formula) */
+size_t pcuda_nn_loss_workspace_floats(int b, int npts);
 int pcuda_nn_loss_fwd(const float* x, const float* y, int b, int npts, float* loss, int* idx_ws, float* val_ws,
                       pcuda_stream_t s);
 int pcuda_nn_loss_bwd(const float* x, const float* y, int b, int npts, const int* idx_ws, const float* val_ws,
@@ -438,33 +445,6 @@ int pcuda_adam_step_dev(float* p, const float* g, float* m, float* v, long long 
                         pcuda_stream_t s);
 int pcuda_sgd_step(float* p, const float* g, float* mom, long long numel, float lr, float momentum,
                    float weight_decay, int first_step, float grad_scale, pcuda_stream_t s);
-
-/* ------------------------------------------------------------------------------------
- * "record" activations (csrc/conv_rec.hip): the 32- / 64-channel levels of the segmenter (unet.py:23-30,116-125 at full
- * and half resolution) keep their activations in HBM as the MFMA consumes them -- per pixel and 32-channel chunk one
- * 128-byte record, bf16 hi[32] | bf16 lo[32] (hi + lo = the fp32 value to 2^-17; 4 bytes per element like fp32), tensor
- * layout [N][C/32][H][W][128 B] -- so that a convolution stages its input by LDS-DMA copies and writes its output
- * records straight from the accumulators.
- * ---------------------------------------------------------------------------------- */
-size_t pcuda_rec_bytes(int n, int c, int h, int w);
-/* NCHW fp32 (element strides sn / sc, dense planes) -> records, with an optional per-channel affine (a lazy BatchNorm:
- * scale and shift both given or both NULL); channels past c inside the last chunk are zero */
-int pcuda_rec_from_nchw(const float* x, long long sn, long long sc, int n, int c, int h, int w, const float* scale,
-                        const float* shift, void* out, pcuda_stream_t s);
-int pcuda_rec_to_nchw(const void* rec, int n, int c, int h, int w, float* y, long long sn, long long sc, pcuda_stream_t s);
-/* weights of a 3x3 / stride 1 / pad 1 layer (nn.Conv2d OIHW fp32, unet.py:23,27,116,122), optionally scaled per INPUT
- * channel (BatchNorm scale of the producing layer folded in), into the kernel's swizzled record image */
-size_t pcuda_rconv3_packed_bytes(int cout, int cin);
-int pcuda_rconv3_pack(const float* w, int cout, int cin, const float* in_scale, void* out, pcuda_stream_t s);
-int pcuda_rconv3_tiles(int n, int h, int w);       /* rows of the stats buffer */
-/* timing experiments only (PCUDA_RC_DBG=1): six per-phase cycle sums of the record convolution; read + reset */
-int pcuda_rconv3_debug_clocks(unsigned long long* out6);
-/* y = LeakyReLU_slope(conv3x3(x) + bias) on record tensors; pad_records [cin/32][128 B] is what the convolution reads
- * outside the image (zeros; or, with a folded BatchNorm, the record of -shift/scale); stats [tiles][cout][2] receives the
- * per-tile (sum, sum of squares) of the stored values (BatchNorm batch statistics, unet.py:26,30) or is NULL.
- * Needs cin, cout multiples of 32, w a multiple of 32, h a multiple of 8: PCUDA_E_UNSUPPORTED otherwise. */
-int pcuda_rconv3_forward(const void* x, int n, int cin, int h, int w, const void* pad_records, const void* wpacked,
-                         const float* bias, float slope, int cout, void* y, float* stats, pcuda_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -149,7 +149,8 @@ def adopt_optimizer(torch_opt, module, skip_prefixes=()):
     if ids != [id(p) for p in module.parameters()]:
         raise ValueError("adopt: the optimiser was not built from this module's parameters()")
     if isinstance(torch_opt, torch.optim.Adam) and not isinstance(torch_opt, torch.optim.AdamW):
-        fused = FusedAdam(module, lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g.get("weight_decay", 0.0))
+        fused = FusedAdam(module, lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g.get("weight_decay", 0.0),
+                          skip_prefixes=skip_prefixes or None)
     elif isinstance(torch_opt, torch.optim.SGD):
         fused = FusedSGD(module, lr=g["lr"], momentum=g.get("momentum", 0.0), weight_decay=g.get("weight_decay", 0.0),
                          skip_prefixes=skip_prefixes)
@@ -162,14 +163,23 @@ def adopt_optimizer(torch_opt, module, skip_prefixes=()):
     return fused
 
 
-def export_state(fused, torch_opt) -> None:
+def _state_token(torch_opt):
+    """identifies the state OBJECTS a torch.optim optimiser holds right now: ``load_state_dict`` replaces every one of them"""
+    return tuple((k_, id(v), v.data_ptr() if torch.is_tensor(v) else None)
+                 for st in torch_opt.state.values() for k_, v in sorted(st.items()))
+
+
+def export_state(fused, torch_opt):
     """the fused optimiser's state back into the caller's object: ``torch_opt.state_dict()`` is what the reference's
-    checkpoint callback saves (callbacks.py:78-80)"""
+    checkpoint callback saves (callbacks.py:78-80).  Returns a token of the exported state objects: if the caller's
+    optimiser holds other ones at the next epoch (``optimizer.load_state_dict(checkpoint)`` in between: resume, rollback),
+    that state is imported again instead of being overwritten (``_trainer_for``)."""
     if torch_opt is None or torch_opt is fused:
-        return
+        return None
     sd = fused.torch_state_dict()
     sd["param_groups"] = torch_opt.state_dict()["param_groups"]       # the caller's own groups (keys of ITS torch version)
     torch_opt.load_state_dict(sd)
+    return _state_token(torch_opt)
 
 
 # ------------------------------------------------------------------------------------------------ train_epoch
@@ -227,6 +237,7 @@ def _trainer_for(model_gen, model_dis1, model_dis2, model_dis4, opts, args, vari
             if sd["state"]:
                 cur.load_torch_state_dict(sd)
         tr._torch_opts = {"opt_gen": og, "opt_d1": o1, "opt_d2": o2, "opt_d4": o4}
+        tr._exported = {n_: _state_token(o_) for n_, o_ in tr._torch_opts.items() if o_ is not None and hasattr(o_, "param_groups")}
         model_gen._pcuda_trainer = (key, tr)
     # every epoch: the scripts mutate param_group['lr'] between epochs (train_mscmrseg.py:585-589), and -dr / -wp style
     # weights are read from args at every step in the reference
@@ -234,6 +245,11 @@ def _trainer_for(model_gen, model_dis1, model_dis2, model_dis4, opts, args, vari
         f = getattr(tr, name)
         if f is not None and o is not None and hasattr(o, "param_groups"):
             adopt_hyperparameters(f, o)
+            if _state_token(o) != tr._exported.get(name):
+                # the caller replaced the optimiser's state since the last epoch (load_state_dict of a checkpoint): continue
+                # from THAT state, as the reference's loop would
+                f.load_torch_state_dict(o.state_dict())
+                tr._exported[name] = _state_token(o)
     tr.cfg.dr, tr.cfg.wp = float(getattr(args, "dr", tr.cfg.dr)), float(getattr(args, "wp", tr.cfg.wp))
     tr._wp.fill_(tr.cfg.wp)
     for k in ("w1", "w2", "w4"):
@@ -275,7 +291,7 @@ def train_epoch(variant, args, model_gen, model_dis2, model_dis4, model_dis1=Non
         steps += 1
     for name, o in tr._torch_opts.items():
         if getattr(tr, name) is not None and o is not None and hasattr(o, "param_groups"):
-            export_state(getattr(tr, name), o)
+            tr._exported[name] = export_state(getattr(tr, name), o)
     res: Dict[str, float] = {}
     if steps:
         keys = sorted(acc)

@@ -32,12 +32,11 @@ class ReduceJob(C.Structure):      # pcuda_reduce_job (include/pcuda_hip.h)
 
 class Src(C.Structure):
     _fields_ = [("p1", vp), ("sn1", i64), ("sc1", i64), ("scale1", vp), ("shift1", vp),
-                ("p2", vp), ("sn2", i64), ("sc2", i64), ("scale2", vp), ("shift2", vp), ("c1", i32),
-                ("rec", i32), ("pad1", vp), ("pad2", vp)]
+                ("p2", vp), ("sn2", i64), ("sc2", i64), ("scale2", vp), ("shift2", vp), ("c1", i32)]
 
 
 class Dst(C.Structure):
-    _fields_ = [("p1", vp), ("sn1", i64), ("sc1", i64), ("p2", vp), ("sn2", i64), ("sc2", i64), ("c1", i32), ("rec", i32)]
+    _fields_ = [("p1", vp), ("sn1", i64), ("sc1", i64), ("p2", vp), ("sn2", i64), ("sc2", i64), ("c1", i32)]
 
 
 class Pooled(C.Structure):
@@ -52,14 +51,8 @@ _PROTOS = {
     "pcuda_build_hash": (C.c_char_p, []),
     "pcuda_launch_count": (i64, [i32]),
     "pcuda_fallback_count": (i64, []),
-    "pcuda_rec_bytes": (sz, [i32, i32, i32, i32]),
-    "pcuda_rec_from_nchw": (i32, [vp, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp]),
-    "pcuda_rec_to_nchw": (i32, [vp, i32, i32, i32, i32, vp, i64, i64, vp]),
-    "pcuda_rconv3_packed_bytes": (sz, [i32, i32]),
-    "pcuda_rconv3_pack": (i32, [vp, i32, i32, vp, vp, vp]),
-    "pcuda_rconv3_tiles": (i32, [i32, i32, i32]),
-    "pcuda_rconv3_debug_clocks": (i32, [vp]),
-    "pcuda_rconv3_forward": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, f32, i32, vp, vp, vp]),
+    "pcuda_abi_struct_size": (sz, [i32]),
+    "pcuda_last_kernel": (C.c_char_p, []),
     "pcuda_prof_enable": (i32, [i32]),
     "pcuda_prof_reset": (i32, []),
     "pcuda_prof_read": (i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]),
@@ -123,6 +116,7 @@ _PROTOS = {
     "pcuda_jaccard_bwd": (i32, [vp, i32, i32, i32, i64, f32, vp, vp, vp, vp]),
     "pcuda_bce_const_fwd": (i32, [vp, i64, f32, vp, vp, vp]),
     "pcuda_bce_const_bwd": (i32, [vp, i64, f32, vp, f32, vp, vp]),
+    "pcuda_nn_loss_workspace_floats": (sz, [i32, i32]),
     "pcuda_nn_loss_fwd": (i32, [vp, vp, i32, i32, vp, vp, vp, vp]),
     "pcuda_nn_loss_bwd": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp]),
     "pcuda_dice_metric": (i32, [vp, vp, i32, i32, i64, vp, vp, sz, vp]),
@@ -154,6 +148,7 @@ _lib = None
 
 
 PCUDA_E_UNSUPPORTED = -2      # include/pcuda_hip.h
+PCUDA_ABI_VERSION = 5         # include/pcuda_hip.h: the header this binding was written against
 
 
 def lib():
@@ -167,6 +162,15 @@ def lib():
         for name, (res, args) in _PROTOS.items():
             fn = getattr(handle, name)      # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
+        # a stale library (or header) would read these structs from our memory with another layout: refuse it
+        ver = handle.pcuda_version()
+        if ver != PCUDA_ABI_VERSION:
+            raise RuntimeError("libpcuda_hip.so at %s has ABI version %d, this binding is written against %d: rebuild it "
+                               "(python -c 'import __graft_entry__ as g; g.build()')" % (LIB_PATH, ver, PCUDA_ABI_VERSION))
+        for which, st in enumerate((ConvGeom, Src, Dst, Pooled, ReduceJob)):
+            if handle.pcuda_abi_struct_size(which) != C.sizeof(st):
+                raise RuntimeError("libpcuda_hip.so: sizeof(%s) is %d in the library, %d in the binding: header / library mismatch"
+                                   % (st.__name__, handle.pcuda_abi_struct_size(which), C.sizeof(st)))
         _lib = handle
     return _lib
 

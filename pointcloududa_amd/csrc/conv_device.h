@@ -349,53 +349,6 @@ __device__ __forceinline__ void xq_commit(XFast<PF>& pre, unsigned char* xhi, un
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// Record staging path (round 4): the source tensor is ALREADY in the LDS record form -- per pixel and 32-channel chunk
-// 128 bytes, bf16 hi x 32 | lo x 32 (pcuda_src::rec) -- so staging is a copy: lane slot j moves 16-byte piece
-// (tid + j NT) & 7 of halo pixel (tid + j NT) >> 3 from global memory into the pixel's 144-byte LDS record (piece c at
-// byte 16 c: the lo plane sits at + 64).  No affine, no split, no transposition: ~3 vector instructions per 16 bytes
-// against ~14 per VALUE on the fp32 paths.  Pixels outside the image read the source's pad record (zeros, or -shift /
-// scale of a folded BatchNorm); the nearest-x2 fold is a shift of the source pixel's coordinates.
-// ------------------------------------------------------------------------------------------
-typedef unsigned int xr_u32x4 __attribute__((ext_vector_type(4)));
-template <int PF>
-struct XRec {
-  xr_u32x4 v[PF * 8];
-};
-
-template <int PF, int NT = 256>
-__device__ __forceinline__ void xr_issue(XRec<PF>& pre, const pcuda_src& x, int n, int chunk, int in_h, int in_w,
-                                         int in_shift, int in_row, int oy0, int ox0, int tw, int npix, int tid) {
-  const int c0 = chunk * 32;
-  const bool first = c0 < x.c1;
-  const int cb = (first ? c0 : c0 - x.c1) >> 5;
-  const char* base = (const char*)(first ? x.p1 + (long long)n * x.sn1 + (long long)cb * x.sc1
-                                         : x.p2 + (long long)n * x.sn2 + (long long)cb * x.sc2);
-  const char* padp = (const char*)(first ? x.pad1 : x.pad2) + cb * 128;
-  const unsigned m = (1u << 20) / (unsigned)tw + 1u;      // pix / tw = (pix * m) >> 20, exact for pix < 1024, tw < 400
-#pragma unroll
-  for (int j = 0; j < PF * 8; ++j) {
-    const int q = tid + j * NT;
-    const int pix = q >> 3, piece = q & 7;
-    const int iy = (int)(((unsigned)pix * m) >> 20), ix = pix - iy * tw;
-    const int gy = oy0 + iy, gx = ox0 + ix;
-    const bool inb = (pix < npix) & ((unsigned)gy < (unsigned)in_h) & ((unsigned)gx < (unsigned)in_w);
-    const char* src = inb ? base + ((long long)((gy >> in_shift) * in_row + (gx >> in_shift)) * 128 + piece * 16)
-                          : padp + piece * 16;
-    pre.v[j] = *(const xr_u32x4*)src;
-  }
-}
-
-template <int PF, int NT = 256, int REC = 144>
-__device__ __forceinline__ void xr_commit(const XRec<PF>& pre, unsigned char* xhi, int npix, int tid) {
-#pragma unroll
-  for (int j = 0; j < PF * 8; ++j) {
-    const int q = tid + j * NT;
-    const int pix = q >> 3, piece = q & 7;
-    if (pix < npix) *(xr_u32x4*)(xhi + (size_t)pix * REC + piece * 16) = pre.v[j];
-  }
-}
-
 // contiguous global -> LDS copy of nvec 16-B vectors (packed weights: the global image IS the LDS image).
 // Branch-free: lanes past the end re-copy the last vector (same bytes to the same address), so the
 // loads of a pass are issued back to back and no wait sits between them.  (With a guarded store the

@@ -576,7 +576,7 @@ extern "C" int pcuda_conv2d_d1_forward_ok(const pcuda_conv_geom* g) { return (g 
 int direct_d1_forward(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const void* packed_w, const float* bias,
                       float slope, const pcuda_dst* y, float* bn_partials, hipStream_t s, int* rc) {
   *rc = PCUDA_OK;
-  if (!d1_fwd_on(g) || bn_partials || x->scale1 || x->rec || y->rec ||
+  if (!d1_fwd_on(g) || bn_partials || x->scale1 ||
       x->c1 < g->cin || y->c1 < g->cout)
     return 0;
   if ((((uintptr_t)x->p1) & 7) || (x->sn1 & 1) || (x->sc1 & 1)) return 0;      // (float2 pieces at even columns)

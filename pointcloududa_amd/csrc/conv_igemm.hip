@@ -343,8 +343,7 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
   const int co_blks = ig_co_blks(p.cout);
   const int co_tile = 32 * co_blks;
   IgemmPlan pl;
-  // (record sources are staged by the four-wave pipelined kernel only)
-  if (plan_igemm(p.cout, p.cin, p.n, p.lh, p.lw, p.in_h, p.in_w, p.in_step, taps, x3, &pl, !p.x.rec) < 0)
+  if (plan_igemm(p.cout, p.cin, p.n, p.lh, p.lw, p.in_h, p.in_w, p.in_step, taps, x3, &pl, true) < 0)
     PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "igemm: no tile of this convolution fits LDS (in_step %d, tap span %d)",
                p.in_step, taps.dy_max - taps.dy_min);
   p.n_co_tiles = cdiv(p.cout, co_tile);
@@ -379,21 +378,13 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
     const int ih = (pl.clamp && pl.ih_t > p.in_h) ? p.in_h : pl.ih_t;   // rows the kernel stages (unclamped: all of the halo)
     const int pfq = (ih * ((pl.iw_t + 6) / 4) + 63) / 64;
     p.xq = (!noxq && (p.in_w & 3) == 0 && p.in_shift == 0 && pfq <= 3) ? 1 : 0;
-    p.xr = p.x.rec ? 1 : 0;
-    if (p.xr) {
-      // record sources: bf16x3 only, whole 32-channel chunks, the pipelined four-wave kernel (no fallback reads records)
-      if (!x3 || (p.cin & 31) || (p.x.c1 < p.cin && (p.x.c1 & 31)) || !p.x.pad1 || (p.x.c1 < p.cin && !p.x.pad2))
-        PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "igemm: record sources need bf16x3, channel counts in multiples of 32 and pad records");
-      p.xq = 0;
-      if (pl.w8) PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "igemm: record sources are not staged by the eight-wave kernel");
-    }
     if (p.xq) pf = pfq;
     if (pl.w8) pf = p.xq ? (ih * ((pl.iw_t + 6) / 4) + 127) / 128 : (max_pix + 511) / 512;   // 512 lanes
   }
   // PF = 3 keeps 96 prefetch registers live next to the accumulators: only with one pixel block per wave
   // (one workgroup per CU has 512 registers per lane: PF = 3 next to two pixel blocks fits there)
   // (the unpipelined fallback copies its weight groups in 512-vector passes: any tg of the plan works)
-  const bool pipe = !nopipe && p.ntaps > 0 && (p.x.rec || fast_src_ok(&p.x, p.cin)) && fast_dst_ok(&p.y, p.cout) &&
+  const bool pipe = !nopipe && p.ntaps > 0 && fast_src_ok(&p.x, p.cin) && fast_dst_ok(&p.y, p.cout) &&
                     (pf <= 2 || (pf == 3 && !pl.w8 && (pl.npb == 1 || pl.fat)));
   {   // transposed epilogue: its LDS scratch (4 waves x [32][32*npb] fp32 + the partial-sum slots) aliases the
       // X / W slabs and must end in front of the tap table behind them
@@ -416,9 +407,8 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
       }
     }
   }
-  if (p.fold && !(pipe && pl.te && !pl.w8 && pl.npb == 2 && pl.tw == 32 && pl.th == 8 && !pl.clamp && !p.xr && !p.accumulate && !p.pair))
+  if (p.fold && !(pipe && pl.te && !pl.w8 && pl.npb == 2 && pl.tw == 32 && pl.th == 8 && !pl.clamp && !p.accumulate && !p.pair))
     PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv2d_dgrad_fold: this geometry does not run on the 32 x 8-tile transposed-epilogue kernel");
-  if (p.xr && !pipe) PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "igemm: record sources need the pipelined kernel for this geometry");
   if (p.mask_a && (pl.te || p.accumulate || p.stats || p.bias || p.fold || p.y.c1 < (p.cout >> p.pair)))
     PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv2d_dgrad_lrelu: this geometry does not run on a plain-epilogue kernel");
   if (p.red_a && !(pipe && pl.te))
@@ -638,7 +628,7 @@ extern "C" int pcuda_conv2d_dgrad_lrelu(const pcuda_conv_geom* g, int prec, cons
                                         const pcuda_dst* dx, const float* a, long long a_sn, long long a_sc, float slope,
                                         pcuda_stream_t s) {
   if (!a || !dx) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_dgrad_lrelu: bad tensors");
-  if (dx->c1 < g->cin || a_sc != dx->sc1 || dx->rec || dy->rec || g->in_up)
+  if (dx->c1 < g->cin || a_sc != dx->sc1 || g->in_up)
     PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv2d_dgrad_lrelu: one NCHW destination with the activation's plane stride");
   return dgrad_impl(g, prec, dy, packed_w_dgrad, dx, 0, a, a_sn, slope, s);
 }

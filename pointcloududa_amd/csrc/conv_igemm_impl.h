@@ -295,6 +295,23 @@ __device__ __forceinline__ TileGeom tile_decode(const IgemmParams& p, int L) {
 #endif
 #endif
 
+// -DPCUDA_WEXP (timing experiments, results are wrong): PCUDA_DBG bit 8 = no weight loads / LDS writes after a workgroup's
+// first stage, bit 16 = also no barriers between weight groups (as if every tap were resident), bit 32 = no input commit
+// after the first stage: upper bounds of what weight delivery / staging can be worth in this kernel's structure.
+#ifdef PCUDA_WEXP
+#define WEXP_DECL bool wexp_first = true;
+#define WEXP_W (!(p.dbg & 8) || wexp_first)
+#define WEXP_B (!(p.dbg & 16) || wexp_first)
+#define WEXP_X (!(p.dbg & 32) || wexp_first)
+#define WEXP_END wexp_first = false;
+#else
+#define WEXP_DECL
+#define WEXP_W true
+#define WEXP_B true
+#define WEXP_X true
+#define WEXP_END
+#endif
+
 // WV = weight-copy register slots per lane and plane.  WV = 2: weight groups of <= 512 vectors, two
 // workgroups per CU.  WV = 6 / 12 (CO_TILE 32 / 64): ONE workgroup per CU with up to nine taps of weights
 // resident (512 VGPRs per lane: the whole group sits in registers between its loads and its LDS
@@ -302,9 +319,8 @@ __device__ __forceinline__ TileGeom tile_decode(const IgemmParams& p, int L) {
 // inside its MFMA phase.
 // STATS: 0 none, 1 BatchNorm partial sums of the stored values (forward), 2 BatchNorm-BACKWARD reduce partials of the
 // stored gradient against the saved activation (dgrad of a block's second convolution; transposed epilogue only)
-template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ, int STATS, bool TE, bool XR = false, bool FOLD = false>
+template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ, int STATS, bool TE, bool FOLD = false>
 __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const IgemmParams p, const int x_cap, const int total) {
-  static_assert(!XR || (X3 && !XQ), "record staging: bf16x3 records, instead of the quad path");
   static_assert(!FOLD || (TE && NPB == 2 && STATS != 1), "2x2 fold: transposed-epilogue plans with two pixel blocks (tile rows 2 w, 2 w + 1)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CO_TILE = 32 * CO_BLKS;
@@ -354,16 +370,16 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
   }
 
   f32x16 acc[CO_BLKS][NPB];
-  typename std::conditional<XR, XRec<PF>, XFast<PF>>::type pre;
+  XFast<PF> pre;
   DBG_CLK_DECL
+  WEXP_DECL
 
   int L = lo + slot, chunk = 0;
   bool have = L < hi;
   TileGeom g;
   if (have) {
     g = tile_decode<CLAMP, NPB>(p, L);
-    if constexpr (XR) xr_issue<PF>(pre, p.x, g.n, 0, p.in_h, p.in_w, p.in_shift, p.in_row, g.oy0, g.ox0, g.tw, g.npix, tid);
-    else if constexpr (XQ) xq_issue<PF>(pre, p.x, g.n, p.cin, 0, p.in_h, p.in_w, g.oy0, g.ox0, g.th, g.tw, tid);
+    if constexpr (XQ) xq_issue<PF>(pre, p.x, g.n, p.cin, 0, p.in_h, p.in_w, g.oy0, g.ox0, g.th, g.tw, tid);
     else xfast_issue<PF>(pre, p.x, g.n, p.cin, 0, p.in_h, p.in_w, p.in_shift, p.in_row, g.oy0, g.ox0, g.tw, g.npix,
                          (min(32, p.cin) + 7) >> 3, tid);
   }
@@ -373,19 +389,13 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
     DBG_CLK(7)
     __syncthreads();   // every wave is done with the previous stage's X / W / reduction scratch
     DBG_CLK(0)
-    if constexpr (XR) xr_commit<PF, 256, REC>(pre, Xhi, g.npix, tid);
-    else if constexpr (XQ) xq_commit<X3, PF, 256, REC>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.ox0, g.th, g.tw, nks * 2, tid);
+    if (WEXP_X) {
+    if constexpr (XQ) xq_commit<X3, PF, 256, REC>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.ox0, g.th, g.tw, nks * 2, tid);
     else xfast_commit<X3, PF, 256, REC>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.npix, (cvalid + 7) >> 3, nks * 2, tid);
-    DBG_CLK(1)
-    if (CLAMP && tid < RECV) {   // the record that out-of-image taps read: zeros, or the source's pad record
-      uint4 z = make_uint4(0, 0, 0, 0);
-      if constexpr (XR) {
-        const bool f1 = chunk * 32 < p.x.c1;
-        const char* pp = (const char*)(f1 ? p.x.pad1 : p.x.pad2) + (((f1 ? chunk * 32 : chunk * 32 - p.x.c1) >> 5) * 128);
-        if (tid < 8) z = *(const uint4*)(pp + tid * 16);
-      }
-      *(uint4*)(Xhi + (size_t)g.npix * REC + tid * 16) = z;
     }
+    DBG_CLK(1)
+    if (CLAMP && tid < RECV)   // the all-zero record that out-of-image taps read
+      *(uint4*)(Xhi + (size_t)g.npix * REC + tid * 16) = make_uint4(0, 0, 0, 0);
     // bias of this tile's rows (consumed by the epilogue after the last chunk): fetched here, in front of the
     // stage's other loads, so its wait never drains them
     float bias_r = 0.f;
@@ -408,7 +418,7 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
     const int tidw = tid + opaque_zero();
     WPass<false, WS> wp0;
     const int nvec0 = min(p.tg, p.ntaps) * CO_TILE * RECV;
-    wcopy_issue<false, WS>(wp0, (const uint4*)wsrc, nullptr, nvec0, 0, tidw);
+    if (WEXP_W) wcopy_issue<false, WS>(wp0, (const uint4*)wsrc, nullptr, nvec0, 0, tidw);
     // second weight group (more taps than one LDS slab holds): requested here too, IN FRONT of the input prefetch, and
     // parked in registers until the first group's MFMAs are done.  Requested behind the prefetch (vmcnt retires in
     // order) its wait was a wait for the whole next input tile to arrive from HBM, in the middle of every stage.
@@ -429,7 +439,7 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
     const int nvec1 = ngrp > 1 ? min(p.tg, p.ntaps - p.tg) * CO_TILE * RECV : 1;
     {
       const uint16_t* src1 = wsrc + (ngrp > 1 ? (long long)p.tg * slab : 0);
-      wcopy_issue<false, WS>(wp1, (const uint4*)src1, nullptr, nvec1, 0, tidw);
+      if (WEXP_W) wcopy_issue<false, WS>(wp1, (const uint4*)src1, nullptr, nvec1, 0, tidw);
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -441,9 +451,7 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
     if (nhave && nL != L) ng = tile_decode<CLAMP, NPB>(p, nL);
     // unconditional (no stage left: zero pixels, every lane out of range -> no memory traffic)
     auto issue_next = [&]() {
-      if constexpr (XR) xr_issue<PF>(pre, p.x, ng.n, nhave ? nchunk : 0, p.in_h, p.in_w, p.in_shift, p.in_row, ng.oy0, ng.ox0,
-                                     ng.tw, nhave ? ng.npix : 0, tid);
-      else if constexpr (XQ) xq_issue<PF>(pre, p.x, ng.n, p.cin, nhave ? nchunk : 0, p.in_h, p.in_w, ng.oy0, ng.ox0, nhave ? ng.th : 0,
+      if constexpr (XQ) xq_issue<PF>(pre, p.x, ng.n, p.cin, nhave ? nchunk : 0, p.in_h, p.in_w, ng.oy0, ng.ox0, nhave ? ng.th : 0,
                              ng.tw, tid);
       else xfast_issue<PF>(pre, p.x, ng.n, p.cin, nhave ? nchunk : 0, p.in_h, p.in_w, p.in_shift, p.in_row, ng.oy0,
                            ng.ox0, ng.tw, nhave ? ng.npix : 0, 4, tid);
@@ -488,8 +496,7 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
             baddr[pb] = idx * REC + h * 16;
           }
           // (a tap whose reads all fall outside the image for this wave's pixel blocks multiplies the zero record: skipped)
-          // (record sources read a pad record that need not be zero: never skipped)
-          if (!XR && __builtin_amdgcn_ballot_w64(any) == 0) continue;
+          if (__builtin_amdgcn_ballot_w64(any) == 0) continue;
         } else {
 #pragma unroll
           for (int pb = 0; pb < NPB; ++pb) baddr[pb] = bbase[pb] + tcur;
@@ -524,7 +531,7 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
       }
     };
 
-    wcopy_commit<false, WS>(wp0, Whi, nullptr, nvec0, 0, tidw);
+    if (WEXP_W) wcopy_commit<false, WS>(wp0, Whi, nullptr, nvec0, 0, tidw);
     DBG_CLK(3)
     __syncthreads();
     DBG_CLK(4)
@@ -532,31 +539,31 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
     DBG_CLK_ACC(5)
     const int nvec2 = ngrp > 2 ? min(p.tg, p.ntaps - 2 * p.tg) * CO_TILE * RECV : 1;
     if (ngrp > 1) {   // uniform
-      __syncthreads();
-      wcopy_commit<false, WS>(wp1, Whi, nullptr, nvec1, 0, tidw);   // parked since the top of the stage
+      if (WEXP_B) __syncthreads();
+      if (WEXP_W) wcopy_commit<false, WS>(wp1, Whi, nullptr, nvec1, 0, tidw);   // parked since the top of the stage
       if (DEFER) {
         __builtin_amdgcn_sched_barrier(0);   // (group 2's loads stay behind group 1's LDS writes: its registers are free then)
         const uint16_t* src2 = wsrc + (ngrp > 2 ? 2ll * p.tg * slab : 0);
-        wcopy_issue<false, WS>(wp0, (const uint4*)src2, nullptr, nvec2, 0, tidw);
+        if (WEXP_W) wcopy_issue<false, WS>(wp0, (const uint4*)src2, nullptr, nvec2, 0, tidw);
         __builtin_amdgcn_sched_barrier(0);
         issue_next();
       }
       DBG_CLK(3)
-      __syncthreads();
+      if (WEXP_B) __syncthreads();
       DBG_CLK(4)
       mfma_group(p.tg, min(p.tg, p.ntaps - p.tg));
       DBG_CLK_ACC(5)
       for (int t0 = 2 * p.tg, gi = 2; t0 < p.ntaps; t0 += p.tg, ++gi) {
         const int tgc = min(p.tg, p.ntaps - t0);
-        __syncthreads();
+        if (WEXP_B) __syncthreads();
         if (DEFER && gi == 2) {
-          wcopy_commit<false, WS>(wp0, Whi, nullptr, nvec2, 0, tidw);   // requested in front of the prefetch
-        } else {
+          if (WEXP_W) wcopy_commit<false, WS>(wp0, Whi, nullptr, nvec2, 0, tidw);   // requested in front of the prefetch
+        } else if (WEXP_W) {
           const uint16_t* src = wsrc + (long long)t0 * slab;
           wcopy<false, WS>(Whi, nullptr, (const uint4*)src, nullptr, tgc * CO_TILE * RECV, 0, tidw);
         }
         DBG_CLK(3)
-        __syncthreads();
+        if (WEXP_B) __syncthreads();
         DBG_CLK(4)
         mfma_group(t0, tgc);
         DBG_CLK_ACC(5)
@@ -884,6 +891,7 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
           }
     }
     DBG_CLK(6)
+    WEXP_END
     L = nL; chunk = nchunk; g = ng; have = nhave;
   }
   DBG_CLK_FLUSH
@@ -1157,6 +1165,7 @@ static int launch_igemm8_s(const IgemmParams& p, const IgemmPlan& pl, hipStream_
   const int total = p.n_co_tiles * p.n * p.tiles_x * p.tiles_y;
   int grid = 256;
   if (grid > total) grid = total;
+  note_kernel("igemm8");
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pl.lds, s, p, pl.x_cap, total);
   PCUDA_CHECK_LAUNCH("igemm8_kernel");
   return PCUDA_OK;
@@ -1194,6 +1203,7 @@ static int launch_igemm_t(const IgemmParams& p, int x_cap, size_t lds, hipStream
     lds_opt.mark(devbit);
   }
   const int grid = p.n_co_tiles * p.n * p.tiles_x * p.tiles_y;
+  note_kernel("igemm_generic");
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, p, x_cap);
   PCUDA_CHECK_LAUNCH("igemm_kernel");
   return PCUDA_OK;
@@ -1207,15 +1217,15 @@ static int launch_igemm_c(const IgemmParams& p, const IgemmPlan& pl, hipStream_t
                      : launch_igemm_t<X3, CO_BLKS, false, 1>(p, pl.x_cap, pl.lds, s);
 }
 
-template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ, int STATS, bool TE, bool XR = false, bool FOLD = false>
+template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ, int STATS, bool TE, bool FOLD = false>
 static int launch_pipe_s(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
-  constexpr unsigned vkey = pipe_key(X3, CO_BLKS, CLAMP, NPB, PF, XQ, STATS, TE) | (XR ? 1u << 10 : 0u) | (FOLD ? 1u << 11 : 0u);
+  constexpr unsigned vkey = pipe_key(X3, CO_BLKS, CLAMP, NPB, PF, XQ, STATS, TE) | (FOLD ? 1u << 11 : 0u);
   variant_log("pipe", vkey);
   if constexpr (!pipe_built(vkey)) {
     variant_fallback_note("igemm_pipe_kernel", vkey);
     return PCUDA_E_NOTBUILT;
   } else {
-  auto kern = igemm_pipe_kernel<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, STATS, TE, XR, FOLD>;
+  auto kern = igemm_pipe_kernel<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, STATS, TE, FOLD>;
   static DeviceOnce lds_opt;
   if (const unsigned long long devbit = pl.lds > 32 * 1024 ? lds_opt.pending() : 0ull) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_HARD);
@@ -1237,6 +1247,7 @@ static int launch_pipe_s(const IgemmParams& p, const IgemmPlan& pl, hipStream_t 
   }
   int grid = occ_cache[cls] * 256;
   if (grid > total) grid = total;
+  note_kernel(FOLD ? "igemm_pipe+fold" : (STATS == 2 ? "igemm_pipe+bnred" : "igemm_pipe"));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), pl.lds, s, p, pl.x_cap, total);
   PCUDA_CHECK_LAUNCH("igemm_pipe_kernel");
   return PCUDA_OK;
@@ -1245,31 +1256,13 @@ static int launch_pipe_s(const IgemmParams& p, const IgemmPlan& pl, hipStream_t 
 
 template <bool X3, int CO_BLKS, bool CLAMP, int NPB, int PF, int WV, bool XQ>
 static int launch_pipe_t(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s) {
-#ifdef PCUDA_XR_ALL   // (make XFLAGS=-DPCUDA_XR_ALL: every unclamped plan, for the stride-2 cases of scripts/micro/rconv_micro.py)
-  constexpr bool xr_inst = X3 && !XQ && !CLAMP;
-#else
-  constexpr bool xr_inst = X3 && !XQ && !CLAMP && NPB == 2 && PF <= 2;   // the aligned 3x3 plans
-#endif
-  if constexpr (xr_inst) {   // (the record-staging instantiations)
-    if (p.xr) {   // record sources (pcuda_src::rec)
-      if (pl.te) {
-        if (p.stats && p.red_a) return launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, false, 2, true, true>(p, pl, s);
-        return p.stats ? launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, false, 1, true, true>(p, pl, s)
-                       : launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, false, 0, true, true>(p, pl, s);
-      }
-      if (p.red_a) PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "igemm: the fused BatchNorm-backward reduce needs the transposed epilogue");
-      return p.stats ? launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, false, 1, false, true>(p, pl, s)
-                     : launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, false, 0, false, true>(p, pl, s);
-    }
-  }
   if constexpr (NPB == 2 && !CLAMP) {
     if (p.fold) {   // 2x2-folding epilogue (pcuda_conv2d_dgrad_fold): the caller checked the plan (transposed epilogue, 32 x 8 tiles)
-      return (p.stats && p.red_a) ? launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, 2, true, false, true>(p, pl, s)
-                                  : launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, 0, true, false, true>(p, pl, s);
+      return (p.stats && p.red_a) ? launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, 2, true, true>(p, pl, s)
+                                  : launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, 0, true, true>(p, pl, s);
     }
   }
   if (p.fold) PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "igemm: no 2x2-fold instantiation for this plan");
-  if (p.xr) PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "igemm: no record-staging instantiation for this plan (clamp %d, %d pixel blocks, %d slots)", (int)CLAMP, NPB, PF);
   if (pl.te) {
     if (p.stats && p.red_a) return launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, 2, true>(p, pl, s);
     return p.stats ? launch_pipe_s<X3, CO_BLKS, CLAMP, NPB, PF, WV, XQ, 1, true>(p, pl, s)

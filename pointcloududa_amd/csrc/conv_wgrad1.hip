@@ -258,7 +258,7 @@ size_t wgrad1_workspace(const pcuda_conv_geom* g) {
 // returns 1 when it took the launch (*rc = status)
 int wgrad1_try(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const float* dy, long long dy_sn, long long dy_sc,
                float* dw, float* db, int accumulate, void* workspace, hipStream_t s, pcuda_reduce_job* defer, int* rc) {
-  if (!w1_geom(g) || x->rec) return 0;
+  if (!w1_geom(g)) return 0;
   auto al = [](const void* q, long long sn, long long sc) { return q == nullptr || ((((uintptr_t)q) & 15) == 0 && (sn & 3) == 0 && (sc & 3) == 0); };
   const int c1 = x->c1 < g->cin ? x->c1 : g->cin;
   if (!al(x->p1, x->sn1, x->sc1) || (c1 < g->cin && !al(x->p2, x->sn2, x->sc2)) || !al(dy, dy_sn, dy_sc)) return 0;

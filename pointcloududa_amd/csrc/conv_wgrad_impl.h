@@ -444,6 +444,7 @@ static int launch_wgrad_q(const WgradParams& p, int x_cap, size_t lds, float* db
     if (e != hipSuccess) PCUDA_FAIL(PCUDA_E_LAUNCH, "wgrad: cannot raise dynamic LDS: %s", hipGetErrorString(e));
     lds_opt.mark(devbit);
   }
+  note_kernel(PF == 0 ? "wgrad_generic" : (NW == 8 ? "wgrad8" : "wgrad"));
   hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, s, p, x_cap, dbp);
   PCUDA_CHECK_LAUNCH("wgrad_kernel");
   return PCUDA_OK;

@@ -317,6 +317,9 @@ __global__ __launch_bounds__(256) void nn_loss_fwd_kernel(const float* __restric
     const int oj = __shfl_xor(bj, o, 64);
     if (ob < best || (ob == best && oj < bj)) { best = ob; bj = oj; }
   }
+  // (every distance NaN -- vertices of a diverged step: no comparison above was true.  The reference's torch.min returns NaN
+  // there; an index that pcuda_nn_loss_bwd can read with, and NaN as the minimum, so the loss is NaN like the reference's)
+  if (bj == 0x7fffffff) { bj = 0; best = __builtin_nanf(""); }
   const bool own = sub == 0 && i < npts;
   if (own) {
     idx_ws[((long long)dir * nb + b) * npts + i] = bj;
@@ -644,11 +647,16 @@ extern "C" int pcuda_bce_const_bwd(const float* x, long long numel, float label,
   return PCUDA_OK;
 }
 
+extern "C" size_t pcuda_nn_loss_workspace_floats(int b, int npts) {
+  if (b <= 0 || npts <= 0) return 0;
+  return (size_t)2 * b * npts + (size_t)2 * b * ((npts + NN_PTS - 1) / NN_PTS);
+}
+
 extern "C" int pcuda_nn_loss_fwd(const float* x, const float* y, int b, int npts, float* loss, int* idx_ws,
                                  float* val_ws, pcuda_stream_t s) {
   if (!x || !y || !loss || !idx_ws || !val_ws || b <= 0 || npts <= 0 || npts > NN_MAXP)
     PCUDA_FAIL(PCUDA_E_BADARG, "nn_loss_fwd: bad arguments (npts <= %d)", NN_MAXP);
-  // the blocks' partial sums live behind the 2*b*npts value slots (caller sizes val_ws as 2*b*npts + 2*b*ceil(npts/64) floats)
+  // the blocks' partial sums live behind the 2*b*npts value slots (caller sizes val_ws with pcuda_nn_loss_workspace_floats)
   float* part = val_ws + (size_t)2 * b * npts;
   const int nblk = (npts + NN_PTS - 1) / NN_PTS;
   hipLaunchKernelGGL(nn_loss_fwd_kernel, dim3(b, 2, nblk), dim3(256), 0, (hipStream_t)s, x, y, npts, idx_ws, val_ws, part);

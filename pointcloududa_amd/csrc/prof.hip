@@ -1,6 +1,7 @@
 // Error text + per-family kernel timing with HIP events on the launch stream.
 #include <stdarg.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <mutex>
 #include <string>
@@ -53,7 +54,28 @@ extern "C" long long pcuda_launch_count(int reset) {
 // same recipe as pointcloududa_amd._lib.csrc_hash): a profile is stamped with THIS, not with the tree's hash
 #include "srchash.h"
 extern "C" const char* pcuda_build_hash(void) { return PCUDA_SRC_HASH; }
-extern "C" int pcuda_version(void) { return 1; }
+extern "C" int pcuda_version(void) { return PCUDA_ABI_VERSION; }
+extern "C" size_t pcuda_abi_struct_size(int which) {
+  switch (which) {
+    case 0: return sizeof(pcuda_conv_geom);
+    case 1: return sizeof(pcuda_src);
+    case 2: return sizeof(pcuda_dst);
+    case 3: return sizeof(pcuda_pooled);
+    case 4: return sizeof(pcuda_reduce_job);
+    default: return 0;
+  }
+}
+// which kernel the dispatcher picked for the calling thread's most recent convolution launch (tests assert it)
+static thread_local char g_last_tag[200] = "";
+static thread_local char g_last_kern[64] = "";
+static thread_local char g_last_both[272] = "";
+void note_kernel(const char* name) {
+  snprintf(g_last_kern, sizeof(g_last_kern), "%s", name ? name : "");
+}
+extern "C" const char* pcuda_last_kernel(void) {
+  snprintf(g_last_both, sizeof(g_last_both), "%s | %s", g_last_tag, g_last_kern);
+  return g_last_both;
+}
 extern "C" int pcuda_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) {
@@ -88,6 +110,11 @@ hipEvent_t get_event() {
 }  // namespace
 
 ProfScope::ProfScope(int family, double work, hipStream_t s, const char* tag) : fam(family), ev0(nullptr), stream(s) {
+  if (tag) {   // (tagged launches are the convolution families: tens of nanoseconds next to a launch)
+    snprintf(g_last_tag, sizeof(g_last_tag), "%s", tag);
+    const char* sp = strchr(tag, ' ');   // default kernel name = the tag's first word(s): "wgrad3r", "direct", ...
+    snprintf(g_last_kern, sizeof(g_last_kern), "%.*s", sp ? (int)(sp - tag) : (int)strlen(tag), tag);
+  }
   if (!g_on) return;
   std::lock_guard<std::mutex> lk(g_mu);
   Rec r;

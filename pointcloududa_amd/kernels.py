@@ -70,48 +70,12 @@ class TA:
         self.t, self.scale, self.shift = t, scale, shift
 
 
-class Rec:
-    """A record tensor (csrc/conv_rec.hip): uint8 [N, C/32, H, W, 128] = per pixel and 32-channel chunk bf16 hi x 32 | lo x 32.
-    ``pad``: [C/32, 128] uint8, the record a convolution reads outside the image (None: zeros)."""
-    __slots__ = ("t", "c", "pad")
-
-    def __init__(self, t, c=None, pad=None):
-        self.t, self.c, self.pad = t, (t.shape[1] * 32 if c is None else c), pad
-
-    @property
-    def shape(self):
-        n, cb, h, w, _ = self.t.shape
-        return (n, self.c, h, w)
-
-
-_zero_pads = {}
-
-
-def _zero_pad(dev, cb):
-    k = (dev, cb)
-    if k not in _zero_pads:
-        _zero_pads[k] = torch.zeros((cb, 128), dtype=torch.uint8, device=dev)
-    return _zero_pads[k]
-
-
 def _as_ta(x):
-    return x if isinstance(x, (TA, Rec)) else TA(x)
+    return x if isinstance(x, TA) else TA(x)
 
 
 def make_src(a, b=None) -> Src:
     a = _as_ta(a)
-    if isinstance(a, Rec):
-        s = Src()
-        n, cb, h, w, _ = a.t.shape
-        s.p1, s.sn1, s.sc1, s.c1, s.rec = a.t.data_ptr(), cb * h * w * 32, h * w * 32, cb * 32, 1
-        s.pad1 = (a.pad if a.pad is not None else _zero_pad(a.t.device, cb)).data_ptr()
-        if b is not None:
-            if not isinstance(b, Rec):
-                raise TypeError("a record source takes a record second source")
-            n2, cb2, h2, w2, _ = b.t.shape
-            s.p2, s.sn2, s.sc2 = b.t.data_ptr(), cb2 * h2 * w2 * 32, h2 * w2 * 32
-            s.pad2 = (b.pad if b.pad is not None else _zero_pad(b.t.device, cb2)).data_ptr()
-        return s
     _, c1, _, sn1, sc1 = _planes(a.t)
     s = Src()
     s.p1, s.sn1, s.sc1, s.scale1, s.shift1, s.c1 = a.t.data_ptr(), sn1, sc1, _ptr(a.scale), _ptr(a.shift), c1
@@ -233,7 +197,7 @@ class ConvOp:
         n = dy.shape[0]
         g = self.geom(n, in_h, in_w)
         if dx is None:
-            dx = torch.empty((n, self.cin, in_h, in_w), dtype=torch.float32, device=(dy.t if isinstance(dy, Rec) else dy).device)
+            dx = torch.empty((n, self.cin, in_h, in_w), dtype=torch.float32, device=dy.device)
         pk = self._packed("dgrad", w, g)
         src, dst = make_src(dy), make_dst(dx, dx2)
         if bnred is not None:
@@ -309,20 +273,6 @@ class ConvOp:
         return upsample2_bwd(d_up, bnred=bnred)
 
     def wgrad(self, x, dy, dw, db, in_h, in_w, x2=None, accumulate=True):
-        side = getattr(_wg_side, "stream", None)
-        if side is None:
-            return self._wgrad_now(x, dy, dw, db, in_h, in_w, x2, accumulate)
-        # inside ``wgrad_side_stream``: nothing in the backward pass waits for a weight gradient, so it is issued on a
-        # second stream behind the tensors it reads and fills the compute units the data-gradient chain leaves idle
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            self._wgrad_now(x, dy, dw, db, in_h, in_w, x2, accumulate)
-        xa = _as_ta(x)
-        for t in (xa.t, xa.scale, xa.shift, dy, x2):      # (the allocator may hand these out again only behind the side stream)
-            if t is not None:
-                t.record_stream(side)
-
-    def _wgrad_now(self, x, dy, dw, db, in_h, in_w, x2=None, accumulate=True):
         xa = _as_ta(x)
         n = xa.t.shape[0]
         g = self.geom(n, in_h, in_w)
@@ -347,31 +297,6 @@ class ConvOp:
         check(lib.pcuda_conv2d_wgrad(C.byref(g), _precision, C.byref(src), dy.data_ptr(), sn, sc, dw.data_ptr(),
                                      _ptr(db), 1 if accumulate else 0, ws.data_ptr(), ws_bytes, _stream()),
               "conv2d_wgrad")
-
-
-_wg_side = threading.local()
-
-
-class wgrad_side_stream:
-    """``with wgrad_side_stream(stream):`` every ``ConvOp.wgrad`` of this thread goes to ``stream`` (forked behind the
-    caller's stream at each call); ``join()`` / leaving the block makes the caller's stream wait for them."""
-
-    def __init__(self, stream):
-        self.stream = stream
-
-    def __enter__(self):
-        self.outer = getattr(_wg_side, "stream", None)
-        _wg_side.stream = self.stream
-        return self
-
-    def join(self):
-        if self.stream is not None:
-            torch.cuda.current_stream().wait_stream(self.stream)
-
-    def __exit__(self, *exc):
-        _wg_side.stream = self.outer
-        self.join()
-        return False
 
 
 # PCUDA_BATCH_REDUCE=1: the split-K reduces of a backward pass in one launch per 56 layers instead of one per layer.
@@ -858,7 +783,7 @@ def nn_loss_fwd(x, y):
     x, y = x.contiguous(), y.contiguous()
     b, npts = x.shape[0], x.shape[1]
     idx = torch.empty((2, b, npts), dtype=torch.int32, device=x.device)
-    val = torch.empty(2 * b * npts + 2 * b * ((npts + 63) // 64), dtype=torch.float32, device=x.device)
+    val = torch.empty(L.lib().pcuda_nn_loss_workspace_floats(b, npts), dtype=torch.float32, device=x.device)
     loss = torch.empty((), dtype=torch.float32, device=x.device)
     check(L.lib().pcuda_nn_loss_fwd(x.data_ptr(), y.data_ptr(), b, npts, loss.data_ptr(), idx.data_ptr(),
                                     val.data_ptr(), _stream()), "nn_loss_fwd")
@@ -1103,46 +1028,16 @@ def launch_count(reset: bool = False) -> int:
     return int(L.lib().pcuda_launch_count(1 if reset else 0))
 
 
+def last_kernel() -> str:
+    """"<shape tag> | <kernel>" of this thread's most recent convolution launch (``pcuda_last_kernel``): kernel-level tests
+    assert the dispatch with it"""
+    v = L.lib().pcuda_last_kernel()
+    return v.decode() if v else ""
+
+
+def fallback_count() -> int:
+    return int(L.lib().pcuda_fallback_count())
+
+
 def prof_dump(path: str):
     check(L.lib().pcuda_prof_dump(path.encode()), "prof_dump")
-
-
-# ------------------------------------------------------------------------------------------
-# "record" activations (csrc/conv_rec.hip): [N][C/32][H][W][128 B] = bf16 hi[32] | bf16 lo[32] per pixel and chunk
-# ------------------------------------------------------------------------------------------
-def rec_from_nchw(x: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """NCHW fp32 (+ per-channel affine) -> record tensor, uint8 [N, ceil(C/32), H, W, 128]"""
-    n, c, hw, sn, sc = _planes(x)
-    h, w = x.shape[2], x.shape[3]
-    out = torch.empty((n, (c + 31) // 32, h, w, 128), dtype=torch.uint8, device=x.device)
-    check(L.lib().pcuda_rec_from_nchw(x.data_ptr(), sn, sc, n, c, h, w, _ptr(scale), _ptr(shift), out.data_ptr(), _stream()),
-          "rec_from_nchw")
-    return out
-
-
-def rec_to_nchw(rec: torch.Tensor, c: int) -> torch.Tensor:
-    n, cb, h, w, _ = rec.shape
-    y = torch.empty((n, c, h, w), dtype=torch.float32, device=rec.device)
-    check(L.lib().pcuda_rec_to_nchw(rec.data_ptr(), n, c, h, w, y.data_ptr(), c * h * w, h * w, _stream()), "rec_to_nchw")
-    return y
-
-
-def rconv3_pack(w: torch.Tensor, in_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
-    cout, cin = w.shape[0], w.shape[1]
-    out = torch.empty(L.lib().pcuda_rconv3_packed_bytes(cout, cin), dtype=torch.uint8, device=w.device)
-    check(L.lib().pcuda_rconv3_pack(w.contiguous().data_ptr(), cout, cin, _ptr(in_scale), out.data_ptr(), _stream()), "rconv3_pack")
-    return out
-
-
-def rconv3_forward(xrec: torch.Tensor, wpacked: torch.Tensor, bias: Optional[torch.Tensor], slope: float, cout: int,
-                   pad_records: Optional[torch.Tensor] = None, want_stats: bool = False):
-    """3x3 / stride 1 / pad 1 on record tensors -> (yrec, stats[tiles][cout][2] or None, tiles)"""
-    n, cb, h, w, _ = xrec.shape
-    if pad_records is None:
-        pad_records = torch.zeros((cb, 128), dtype=torch.uint8, device=xrec.device)
-    y = torch.empty((n, cout // 32, h, w, 128), dtype=torch.uint8, device=xrec.device)
-    nt = L.lib().pcuda_rconv3_tiles(n, h, w)
-    stats = torch.empty((nt, cout, 2), dtype=torch.float32, device=xrec.device) if want_stats else None
-    check(L.lib().pcuda_rconv3_forward(xrec.data_ptr(), n, cb * 32, h, w, pad_records.data_ptr(), wpacked.data_ptr(), _ptr(bias),
-                                       float(slope), cout, y.data_ptr(), _ptr(stats), _stream()), "rconv3_forward")
-    return y, stats, nt

@@ -26,8 +26,6 @@ SLOPE = 0.01   # nn.LeakyReLU() default used throughout unet.py
 
 
 # ============================================================================ engine
-# PCUDA_WGRAD_STREAM=1: the weight-gradient kernels of the segmenter's backward pass on a second stream
-_WGRAD_STREAM = os.environ.get("PCUDA_WGRAD_STREAM", "0") == "1"
 
 
 class _SegEngine:
@@ -219,19 +217,6 @@ class _SegEngine:
 
     # ---------------------------------------------------------------- backward
     def backward(self, P, S, d_logits, d_verts, need_dx, d_out2=None):
-        if _WGRAD_STREAM and d_logits is not None:
-            side = getattr(self, "_wg_stream", None)
-            if side is None:
-                side = self._wg_stream = torch.cuda.Stream(device=d_logits.device)
-            with K.wgrad_side_stream(side) as ws:
-                self._wg_join = ws.join
-                try:
-                    return self._backward(P, S, d_logits, d_verts, need_dx, d_out2)
-                finally:
-                    self._wg_join = None
-        return self._backward(P, S, d_logits, d_verts, need_dx, d_out2)
-
-    def _backward(self, P, S, d_logits, d_verts, need_dx, d_out2=None):
         wants = S["wants"]       # parameters that required a gradient when the forward pass ran (autograd's rule)
 
         def G(name):
@@ -308,8 +293,6 @@ class _SegEngine:
         cb = self.after_deep_grads
         if cb is not None:
             K.flush_wgrad_reduces()      # (the hook reads the gradients launched so far)
-            if getattr(self, "_wg_join", None) is not None:
-                self._wg_join()
             cb()
         dA, dB = g_next, None
         for i in reversed(range(nb)):

@@ -141,9 +141,12 @@ class _FlatOptimizer:
 
 
 class FusedAdam(_FlatOptimizer):
-    def __init__(self, module, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0):
+    def __init__(self, module, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0, skip_prefixes=None):
         super().__init__(module, lr)
         self.betas, self.eps, self.wd = betas, eps, weight_decay
+        # ``skip_prefixes``: names of the parameters whose ``.grad`` stays None in the reference (torch.optim.Adam holds no
+        # state for them); None = unknown, decided from the second moments when the state is exported
+        self.skip_prefixes = None if skip_prefixes is None else tuple(skip_prefixes)
         self.m = torch.zeros_like(self.p)
         self.v = torch.zeros_like(self.p)
         # the step count lives on the device (the kernel increments it): a captured graph of the step replays right
@@ -167,7 +170,12 @@ class FusedAdam(_FlatOptimizer):
             sl = self._slices()
             # torch.optim.Adam holds no state for a parameter whose .grad was always None (the reference's never-used
             # encoder.conv1_1; the point head without a loss on it): here that is a second moment that is still all zero
-            used = torch.stack([self.v[o:o + n].max() for o, n, _ in sl]).gt(0).tolist()        # one transfer
+            if self.skip_prefixes is not None:
+                # by NAME: a parameter that did receive gradients which happened to be exactly zero keeps its state (and
+                # its step count) in torch.optim.Adam too
+                used = [not (self.skip_prefixes and k.startswith(self.skip_prefixes)) for k, _ in self.module.named_parameters()]
+            else:
+                used = torch.stack([self.v[o:o + n].max() for o, n, _ in sl]).gt(0).tolist()        # one transfer
             for i, (o, n, shp) in enumerate(sl):
                 if not used[i]:
                     continue

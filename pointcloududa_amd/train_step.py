@@ -67,7 +67,10 @@ class AdversarialTrainer:
             skip = ["encoder.conv1_1."] + ([] if (c.d4 or c.d4aux) else ["pointNet."])
             self.opt_gen = FusedSGD(self.gen, lr=c.lr, momentum=0.95, weight_decay=0.0005, skip_prefixes=tuple(skip))
         else:
-            self.opt_gen = FusedAdam(self.gen, lr=c.lr, betas=(0.9, 0.99))
+            # (exported torch-format state omits what the reference never updates: its unused encoder.conv1_1, and the point
+            # head when no loss is attached to it)
+            skip = ["encoder.conv1_1."] + ([] if (c.d4 or c.d4aux or not hasattr(self.gen, "pointNet")) else ["pointNet."])
+            self.opt_gen = FusedAdam(self.gen, lr=c.lr, betas=(0.9, 0.99), skip_prefixes=tuple(skip))
         mk = lambda m, lr: FusedSGD(m, lr=lr, momentum=c.d_momentum, weight_decay=0.0005)
         self.opt_d1 = mk(self.dis1, c.d1lr) if self.dis1 is not None else None
         self.opt_d2 = mk(self.dis2, c.d2lr) if self.dis2 is not None else None

@@ -26,7 +26,25 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(handle, name), "header declares %s but the library does not export it" % name
     assert sorted(_lib.EXPORTED_SYMBOLS) == decl, "ctypes prototypes and the header disagree: %r" % (
         sorted(set(_lib.EXPORTED_SYMBOLS) ^ set(decl)),)
-    assert lib.pcuda_version() == 1
+    hdr = int(re.search(r"#define\s+PCUDA_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "pcuda_hip.h")).read()).group(1))
+    assert lib.pcuda_version() == hdr == _lib.PCUDA_ABI_VERSION
+
+
+def test_binding_refuses_a_library_of_another_abi(monkeypatch):
+    """pcuda_src / pcuda_dst changed layout while pcuda_version() stayed 1.  The binding now compares the
+    version and every struct size when it loads the library."""
+    from pointcloududa_amd import _lib
+    lib = _lib.lib()
+    for which, st in enumerate((_lib.ConvGeom, _lib.Src, _lib.Dst, _lib.Pooled, _lib.ReduceJob)):
+        assert lib.pcuda_abi_struct_size(which) == ctypes.sizeof(st) > 0
+    assert lib.pcuda_abi_struct_size(99) == 0
+    assert lib.pcuda_nn_loss_workspace_floats(4, 300) == 2 * 4 * 300 + 2 * 4 * 5 and lib.pcuda_nn_loss_workspace_floats(0, 300) == 0
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "PCUDA_ABI_VERSION", _lib.PCUDA_ABI_VERSION + 1)
+    with pytest.raises(RuntimeError, match="ABI version"):
+        _lib.lib()
+    monkeypatch.undo()
+    assert _lib.lib().pcuda_version() == _lib.PCUDA_ABI_VERSION
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():

@@ -19,6 +19,9 @@ from conftest import rel_err
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
+# whole-step segmenter gradients: worst-case linear accumulation of 2 x 2^-17 per convolution layer over the 29 + 5 layers
+# between the adversarial loss and the first encoder block (derivation in test_train_step_backward_shared_routing)
+SEG_CHAIN_TOL = 2 * (29 + 5) * 2.0 ** -17
 
 
 def _load(mod, params, dev):
@@ -273,11 +276,13 @@ def test_train_step_backward_shared_routing(dev, variant, pn_kw, in_ch, n_class,
     discriminator frozen on the target batch and training on source and target).  Losses: 1e-5.  Every discriminator
     gradient: 1e-4 of the scale of its two passes' gradients (source-as-1 and target-as-0 largely cancel in their sum at
     initialisation: D(x) ~ 0 on both).  The segmenter's gradients -- supervised, and supervised + adversarial, the one
-    its optimiser consumes -- 4e-4: they sit at the end of a chain of 29 (+ 5 discriminator) layers of bf16x3 products
-    and depend on the seed AND on the summation order (the per-network twins above see 4-6e-5 on theirs; these batches
-    1.4-3.1e-4 at the first encoder block, the end of that chain: the SAME arithmetic on two tilings of the small layers --
-    a plan rule of round 4, PCUDA_NO_UNDERFILL -- moved the mmwhs case from 2.4e-4 to 3.1e-4, which is the scatter of this
-    figure; the bar was 3e-4 until then).  The worst value per gradient is printed."""
+    its optimiser consumes -- SEG_CHAIN_TOL, a bound DERIVED from the arithmetic, not fitted to a run (round-4 review, weak
+    2: the bar had followed a plan change from 3e-4 to 4e-4): the gradient of the first encoder block sits behind 29
+    segmenter + 5 discriminator convolution layers; a bf16x3 product carries each operand to 2^-17 of its scale (hi + lo,
+    two bf16 roundings) and drops the lo x lo term (2^-18), so a layer's output is off by at most ~2 x 2^-17 of its
+    tensor's scale, and in the worst case the layers' errors add linearly: 2 x 34 x 2^-17 = 5.2e-4, whatever tiling or
+    summation order the planner picks (observed: 1.4e-4 ... 3.1e-4 across seeds and plans; the per-network twins above,
+    whose chains are 5-29 layers, see 4-6e-5).  The worst value per gradient is printed."""
     import oracle.step as OS
     from oracle import nets as ON
     from oracle.synth import synth_batch
@@ -374,7 +379,7 @@ def test_train_step_backward_shared_routing(dev, variant, pn_kw, in_ch, n_class,
     for nm, mod in (("grad_seg", gen), ("grad_total", gen), ("grad_d1", d1), ("grad_d2", d2), ("grad_d4", d4)):
         named = [(k, _G(g)) for k, g in flat_named(mod, tr.last[nm])]
         ref = orc.kept[nm]
-        w = _compare_grads(named, ref, tol=4e-4 if mod is gen else TOL, parts=orc.kept.get(nm + "_src"))
+        w = _compare_grads(named, ref, tol=SEG_CHAIN_TOL if mod is gen else TOL, parts=orc.kept.get(nm + "_src"))
         report.append("%s %s %.2e" % (nm, w[0], w[1]))
     print("%s step %s: worst gradient errors: %s; worst layer-local forward error %s %.2e"
           % (variant, flags, "; ".join(report), pre.get("tag"), pre.get("e", 0.0)))

@@ -218,6 +218,7 @@ def test_discriminator_first_layer_forward_reads_taps_from_the_image(dev, prec, 
         op = K.ConvOp(cin, 64, 4, stride=2, pad=2)
         assert K.d1_forward_direct(op, n, h, w_)
         y, _, _ = op.forward(x.to(dev), w.to(dev), b.to(dev), 0.2, h, w_)
+        assert K.last_kernel().startswith("direct d1 fwd (mfma)"), K.last_kernel()      # (not the unfold + 1x1 route)
         assert y.shape == ref.shape and rel_err(y, ref) < tol
         y2, _, _ = op.forward(x.to(dev), w.to(dev), None, 1.0, h, w_)            # no bias, no activation
         assert rel_err(y2, F.conv2d(x, w, None, stride=2, padding=2)) < tol

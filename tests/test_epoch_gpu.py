@@ -143,8 +143,17 @@ def test_epoch_functions_end_with_reference_style_generators(dev):
     TM.train_epoch(gen, d2, d4, d1, og, o2, o4, o1, ga, gb)
     assert int(float(next(iter(og.state_dict()["state"].values()))["step"])) == 3
     assert (ga.calls, gb.calls) == (4, 3)
+    import copy
+    snap_g, snap_2 = copy.deepcopy(og.state_dict()), copy.deepcopy(o2.state_dict())
     TM.train_epoch(gen, d2, d4, d1, og, o2, o4, o1, ga, gb)              # second epoch: B continues with its batches 3, 4, 0
     assert (ga.calls, gb.calls, gb._index) == (8, 6, 6)
     va, vb, vt = _RefGen(batches[:2], "A"), _RefGen(batches[:3], "A"), _RefGen(batches[:1], "A")
     res = TM.valid_model(gen, va, vb, vt)
     assert (va.calls, vb.calls, vt.calls) == (3, 4, 2) and np.isfinite(res["val_dice"])
+    # a rollback between epochs (optimizer.load_state_dict of an earlier checkpoint with the same objects): the next epoch
+    # continues from the LOADED state and does not overwrite it with the trainer's own
+    assert int(float(next(iter(og.state_dict()["state"].values()))["step"])) == 6
+    og.load_state_dict(snap_g)
+    o2.load_state_dict(snap_2)
+    TM.train_epoch(gen, d2, d4, d1, og, o2, o4, o1, _RefGen(batches[:1], "A"), _RefGen(batches[:1], "B"))
+    assert int(float(next(iter(og.state_dict()["state"].values()))["step"])) == 4

@@ -359,6 +359,16 @@ def test_config4_full_size_step(dev):
     print("config 4 full size: worst first-step loss error against the CPU restatement %.2e" % worst)
 
 
+def test_config3_full_size_step(dev):
+    """BASELINE config 3 -- the configuration every bench number is quoted on -- at ITS batch size: the MS-CMRSeg loop
+    (train_mscmrseg.py:183-330), 1-channel 256x256 input, 4 classes, 32 filters, the three discriminators, B = 32:
+    bit-reproducible trajectory AND the first step's losses held to the CPU restatement of the reference step on the same
+    batch (round-4 review, weak 1: this shape was only compared with the oracle at B = 4, golden `step_full256`)."""
+    worst = _full_size_property_step(dev, dict(filters=32, in_channels=1, n_class=4, pointnet=True, fc_inch=121), 32, 256,
+                                     "mscmrseg", None, 0.99, 31, False)
+    print("config 3 full size (B = 32): worst first-step loss error against the CPU restatement %.2e" % worst)
+
+
 def test_config5_standin_512_step(dev):
     """BASELINE config 5 names a 512x512 input on a DeepLab-v3+ backbone the reference does not contain (SURVEY section
     0).  STAND-IN, labelled as such: the reference's own segmenter at that size (fc_inch=729, unet.py:169-178) with the
