@@ -389,13 +389,22 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step(*batch)
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0         # this rank's own work done (before the closing barrier)
     sync()
     dt = time.perf_counter() - t0
     ranks_in_group = 1
+    per_rank = {"min": round(b * args.steps / dt, 2), "max": round(b * args.steps / dt, 2)}
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        tmin = torch.tensor([dt_own], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        # (a straggler rank shows as min << max: the slowest rank sets `value`; the fastest one's own completion time, taken
+        # before the closing barrier, says how long it waited there.  The per-step all-reduces couple the ranks, so a
+        # spread here is the last step's skew plus whatever a rank loses outside the collectives)
+        per_rank = {"min": round(b * args.steps / dt, 2), "max": round(b * args.steps / float(tmin.item()), 2)}
         cnt = torch.ones(1, dtype=torch.float64, device=dev)      # what RCCL itself says about the group
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         ranks_in_group = int(cnt.item())
@@ -447,6 +456,10 @@ def main():
         "scaling": "weak", "vs_baseline": None,
         "host_issue_ms_per_step": round(host_issue_ms, 3), "launches_per_step": round(launches_per_step, 1),
         "comm_exposed_ms": comm_exposed_ms,
+        "per_rank_img_s": per_rank,
+        # shader clock while every SIMD issues MFMAs back to back, measured AFTER the timed region on this box (rank 0's GPU):
+        # boxes of the pool differ by up to 10 % on one binary; value / clock normalises lines of different rounds
+        "clock_ghz_under_load": round(K.clock_ghz_under_load(dev), 3),
         # launches that ran on a generic fallback kernel (csrc/variants.h: pruned default build): must be 0 for a benchmark line
         "fallback_launches": int(K.L.lib().pcuda_fallback_count()),
         "dtype": "bf16x3 MFMA (split-bf16, fp32 accumulate; fp32 storage)" if args.precision == "bf16x3"

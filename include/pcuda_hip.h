@@ -63,6 +63,10 @@ long long pcuda_fallback_count(void);
  * carries, and which kernel family the dispatcher picked for it: igemm_pipe / igemm8 / igemm_generic / wgrad[+fallback] /
  * wgrad3 / wgrad3r / wgrad1 / direct ...): lets a kernel-level test assert WHICH kernel produced the result it checks */
 const char* pcuda_last_kernel(void);
+/* measurement aid (bench.py `clock_ghz_under_load`): 512 workgroups x 4 waves issue `iters` x 4 back-to-back 32x32x16 bf16
+ * MFMAs; out2_dev[0] / out2_dev[1] receive the summed shader-clock (s_memtime) and 100-MHz reference-clock (s_memrealtime)
+ * ticks of every workgroup's first wave: shader GHz = 0.1 * out2[0] / out2[1].  sink_dev: one float (never written). */
+int pcuda_clock_probe(unsigned long long* out2_dev, float* sink_dev, int iters, pcuda_stream_t s);
 
 /* kernel-family timing (HIP events recorded on the launch stream around every launch of
  * a family while enabled; used by bench.py for the live roofline figure) */

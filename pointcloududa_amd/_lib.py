@@ -53,6 +53,7 @@ _PROTOS = {
     "pcuda_fallback_count": (i64, []),
     "pcuda_abi_struct_size": (sz, [i32]),
     "pcuda_last_kernel": (C.c_char_p, []),
+    "pcuda_clock_probe": (i32, [vp, vp, i32, vp]),
     "pcuda_prof_enable": (i32, [i32]),
     "pcuda_prof_reset": (i32, []),
     "pcuda_prof_read": (i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]),

@@ -279,6 +279,15 @@ __device__ __forceinline__ TileGeom tile_decode(const IgemmParams& p, int L) {
     clk[i] += now_ - tlast; tlast = now_;                                           \
   }                                                                                 \
   __builtin_amdgcn_sched_barrier(0);
+// (eight-wave kernel: one accumulator array index)
+#define DBG_CLK_ACC8(i)                                                             \
+  __builtin_amdgcn_sched_barrier(0);                                                \
+  if (p.dbg & 128) {                                                                \
+    asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[CBW - 1][15]));                  \
+    const unsigned long long now_ = __builtin_readcyclecounter();                   \
+    clk[i] += now_ - tlast; tlast = now_;                                           \
+  }                                                                                 \
+  __builtin_amdgcn_sched_barrier(0);
 #define DBG_CLK_FLUSH                                                               \
   if ((p.dbg & 128) && p.dbg_clk && tid == 0) {                                     \
     for (int i = 0; i < 8; ++i) atomicAdd(&p.dbg_clk[i], clk[i]);                   \
@@ -287,6 +296,7 @@ __device__ __forceinline__ TileGeom tile_decode(const IgemmParams& p, int L) {
 #define DBG_CLK_DECL
 #define DBG_CLK(i) PCUDA_CLK_FENCE
 #define DBG_CLK_ACC(i) PCUDA_CLK_FENCE
+#define DBG_CLK_ACC8(i) PCUDA_CLK_FENCE
 #define DBG_CLK_FLUSH
 #ifdef PCUDA_CLK_KEEP_FENCES
 #define PCUDA_CLK_FENCE __builtin_amdgcn_sched_barrier(0);
@@ -297,18 +307,20 @@ __device__ __forceinline__ TileGeom tile_decode(const IgemmParams& p, int L) {
 
 // -DPCUDA_WEXP (timing experiments, results are wrong): PCUDA_DBG bit 8 = no weight loads / LDS writes after a workgroup's
 // first stage, bit 16 = also no barriers between weight groups (as if every tap were resident), bit 32 = no input commit
-// after the first stage: upper bounds of what weight delivery / staging can be worth in this kernel's structure.
+// after the first stage, bit 64 = no epilogue (no output stores, no statistics) after the first stage: upper bounds of what weight delivery / staging can be worth in this kernel's structure.
 #ifdef PCUDA_WEXP
 #define WEXP_DECL bool wexp_first = true;
 #define WEXP_W (!(p.dbg & 8) || wexp_first)
 #define WEXP_B (!(p.dbg & 16) || wexp_first)
 #define WEXP_X (!(p.dbg & 32) || wexp_first)
+#define WEXP_E (!(p.dbg & 64) || wexp_first)
 #define WEXP_END wexp_first = false;
 #else
 #define WEXP_DECL
 #define WEXP_W true
 #define WEXP_B true
 #define WEXP_X true
+#define WEXP_E true
 #define WEXP_END
 #endif
 
@@ -573,7 +585,7 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
     }
 
     DBG_CLK(6)
-    if (chunk == p.nchunks - 1) {
+    if (chunk == p.nchunks - 1 && WEXP_E) {
       // ---- epilogue of this tile.  No flat global access in here: a lane-indexed bias load in front of every
       // store made each store wait (vmcnt(0), in order) for the previous one AND for the whole X prefetch.
       // Bias comes through LDS (fetched at the top of the stage), stores go through buffer resources:
@@ -950,6 +962,8 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
 
   f32x16 acc[CBW];
   XFast<PF> pre;
+  DBG_CLK_DECL
+  WEXP_DECL
 
   auto issue_x = [&](const TileGeom& t, int ch, bool live) {
     if (XQ) xq_issue<PF, NT>(pre, p.x, t.n, p.cin, live ? ch : 0, p.in_h, p.in_w, t.oy0, t.ox0, live ? t.th : 0, t.tw, tid);
@@ -967,11 +981,16 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
   while (have) {
     const int cvalid = min(32, p.cin - chunk * 32);
     const int nks = cvalid > 16 ? 2 : 1;
+    DBG_CLK(7)
     __syncthreads();   // every wave is done with the previous stage's X / W / reduction scratch
+    DBG_CLK(0)
     float bias_r = 0.f;
     if (chunk == p.nchunks - 1 && p.bias && tid < CO_TILE) bias_r = p.bias[min(g.cot * CO_TILE + tid, p.cout - 1)];
+    if (WEXP_X) {
     if (XQ) xq_commit<X3, PF, NT, REC>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.ox0, g.th, g.tw, nks * 2, tid);
     else xfast_commit<X3, PF, NT, REC>(pre, Xhi, Xlo, p.x, p.cin, chunk, g.npix, (cvalid + 7) >> 3, nks * 2, tid);
+    }
+    DBG_CLK(1)
     if (CLAMP && tid < RECV) *(uint4*)(Xhi + (size_t)g.npix * REC + tid * 16) = make_uint4(0, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     // the stage's (first) weight group, with nothing else in the load queue: one L2 round trip.  (Requested
@@ -981,13 +1000,14 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
     const long long slab = (long long)CO_TILE * (REC / 2);
     const uint16_t* wsrc = p.wpack + ((long long)g.cot * p.nchunks + chunk) * p.ntaps * slab;
     const int nvec0 = min(p.tg, p.ntaps) * CO_TILE * RECV;
-    {
+    if (WEXP_W) {
       WPass<false, WS> wp0;
       wcopy_issue<false, WS, NT>(wp0, (const uint4*)wsrc, nullptr, nvec0, 0, tid);
       __builtin_amdgcn_sched_barrier(0);
       wcopy_commit<false, WS, NT>(wp0, Whi, nullptr, nvec0, 0, tid);
       __builtin_amdgcn_sched_barrier(0);
     }
+    DBG_CLK(3)
 
     // next stage: its loads stay in flight through the MFMA phase
     int nL = L, nchunk = chunk + 1;
@@ -996,6 +1016,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
     TileGeom ng = g;
     if (nhave && nL != L) ng = tile_decode<CLAMP, 1>(p, nL);
     issue_x(ng, nchunk, nhave);
+    DBG_CLK(2)
 
     if (chunk == 0) {
 #pragma unroll
@@ -1005,14 +1026,18 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
     }
     const int bbase = ((pty * p.in_step) * g.tw + ptx * p.in_step) * REC + h * 16;
     __syncthreads();
+    DBG_CLK(4)
 
     for (int t0 = 0; t0 < p.ntaps; t0 += p.tg) {
       const int tgc = min(p.tg, p.ntaps - t0);
       if (t0 > 0) {   // more taps than fit (4x4 / 6x6 kernels): later groups load behind the prefetch
-        __syncthreads();
+        DBG_CLK_ACC8(5)
+        if (WEXP_B) __syncthreads();
         const uint16_t* src = wsrc + (long long)t0 * slab;
-        wcopy<false, WS, NT>(Whi, nullptr, (const uint4*)src, nullptr, tgc * CO_TILE * RECV, 0, tid);
-        __syncthreads();
+        if (WEXP_W) wcopy<false, WS, NT>(Whi, nullptr, (const uint4*)src, nullptr, tgc * CO_TILE * RECV, 0, tid);
+        DBG_CLK(3)
+        if (WEXP_B) __syncthreads();
+        DBG_CLK(4)
       }
       int tv = taptab[t0];
       for (int tl = 0; tl < tgc; ++tl) {
@@ -1059,7 +1084,8 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
       }
     }
 
-    if (chunk == p.nchunks - 1) {
+    DBG_CLK_ACC8(5)
+    if (chunk == p.nchunks - 1 && WEXP_E) {
       // ---- epilogue (see igemm_pipe_kernel): bias through LDS, buffer stores, DPP partial sums
       const int co0 = g.cot * CO_TILE;
       if (tid < CO_TILE) sbias[tid] = bias_r;
@@ -1143,8 +1169,11 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
         }
       }
     }
+    DBG_CLK(6)
+    WEXP_END
     L = nL; chunk = nchunk; g = ng; have = nhave;
   }
+  DBG_CLK_FLUSH
 }
 
 template <bool X3, int CO_BLKS, bool CLAMP, int NPBT, int PF, bool XQ, bool STATS>

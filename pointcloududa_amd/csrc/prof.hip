@@ -85,6 +85,45 @@ extern "C" int pcuda_device_count(void) {
   return n;
 }
 
+// ---- shader clock under a matrix-core load (bench.py: `clock_ghz_under_load`).  Boxes of one pool differ by up to 10 % on one
+// binary; this probe says how fast THIS box clocks its CUs while every SIMD issues MFMAs back to back, so that two rounds'
+// lines can be normalised.  s_memtime counts shader-engine clocks, s_memrealtime the constant 100-MHz reference.
+typedef float probe_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 probe_bf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void clock_probe_kernel(unsigned long long* out2, float* sink, int iters) {
+  probe_f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+  probe_bf16x8 a, b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(float)(threadIdx.x & 7); b[i] = (__bf16)(float)(i + 1); }
+  const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) s += acc[j][0] + acc[j][15];
+  asm volatile("s_nop 0" ::"v"(s));
+  const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (s == 123.456f) sink[0] = s;
+  if (threadIdx.x == 0) {
+    atomicAdd(&out2[0], c1 - c0);
+    atomicAdd(&out2[1], r1 - r0);
+  }
+}
+
+extern "C" int pcuda_clock_probe(unsigned long long* out2_dev, float* sink_dev, int iters, pcuda_stream_t s) {
+  if (!out2_dev || !sink_dev || iters <= 0) PCUDA_FAIL(PCUDA_E_BADARG, "clock_probe: bad arguments");
+  if (hipMemsetAsync(out2_dev, 0, 16, (hipStream_t)s) != hipSuccess) PCUDA_FAIL(PCUDA_E_LAUNCH, "clock_probe: memset failed");
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(512), dim3(256), 0, (hipStream_t)s, out2_dev, sink_dev, iters);
+  PCUDA_CHECK_LAUNCH("clock_probe_kernel");
+  return PCUDA_OK;
+}
+
 namespace {
 struct Rec {
   hipEvent_t e0, e1;

@@ -293,6 +293,8 @@ class ConvOp:
                 if any(j.dw == job.dw for j, _ in pend):
                     flush_wgrad_reduces()        # two gradients into one buffer: keep their order
                 pend.append((job, ws))
+                if _batch_reduce_n >= 2 and len(pend) >= _batch_reduce_n:
+                    flush_wgrad_reduces()
             return
         check(lib.pcuda_conv2d_wgrad(C.byref(g), _precision, C.byref(src), dy.data_ptr(), sn, sc, dw.data_ptr(),
                                      _ptr(db), 1 if accumulate else 0, ws.data_ptr(), ws_bytes, _stream()),
@@ -303,7 +305,9 @@ class ConvOp:
 # OFF by default -- measured SLOWER (51.7 vs 49.5 ms per step, same box): a layer's partial sums (~35 MB) are still in
 # the 256 MB infinity cache when its own reduce follows at once, and the workspace block is reused by the next layer; all
 # of a pass's partials together (~1.4 GB) go out to HBM and come back.  The launches were not the cost.
-_batch_reduce = os.environ.get("PCUDA_BATCH_REDUCE", "0") == "1"
+# PCUDA_BATCH_REDUCE=k (k >= 2): flush every k layers -- the pending slabs (k x ~35 MB) stay inside the infinity cache.
+_batch_reduce_n = int(os.environ.get("PCUDA_BATCH_REDUCE", "0") or 0)
+_batch_reduce = _batch_reduce_n >= 1
 _deferred = threading.local()
 
 
@@ -1033,6 +1037,19 @@ def last_kernel() -> str:
     assert the dispatch with it"""
     v = L.lib().pcuda_last_kernel()
     return v.decode() if v else ""
+
+
+def clock_ghz_under_load(dev, iters: int = 8192, reps: int = 3) -> float:
+    """shader clock (GHz) while every SIMD of the chip issues MFMAs back to back (``pcuda_clock_probe``): the last of ``reps``
+    ~3-ms launches, so that the power state has settled"""
+    out = torch.zeros(2, dtype=torch.int64, device=dev)
+    sink = torch.zeros(1, dtype=torch.float32, device=dev)
+    ghz = 0.0
+    for _ in range(reps):
+        check(L.lib().pcuda_clock_probe(out.data_ptr(), sink.data_ptr(), int(iters), _stream()), "clock_probe")
+        c, r = (int(v) for v in out.tolist())
+        ghz = 0.1 * c / max(r, 1)
+    return ghz
 
 
 def fallback_count() -> int:

@@ -360,11 +360,14 @@ def test_pruned_build_falls_back_to_the_generic_kernels(dev):
 
 
 @pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
-@pytest.mark.parametrize("n,cin,cout,h,w", [(8, 64, 32, 128, 128), (4, 128, 64, 64, 96), (3, 256, 128, 32, 64), (2, 16, 8, 20, 24)])
+@pytest.mark.parametrize("n,cin,cout,h,w", [(8, 64, 32, 128, 128), (8, 128, 64, 64, 96), (12, 256, 128, 32, 64), (2, 16, 8, 20, 24)])
 def test_dgrad_with_the_2x2_fold_in_its_epilogue(dev, prec, n, cin, cout, h, w):
     """The data gradient of an up-convolution (nearest x2 folded into the forward's addressing, unet.py:111-112) written at
     the stored resolution -- dgrad + upsample2_bwd in one kernel -- against the two-kernel form and the CPU reference, with
-    and without the BatchNorm-backward reduce riding along; the last geometry has no folding plan (fallback)."""
+    and without the BatchNorm-backward reduce riding along; the last geometry has no folding plan (fallback).  (Batch sizes:
+    the first dispatch assertion of round 5 showed the 128- and 256-row cases at n = 4 / 3 on the eight-wave kernel -- too few
+    tiles for the pipelined one -- i.e. on the two-kernel fallback; they now have the > 320 (tile, co-tile) items the folding
+    kernel's plan needs.)"""
     from pointcloududa_amd import kernels as K
     K.set_precision(prec)
     try:
