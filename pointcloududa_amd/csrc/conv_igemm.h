@@ -55,6 +55,10 @@ struct IgemmParams {
   int tw, th, tmagic;      // output tile TW x TH (TW*TH <= 128*NPB slots, any TW <= 256); tmagic = 65536/TW + 1
   int tiles_x, tiles_y, n;
   int n_co_tiles;
+  // exact division of a tile index by n_co_tiles / tiles_x / tiles_y as one multiply-high (persistent kernels decode a tile
+  // per stage: four runtime divisions were ~120 of a stage's ~660 scalar instructions): q = m ? umulhi(v, m) : v with
+  // m = floor(2^32 / d) + 1 (0 for d = 1), exact for v < 2^32 / d (the host checks the launch's tile count)
+  unsigned m_cot, m_tx, m_ty;
   int clamp;               // 1: LDS tile = tile clipped to the image (+ one zero record)
   int dbg;                 // PCUDA_DBG bits (timing experiments only): 1 no X loads, 2 no MFMA, 4 no epilogue, 8 no W copy
   unsigned long long* dbg_clk;   // PCUDA_DBG bit 128: 8 per-phase cycle sums

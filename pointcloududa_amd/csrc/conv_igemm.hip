@@ -10,6 +10,7 @@
 //                     one launch per stride-parity class = transposed convolution)
 //   wgrad           : wgrad_kernel  (reduction over pixels; X read back through
 //                     ds_read_b64_tr_b16, split-K partial slabs + deterministic reduce)
+#include <algorithm>
 #include <stdlib.h>
 
 #include "conv_igemm.h"
@@ -349,6 +350,8 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
   p.n_co_tiles = cdiv(p.cout, co_tile);
   p.nchunks = cdiv(p.cin, 32);
   p.tw = pl.tw; p.th = pl.th; p.tmagic = 65536 / pl.tw + 1; p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y;
+  auto fmagic = [](int d) -> unsigned { return d <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d) + 1u; };
+  p.m_cot = fmagic(p.n_co_tiles); p.m_tx = fmagic(pl.tiles_x); p.m_ty = fmagic(pl.tiles_y);
   p.ntaps = taps.n;
   memcpy(p.dy, taps.dy, sizeof(p.dy));
   memcpy(p.dx, taps.dx, sizeof(p.dx));
@@ -384,8 +387,11 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
   // PF = 3 keeps 96 prefetch registers live next to the accumulators: only with one pixel block per wave
   // (one workgroup per CU has 512 registers per lane: PF = 3 next to two pixel blocks fits there)
   // (the unpipelined fallback copies its weight groups in 512-vector passes: any tg of the plan works)
+  // (the persistent kernels decode tile indices with multiply-high magic numbers, exact below 2^32 / divisor)
+  const long long total_items = (long long)p.n_co_tiles * p.n * pl.tiles_x * pl.tiles_y;
+  const int max_div = std::max(p.n_co_tiles, std::max(pl.tiles_x, pl.tiles_y));
   const bool pipe = !nopipe && p.ntaps > 0 && fast_src_ok(&p.x, p.cin) && fast_dst_ok(&p.y, p.cout) &&
-                    (pf <= 2 || (pf == 3 && !pl.w8 && (pl.npb == 1 || pl.fat)));
+                    (pf <= 2 || (pf == 3 && !pl.w8 && (pl.npb == 1 || pl.fat))) && total_items < (1ll << 32) / max_div;
   {   // transposed epilogue: its LDS scratch (4 waves x [32][32*npb] fp32 + the partial-sum slots) aliases the
       // X / W slabs and must end in front of the tap table behind them
     static int note = -1;

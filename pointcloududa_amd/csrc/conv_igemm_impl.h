@@ -235,15 +235,17 @@ struct TileGeom {
   int cot, pt, n, y0, x0, oy0, ox0, th, tw, npix;
 };
 
+__device__ __forceinline__ int ig_fdiv(int v, unsigned m) { return m ? (int)__umulhi((unsigned)v, m) : v; }
+
 template <bool CLAMP, int NPB>
 __device__ __forceinline__ TileGeom tile_decode(const IgemmParams& p, int L) {
   TileGeom g;
-  g.cot = L % p.n_co_tiles;
-  g.pt = L / p.n_co_tiles;
-  const int txi = g.pt % p.tiles_x;
-  const int tmp = g.pt / p.tiles_x;
-  const int tyi = tmp % p.tiles_y;
-  g.n = tmp / p.tiles_y;
+  g.pt = ig_fdiv(L, p.m_cot);
+  g.cot = L - g.pt * p.n_co_tiles;
+  const int tmp = ig_fdiv(g.pt, p.m_tx);
+  const int txi = g.pt - tmp * p.tiles_x;
+  g.n = ig_fdiv(tmp, p.m_ty);
+  const int tyi = tmp - g.n * p.tiles_y;
   const int TW = p.tw, TH = p.th;
   g.y0 = tyi * TH; g.x0 = txi * TW;
   g.oy0 = g.y0 * p.in_step + p.dy_min; g.ox0 = g.x0 * p.in_step + p.dx_min;

@@ -43,6 +43,7 @@ CASES = {  # name: (n, cin, cout, h, w, k, s, p, d, up)
 which = sys.argv[1:] or list(CASES)
 for name in which:
     n, cin, cout, h, w, k, s, p, d, up = CASES[name]
+    n = int(os.environ.get("MICRO_N", n))      # (batch override: what a joint source + target launch would cost)
     # the variants the NETWORKS launch (and the default build holds, csrc/variants.h): the segmenter's 3x3 layers have a bias,
     # LeakyReLU(0.01) and BatchNorm partial sums -- the bottleneck (b*/mb*) no BatchNorm; the discriminators' stride-2 layers
     # (d*/md*) no bias, LeakyReLU(0.2), no statistics

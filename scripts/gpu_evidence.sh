@@ -4,7 +4,7 @@
 # calibration.  Everything lands in gpurun_out/ (copy the summaries to profiles/).   usage: TAG=r03 bash scripts/gpu_evidence.sh
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 python3 -c "import sys; sys.path.insert(0, '.'); from pointcloududa_amd._lib import csrc_hash; print('csrc_sha256', csrc_hash())" | tee gpurun_out/${TAG}_build_hash.txt
 # (the whole-step traffic first: bench.py quotes roofline.traffic from profiles/rNN_pmc_traffic.csv of THIS build's hash)
 TAG=$TAG bash scripts/gpu_pmc_step.sh > gpurun_out/${TAG}_pmc_step.log 2>&1; rc=$?; echo "pmc_step rc=$rc"
@@ -25,8 +25,12 @@ PCUDA_SHARE_GPU=1 PCUDA_DIST_BACKEND=gloo timeout -k 10 300 python3 -m torch.dis
 PCUDA_DSTREAMS=0 PCUDA_PROF_DUMP=gpurun_out/${TAG}_layers224.csv python3 bench.py --workload mscmrseg_224 --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 python3 scripts/layer_table.py gpurun_out/${TAG}_layers224.csv 60 > gpurun_out/${TAG}_layer_table_224.txt
 PCUDA_TIMELINE=1 python3 scripts/step_timeline.py > gpurun_out/${TAG}_step_timeline.txt 2>&1
-CASES="g32 g64 g128 g256 b512 d2 d4" TAG=$TAG NSETS=2 bash scripts/pmc_conv.sh > gpurun_out/${TAG}_pmc_conv.log 2>&1; echo "pmc_conv rc=$?"
+# (g6432 / g3264: the register-window weight gradient wgrad3r_kernel; p96 / p192: the 1x1 NT-GEMM wgrad1_kernel; d1: d1_fwd_kernel -- round-4 review item 5)
+CASES="g32 g6432 g3264 g64 g128 g256 b512 p96 p192 d1 d2 d4" TAG=$TAG NSETS=3 bash scripts/pmc_conv.sh > gpurun_out/${TAG}_pmc_conv.log 2>&1; echo "pmc_conv rc=$?"
 python3 scripts/mfma_table.py gpurun_out/${TAG}_pmc_conv.csv gpurun_out/${TAG}_mfma_counters.csv > /dev/null; echo "mfma table rc=$?"
 TAG=$TAG bash scripts/pmc_layers.sh > gpurun_out/${TAG}_pmc_layers.log 2>&1; echo "pmc_layers rc=$?"
 TAG=$TAG bash scripts/micro/fetch_calib.sh > gpurun_out/${TAG}_fetch_calib.log 2>&1; echo "fetch_calib rc=$?"
+# per-phase stamps (make CLK=1 -> lib/libpcuda_clk.so) incl. the eight-wave kernel, and the switched-off-phase bounds (XFLAGS=-DPCUDA_WEXP)
+if [ -f pointcloududa_amd/lib/libpcuda_clk.so ]; then PCUDA_LIB=pointcloududa_amd/lib/libpcuda_clk.so python3 scripts/clk_micro.py g32 g64 g128 g256 d2 d4 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_clk_phases.txt; echo "clk rc=$?"; fi
+if [ -f pointcloududa_amd/lib/libpcuda_wexp.so ]; then CASES="g32 g6432 g64 g128 g256 b512 d2 d3 d4" DBGS="0 24 32 64 56 120" bash scripts/micro/wexp.sh > gpurun_out/${TAG}_wexp_bounds.txt 2>&1; echo "wexp rc=$?"; fi
 ls gpurun_out/${TAG}_*

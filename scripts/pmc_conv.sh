@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ / TA / TCP counters of single conv layers (scripts/conv_micro.py cases), one rocprofv3 --pmc pass per counter set,
-# no trace domains; aggregates per kernel into gpurun_out/${TAG}_pmc_conv.csv.   usage: CASES="g32" TAG=r02 [SCRIPT=scripts/micro/rconv_micro.py] bash scripts/pmc_conv.sh
+# no trace domains; aggregates per kernel into gpurun_out/${TAG}_pmc_conv.csv.   usage: CASES="g32" TAG=r02 bash scripts/pmc_conv.sh
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 TAG=${TAG:-r03}
@@ -30,7 +30,7 @@ for f in glob.glob("gpurun_out/pmcc/**/*counter_collection.csv", recursive=True)
 with open("gpurun_out/%s_pmc_conv.csv" % tag, "w") as o:
     o.write("kernel,counter,per_launch,launches\n")
     for k, d in sorted(agg.items()):
-        if "igemm" not in k and "wgrad" not in k and "rconv3" not in k: continue
+        if not any(t in k for t in ("igemm", "wgrad", "d1_fwd", "d1_dgrad", "d5_fwd", "c1_fwd", "pw_")): continue
         for c, (v, n) in sorted(d.items()):
             o.write('"%s",%s,%.1f,%d\n' % (k[:90], c, v / max(n, 1), n))
 print(open("gpurun_out/%s_pmc_conv.csv" % tag).read()[:6000])
