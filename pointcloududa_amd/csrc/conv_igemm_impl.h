@@ -1277,6 +1277,13 @@ static int launch_pipe_s(const IgemmParams& p, const IgemmPlan& pl, hipStream_t 
     occ_cache[cls] = nb;
   }
   int grid = occ_cache[cls] * 256;
+  {   // PCUDA_PIPE_GRIDMUL=k, PCUDA_PIPE_GRIDMUL_MINCHUNKS=c (experiment): k times the resident workgroups for layers with >= c
+      // 32-channel chunks -- shorter static tile lists per workgroup, the hardware dispatcher balances the rest
+    static int mul = -1, minch = -1;
+    if (mul < 0) { const char* e = getenv("PCUDA_PIPE_GRIDMUL"); mul = e ? atoi(e) : 1; if (mul < 1) mul = 1; }
+    if (minch < 0) { const char* e = getenv("PCUDA_PIPE_GRIDMUL_MINCHUNKS"); minch = e ? atoi(e) : 1; }
+    if (p.nchunks >= minch) grid *= mul;
+  }
   if (grid > total) grid = total;
   note_kernel(FOLD ? "igemm_pipe+fold" : (STATS == 2 ? "igemm_pipe+bnred" : "igemm_pipe"));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), pl.lds, s, p, pl.x_cap, total);

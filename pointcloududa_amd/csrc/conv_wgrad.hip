@@ -201,7 +201,23 @@ WgradPlan plan_wgrad(const pcuda_conv_geom* g) {
   if (tgt32 < 0) { const char* e = getenv("PCUDA_WG_BLOCKS32"); tgt32 = e ? atoi(e) : 768; }
   static int tgt64 = -1;
   if (tgt64 < 0) { const char* e = getenv("PCUDA_WG_BLOCKS64"); tgt64 = e ? atoi(e) : 1024; }
-  long long ks = (w.co_blks == 1 ? tgt32 : tgt64) / base;
+  // plans whose LDS footprint leaves room for ONE workgroup per CU (the 16-tap stride-2 layers of the discriminators on the
+  // eight-wave kernel, the dilated bottleneck layers): one round of 256 blocks -- two rounds only doubled their split-K slabs
+  // (round 5, scripts/conv_micro.py: d2 / d3 / d4 0.220 / 0.219 / 0.278 -> 0.205 / 0.204 / 0.258 ms, 512->512 at 16x16 dilation 4
+  // 0.253 -> 0.241; the two-per-CU plans lose 20-30 % at 256).  Sized on the bf16x3 footprint so that the slab count does
+  // not depend on the precision (the workspace query has no precision argument).
+  static int tgt1 = -1;
+  if (tgt1 < 0) { const char* e = getenv("PCUDA_WG_BLOCKS1"); tgt1 = e ? atoi(e) : 256; }
+  bool one_per_cu = false;
+  {
+    const long long full = (long long)w.ih_t * w.iw_t;
+    const long long clipped = (long long)(w.ih_t < g->in_h ? w.ih_t : g->in_h) * (w.iw_t < g->in_w ? w.iw_t : g->in_w) + 1;
+    const size_t zb = (size_t)w.co_tile * WG_ZROW * 2;
+    bool clamp = clipped * 2 <= full;
+    if (!clamp && (size_t)full * IG_REC_BYTES * 2 + zb > (size_t)LDS_HARD) clamp = true;
+    one_per_cu = (size_t)(clamp ? clipped : full) * IG_REC_BYTES * 2 + zb > (size_t)LDS_HARD / 2;
+  }
+  long long ks = (one_per_cu ? tgt1 : (w.co_blks == 1 ? tgt32 : tgt64)) / base;
   if (ks < 1) ks = 1;
   if (ks > ntiles) ks = ntiles;
   // keep the partial slabs (written once, re-read once by the reduce kernel) below ~64 MB (measured:
