@@ -63,8 +63,6 @@ struct IgemmParams {
   int dbg;                 // PCUDA_DBG bits (timing experiments only): 1 no X loads, 2 no MFMA, 4 no epilogue, 8 no W copy
   unsigned long long* dbg_clk;   // PCUDA_DBG bit 128: 8 per-phase cycle sums
   int xq;                  // 1: quad (float4) input staging (in_w % 4 == 0, no upsampling fold)
-  int nt;                  // 1: the transposed epilogue stores with the non-temporal hint (outputs that do not fit the caches behind the
-                           // kernel anyway: the 256x256 level's 268-MB tensors; round 5)
   int fold;                // 1: the epilogue sums 2x2 blocks of the logical output (the data gradient of a nearest-x2-folded
                            // input, unet.py:111): y is the half-resolution tensor, out_w its row length
   // paired column classes of a stride-2 data gradient (dword-store epilogues): row 2c + rx of the launch is channel c,

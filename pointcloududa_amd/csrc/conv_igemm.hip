@@ -413,12 +413,6 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
       }
     }
   }
-  {   // streaming stores for outputs of at least PCUDA_NT_MB megabytes (default: see below; 0 = never)
-    static long long nt_mb = -1;
-    if (nt_mb < 0) { const char* e = getenv("PCUDA_NT_MB"); nt_mb = e ? atoll(e) : 0; }
-    const long long out_bytes = (long long)p.n * (p.cout >> p.pair) * (long long)p.lh * p.oy_mul * p.out_w * 4;
-    p.nt = (nt_mb > 0 && out_bytes >= (nt_mb << 20)) ? 1 : 0;
-  }
   if (p.fold && !(pipe && pl.te && !pl.w8 && pl.npb == 2 && pl.tw == 32 && pl.th == 8 && !pl.clamp && !p.accumulate && !p.pair))
     PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv2d_dgrad_fold: this geometry does not run on the 32 x 8-tile transposed-epilogue kernel");
   if (p.mask_a && (pl.te || p.accumulate || p.stats || p.bias || p.fold || p.y.c1 < (p.cout >> p.pair)))

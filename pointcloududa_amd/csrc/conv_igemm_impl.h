@@ -754,9 +754,7 @@ __global__ __launch_bounds__(256, (WV > 4 ? 1 : 2)) void igemm_pipe_kernel(const
             }
 #pragma unroll
             for (int k = 0; k < HN; ++k) {
-              // (p.nt, uniform: streaming stores for an output larger than the caches behind it -- IgemmParams::nt)
-              if (p.nt) { if (ok[k]) __builtin_nontemporal_store(v[k], (f32x4*)dptr[k]); }
-              else if (ok[k]) *(f32x4*)dptr[k] = v[k];
+              if (ok[k]) *(f32x4*)dptr[k] = v[k];
               if (STATS) {
                 float s1 = (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
                 float s2;
