@@ -93,7 +93,7 @@ __device__ __forceinline__ void ap_split8(const float* v, ap_u32x4& hi4, ap_u32x
 #define AP_CUR_N(c) ((int)((c) >> 20))
 
 // STATS: 0 none, 1 BatchNorm partial sums of the stored values, 2 BatchNorm-backward reduce partials (dgrad)
-template <int STATS, bool DBG = false, bool EXP = false>
+template <int STATS, bool ACC = false, bool DBG = false, bool EXP = false>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void conv3ap_kernel(const ApParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -197,7 +197,6 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
   // registers between the load and the wait; with AGPRs as the landing zone it split the register file 128 / 128 and spilled.
   bool xin = false;              // the unit in flight lies inside the image
   auto x_issue = [&](unsigned cur) {
-    if ((DBG || EXP) && (dbg & 512)) cur &= 63u << 14;   // experiment: every prefetch reads image 0, tile column 0, chunk 0 (cache-hot)
     const int c0 = AP_CUR_CHUNK(cur) * 16;
     const int n = AP_CUR_N(cur);
     const bool first = c0 < xc1;
@@ -254,15 +253,6 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
     AP_COMMIT_PIXEL(0) AP_COMMIT_PIXEL(1) AP_COMMIT_PIXEL(2) AP_COMMIT_PIXEL(3)
 #undef AP_COMMIT_PIXEL
   };
-  // weight chunk of stage `cur` into buffer `buf`: 36 one-KiB pieces, nine per wave of the issuing group
-  auto w_dma = [&](unsigned cur, int buf) {
-    if ((DBG || EXP) && (dbg & 1024)) cur = 0;           // experiment: every weight piece from chunk 0 of co tile 0 (cache-hot)
-    const unsigned char* src = wimg + ((long long)AP_CUR_COT(cur) * nchunks + AP_CUR_CHUNK(cur)) * AP_WBYTES + lane * 16 + w * 1024;
-    const unsigned dst = lds0 + buf * AP_WBYTES + w * 1024;
-#pragma unroll
-    for (int j = 0; j < 9; ++j) ap_dma16(src + j * 4096, dst + j * 4096);
-  };
-
   f32x16 acc[2][2];
   unsigned long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
   if (DBG) tlast = __builtin_readcyclecounter();
@@ -351,9 +341,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
         // traffic, priority or not; in the MFMA wave's own stream an instruction waits for nobody.)
         const unsigned char* wsrc = wimg + ((long long)AP_CUR_COT(pw) * nchunks + AP_CUR_CHUNK(pw)) * AP_WBYTES + lane * 16 + w * 1024;
         const unsigned wdst = lds0 + ((sidx + 1) & 1) * AP_WBYTES + w * 1024;
-        const bool dma_here = g == 0 && !((DBG || EXP) && (dbg & (256 | 128)));
+        const bool dma_here = g == 0;
 #define AP_DMA_TAP(j) if (dma_here) { ap_dma16(wsrc + (j) * 4096, wdst + (j) * 4096); } __builtin_amdgcn_sched_barrier(0);
-        if ((DBG || EXP) && (dbg & 32)) __builtin_amdgcn_s_setprio(1);
         __builtin_amdgcn_sched_barrier(0);
         AP_LOAD(0, 0)
         AP_WAIT_FRAGS(0, fa[0], fb[0]);
@@ -384,10 +373,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
         *(float2*)dst = make_float2(a, b);
         stat_pending = false;
       }
-      if ((DBG || EXP) && (dbg & 32)) __builtin_amdgcn_s_setprio(0);
       if (DBG) asm volatile("s_nop 0" ::"v"(acc[0][0][15]), "v"(acc[1][1][15]));
       AP_CLK(1)
-      if ((DBG || EXP) && (dbg & 128) && g == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       if (sidx < S) {
         epi_pending = AP_CUR_CHUNK(cw) == nchunks - 1;
         dw = epi_pending ? cw : dw;
@@ -415,7 +402,6 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
         const unsigned pl1 = (unsigned)p.y.sc1 * 4u, pl2 = (unsigned)p.y.sc2 * 4u;
         const unsigned voff1 = (unsigned)cs * pl1 + pixq, voff2 = (unsigned)cs * pl2 + pixq;   // per lane; the plane base is scalar
         const float slope = p.slope;
-        const int accumulate = p.accumulate;
         const char* const ab = STATS == 2 ? (const char*)(p.red_a + (long long)dn * p.red_sn) : nullptr;
         const unsigned aoff = STATS == 2 ? (unsigned)cs * (unsigned)p.red_sc * 4u + pixq : 0u;
 #pragma unroll
@@ -440,23 +426,25 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               const int cu = co0 + cb * 32 + (ib + k) * 4;         // uniform; the 4 channels lie in one destination
-              const bool first = cu < c1;
-              const char* sbase = first ? yb1 + (long long)cu * pl1 : yb2 + (long long)(cu - c1) * pl2;   // scalar
-              dptr[k] = (char*)sbase + (first ? voff1 : voff2);
+              const bool first = cu < c1;                          // (selects on scalars: no branch per store)
+              const char* const sb = first ? yb1 : yb2;
+              const unsigned plane = first ? pl1 : pl2;
+              const unsigned rel = (unsigned)(first ? cu : cu - c1);
+              dptr[k] = (char*)sb + (unsigned long long)rel * plane + (first ? voff1 : voff2);
               if (STATS == 2) av[k] = *(const f32x4*)(ab + (long long)cu * p.red_sc * 4 + aoff);
-              if (accumulate) o[k] = *(const f32x4*)dptr[k];
+              if (ACC) o[k] = *(const f32x4*)dptr[k];
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                float t = v[ib + k][e] + bia[ib + k];
-                t = t > 0.f ? t : t * slope;
-                v[ib + k][e] = accumulate ? t + o[k][e] : t;
+                const float t = v[ib + k][e] + bia[ib + k];
+                const float a = fmaxf(t, t * slope);               // LeakyReLU for 0 <= slope <= 1 (the launcher checks): the
+                v[ib + k][e] = ACC ? a + o[k][e] : a;              // same value as t > 0 ? t : t * slope, one instruction less
               }
-              *(f32x4*)dptr[k] = v[ib + k];
+              if (!((DBG || EXP) && (dbg & 16))) *(f32x4*)dptr[k] = v[ib + k];
             }
-            if (STATS) {
+            if (STATS && !((DBG || EXP) && (dbg & 32))) {
               float s1[4], s2[4];
 #pragma unroll
               for (int k = 0; k < 4; ++k) {
@@ -488,8 +476,6 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
       }
       epi_pending = false;
       AP_CLK(3)
-      if ((DBG || EXP) && (dbg & 128) && g == 1) w_dma(nw, (sidx + 1) & 1);   // experiment: B's memory segment brings W(nw)
-      if ((DBG || EXP) && (dbg & 64)) __builtin_amdgcn_s_setprio(3);
       AP_CLK(2)
       // the prefetch of the stage after `cw` (past the end: a valid tile again, so that the counted wait stays exact)
       if (!(dbg & 4)) {
@@ -497,7 +483,6 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
         x_issue(nw);
         advance_n();
       }
-      if ((DBG || EXP) && (dbg & 64)) __builtin_amdgcn_s_setprio(0);
       AP_CLK(5)
     }
     AP_BARRIER();

@@ -165,6 +165,19 @@ static inline bool te_dst_ok(const pcuda_dst* y, int cout, int out_w, int lw, in
 }
 
 
+// anti-phase 3x3 kernel (conv_ap.hip): layer property, packed image, launcher (returns 1 when it took the launch)
+struct IgemmParams;
+struct PackParams;
+bool ap_layer_ok(const pcuda_conv_geom* g, int rows, int red, int prec);
+size_t ap_layer_packed_bytes(int rows, int red);
+bool ap_fill_pack(PackParams& p, const float* w, unsigned char* out, int rows, int red, long long s_row, long long s_red,
+                  const TapSet& taps);
+int ap_launch_pack(const float* w, unsigned char* out, int rows, int red, long long s_row, long long s_red, const TapSet& taps,
+                   hipStream_t s);
+bool ap_map_ok(int n, int h, int w);
+int ap_tiles(int n, int h, int w);
+int ap_try_launch(const IgemmParams& p, const TapSet& taps, const unsigned char* image, hipStream_t s, int* rc);
+
 // direct (vector-ALU) kernels of the degenerate layers (conv_direct.hip); each returns 1 when it took the launch
 int direct_fwd_tiles(const pcuda_conv_geom* g);
 int direct_forward(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const void* packed_w, long long w_lo_off,

@@ -128,6 +128,34 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const PackParams* __res
     }
   }
   __syncthreads();
+  if (p.rec == 32) {
+    // anti-phase image (conv_ap_impl.h): [co tile][16-channel chunk][tap][row 0..63][64 B]; a record's four 16-byte pieces
+    // (hi k 0-7, hi k 8-15, lo k 0-7, lo k 8-15) sit in slot q ^ ((row >> 2) & 3): the image IS the kernel's LDS image
+    const int nch16 = p.red >> 4;
+    for (int it = threadIdx.x; it < p.ntaps * PACK_ROWS * 8; it += 256) {
+      const int t = it / (PACK_ROWS * 8), rem = it - t * (PACK_ROWS * 8);
+      const int rowi = rem >> 3, vec = rem & 7;
+      const int half16 = vec >> 2, q = vec & 3;
+      const int c16 = ch * 2 + half16;
+      if (c16 >= nch16) continue;
+      const int cb = half16 * 16 + (q & 1) * 8;
+      const int ts = p.tap_src[t];
+      uint32_t o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int cc = cb + 2 * j;
+        const float v0 = sw[(by_row ? rowi * 32 + cc : cc * nsr + rowi) * kk + ts];
+        const float v1 = sw[(by_row ? rowi * 32 + cc + 1 : (cc + 1) * nsr + rowi) * kk + ts];
+        uint32_t hi, lo;
+        split2(v0, v1, hi, lo);
+        o[j] = (q & 2) ? lo : hi;
+      }
+      const int row = rg * PACK_ROWS + rowi;
+      unsigned char* dst = (unsigned char*)p.out + ((((long long)cot * nch16 + c16) * 9 + t) * 64 + row) * 64 + ((q ^ ((row >> 2) & 3)) << 4);
+      *(uint4*)dst = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    return;
+  }
   const bool x3 = p.rec > IG_REC;
   const int nvec = p.rec >> 3;                                // 16-byte vectors per record: 4 hi (+ 4 lo) + 1 pad
   const int per_t = PACK_ROWS * nvec;
@@ -339,7 +367,12 @@ int plan_igemm(int rows, int red, int n, int lh, int lw, int in_h, int in_w, int
   return 0;
 }
 
-int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
+// ap_image: the layer's anti-phase image (behind its ordinary packed layout), or NULL
+int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s, const unsigned char* ap_image = nullptr) {
+  {
+    int rc;
+    if (ap_image && prec == PCUDA_PREC_BF16X3 && ap_try_launch(p, taps, ap_image, s, &rc)) return rc;
+  }
   const bool x3 = prec == PCUDA_PREC_BF16X3;
   const int co_blks = ig_co_blks(p.cout);
   const int co_tile = 32 * co_blks;
@@ -347,6 +380,11 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
   if (plan_igemm(p.cout, p.cin, p.n, p.lh, p.lw, p.in_h, p.in_w, p.in_step, taps, x3, &pl, true) < 0)
     PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "igemm: no tile of this convolution fits LDS (in_step %d, tap span %d)",
                p.in_step, taps.dy_max - taps.dy_min);
+  // (a launch the anti-phase kernel was expected to take -- the caller sized its partial sums by THAT kernel's tiles -- but did
+  //  not, e.g. misaligned tensors: only if this plan writes the same tiles)
+  if (ap_image && p.stats && ap_map_ok(p.n, p.in_h, p.in_w) && p.in_step == 1 && !p.fold &&
+      (long long)pl.tiles_x * pl.tiles_y * p.n != ap_tiles(p.n, p.in_h, p.in_w))
+    PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv: tensors the anti-phase kernel cannot address on a map whose ordinary plan has other tiles");
   p.n_co_tiles = cdiv(p.cout, co_tile);
   p.nchunks = cdiv(p.cin, 32);
   p.tw = pl.tw; p.th = pl.th; p.tmagic = 65536 / pl.tw + 1; p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y;
@@ -425,9 +463,10 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
+// (the anti-phase image of a layer that has one sits BEHIND its ordinary layout: every launch can still take the ordinary kernels)
 extern "C" size_t pcuda_conv2d_packed_fwd_bytes(const pcuda_conv_geom* g, int prec) {
   if (!geom_ok(g)) return 0;
-  return packed_elems(g->cout, g->cin, g->k * g->k, prec) * 2;
+  return packed_elems(g->cout, g->cin, g->k * g->k, prec) * 2 + (ap_layer_ok(g, g->cout, g->cin, prec) ? ap_layer_packed_bytes(g->cout, g->cin) : 0);
 }
 
 extern "C" size_t pcuda_conv2d_packed_dgrad_bytes(const pcuda_conv_geom* g, int prec) {
@@ -442,6 +481,7 @@ extern "C" size_t pcuda_conv2d_packed_dgrad_bytes(const pcuda_conv_geom* g, int 
       TapSet t = dgrad_taps(g, ry, rx);
       tot += packed_elems(g->cin, g->cout, t.n, prec) * 2;
     }
+  if (ap_layer_ok(g, g->cin, g->cout, prec)) tot += ap_layer_packed_bytes(g->cin, g->cout);
   return tot;
 }
 
@@ -450,7 +490,11 @@ extern "C" int pcuda_conv2d_pack_fwd(const pcuda_conv_geom* g, int prec, const f
   if (!geom_ok(g) || !w || !packed) PCUDA_FAIL(PCUDA_E_BADARG, "pack_fwd: bad geometry or null pointer");
   const int kk = g->k * g->k;
   TapSet t = fwd_taps(g);
-  return launch_pack(w, (uint16_t*)packed, prec, g->cout, g->cin, (long long)g->cin * kk, kk, t, (hipStream_t)s);
+  int rc = launch_pack(w, (uint16_t*)packed, prec, g->cout, g->cin, (long long)g->cin * kk, kk, t, (hipStream_t)s);
+  if (rc == PCUDA_OK && ap_layer_ok(g, g->cout, g->cin, prec))
+    rc = ap_launch_pack(w, (unsigned char*)packed + packed_elems(g->cout, g->cin, kk, prec) * 2, g->cout, g->cin,
+                        (long long)g->cin * kk, kk, t, (hipStream_t)s);
+  return rc;
 }
 
 extern "C" int pcuda_conv2d_pack_dgrad(const pcuda_conv_geom* g, int prec, const float* w, void* packed,
@@ -474,6 +518,8 @@ extern "C" int pcuda_conv2d_pack_dgrad(const pcuda_conv_geom* g, int prec, const
       if (rc) return rc;
       out += packed_elems(g->cin, g->cout, t.n, prec);
     }
+  if (ap_layer_ok(g, g->cin, g->cout, prec))
+    return ap_launch_pack(w, (unsigned char*)out, g->cin, g->cout, kk, (long long)g->cin * kk, dgrad_taps(g, 0, 0), (hipStream_t)s);
   return PCUDA_OK;
 }
 
@@ -512,12 +558,24 @@ extern "C" int pcuda_conv2d_pack_all(const pcuda_conv_geom* g, int prec, const f
   const int blocks = (int)((maxplane + 255) / 256 > 2048 ? 2048 : (maxplane + 255) / 256);
   hipLaunchKernelGGL(pack_multi_kernel, dim3(blocks, jobs.n), dim3(256), 0, (hipStream_t)s, jobs);
   PCUDA_CHECK_LAUNCH("pack_multi_kernel");
+  if (ap_layer_ok(g, g->cout, g->cin, prec)) {
+    int rc = ap_launch_pack(w, (unsigned char*)packed_fwd + packed_elems(g->cout, g->cin, kk, prec) * 2, g->cout, g->cin,
+                            (long long)g->cin * kk, kk, fwd_taps(g), (hipStream_t)s);
+    if (rc) return rc;
+  }
+  if (packed_dgrad && ap_layer_ok(g, g->cin, g->cout, prec)) {   // (stride 1: one class in front of the image)
+    TapSet t = dgrad_taps(g, 0, 0);
+    int rc = ap_launch_pack(w, (unsigned char*)packed_dgrad + packed_elems(g->cin, g->cout, t.n, prec) * 2, g->cin, g->cout, kk,
+                            (long long)g->cin * kk, t, (hipStream_t)s);
+    if (rc) return rc;
+  }
   return PCUDA_OK;
 }
 
 extern "C" int pcuda_conv2d_fwd_tiles(const pcuda_conv_geom* g, int prec) {
   if (!geom_ok(g)) return 0;
   if (const int d = direct_fwd_tiles(g)) return d;
+  if (ap_layer_ok(g, g->cout, g->cin, prec) && ap_map_ok(g->n, g->in_h, g->in_w)) return ap_tiles(g->n, g->in_h, g->in_w);
   TapSet t = fwd_taps(g);
   IgemmPlan pl;
   if (plan_igemm(g->cout, g->cin, g->n, g->out_h, g->out_w, g->in_h, g->in_w, g->stride, t, prec == PCUDA_PREC_BF16X3, &pl) < 0)
@@ -552,7 +610,9 @@ extern "C" int pcuda_conv2d_forward(const pcuda_conv_geom* g, int prec, const pc
   p.bias = bias; p.slope = slope; p.accumulate = 0; p.stats = bn_partials;
   p.n = g->n;
   TapSet t = fwd_taps(g);
-  return launch_igemm(p, prec, t, (hipStream_t)s);
+  const unsigned char* ap_image = ap_layer_ok(g, g->cout, g->cin, prec)
+                                      ? (const unsigned char*)packed_w + packed_elems(g->cout, g->cin, g->k * g->k, prec) * 2 : nullptr;
+  return launch_igemm(p, prec, t, (hipStream_t)s, ap_image);
 }
 
 // mask_a != NULL: the LeakyReLU backward of the layer in front rides in the epilogue (pcuda_conv2d_dgrad_lrelu)
@@ -612,7 +672,8 @@ static int dgrad_impl(const pcuda_conv_geom* g, int prec, const pcuda_src* dy, c
         p.bias = nullptr; p.slope = 1.f; p.accumulate = accumulate; p.stats = nullptr;
         p.mask_a = mask_a; p.mask_sn = mask_sn; p.mask_slope = mask_slope;
         p.n = g->n;
-        int rc = launch_igemm(p, prec, t, (hipStream_t)s);
+        const unsigned char* ap_image = (!mask_a && ap_layer_ok(g, g->cin, g->cout, prec)) ? (const unsigned char*)(wp + plane) : nullptr;
+        int rc = launch_igemm(p, prec, t, (hipStream_t)s, ap_image);
         if (rc) return rc;
       }
       wp += plane;
@@ -636,6 +697,9 @@ extern "C" int pcuda_conv2d_dgrad_lrelu(const pcuda_conv_geom* g, int prec, cons
   if (!a || !dx) PCUDA_FAIL(PCUDA_E_BADARG, "conv2d_dgrad_lrelu: bad tensors");
   if (dx->c1 < g->cin || a_sc != dx->sc1 || g->in_up)
     PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv2d_dgrad_lrelu: one NCHW destination with the activation's plane stride");
+  // (a data gradient the anti-phase kernel takes has no masked store: the caller runs that kernel + pcuda_lrelu_bwd)
+  if (ap_layer_ok(g, g->cin, g->cout, prec) && ap_map_ok(g->n, g->in_h, g->in_w))
+    PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv2d_dgrad_lrelu: this layer's data gradient runs on the anti-phase kernel");
   return dgrad_impl(g, prec, dy, packed_w_dgrad, dx, 0, a, a_sn, slope, s);
 }
 
@@ -657,6 +721,7 @@ extern "C" int pcuda_debug_read_clocks(unsigned long long* out8) {
 extern "C" int pcuda_conv2d_dgrad_tiles(const pcuda_conv_geom* g, int prec) {
   if (!geom_ok(g) || g->stride != 1) return 0;
   if (const int d = direct_dgrad_tiles(g)) return d;
+  if (ap_layer_ok(g, g->cin, g->cout, prec) && ap_map_ok(g->n, g->in_h, g->in_w)) return ap_tiles(g->n, g->in_h, g->in_w);
   TapSet t = dgrad_taps(g, 0, 0);
   IgemmPlan pl;
   if (plan_igemm(g->cin, g->cout, g->n, g->in_h, g->in_w, g->out_h, g->out_w, 1, t, prec == PCUDA_PREC_BF16X3, &pl) < 0) return 0;
@@ -692,7 +757,9 @@ extern "C" int pcuda_conv2d_dgrad_bnred(const pcuda_conv_geom* g, int prec, cons
   p.stats = red_partials;
   p.red_a = a; p.red_sn = a_sn; p.red_sc = a_sc; p.red_mean = mean; p.red_invstd = invstd;
   p.n = g->n;
-  return launch_igemm(p, prec, t, (hipStream_t)s);
+  const unsigned char* ap_image = ap_layer_ok(g, g->cin, g->cout, prec)
+                                      ? (const unsigned char*)packed_w_dgrad + packed_elems(g->cin, g->cout, t.n, prec) * 2 : nullptr;
+  return launch_igemm(p, prec, t, (hipStream_t)s, ap_image);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -748,6 +815,12 @@ extern "C" int pcuda_conv2d_pack_jobs_fill(const pcuda_conv_geom* g, int prec, c
   int nj = 0;
   size_t plane = fill_pack(jobs[nj], w, (uint16_t*)packed_fwd, prec, g->cout, g->cin, (long long)g->cin * kk, kk, fwd_taps(g));
   job_blocks[nj] = pack_table_blocks(jobs[nj]); ++nj;
+  if (ap_layer_ok(g, g->cout, g->cin, prec)) {   // the anti-phase image behind the forward layout
+    if (nj >= max_jobs) PCUDA_FAIL(PCUDA_E_BADARG, "pack_jobs_fill: more layouts than job slots");
+    if (!ap_fill_pack(jobs[nj], w, (unsigned char*)packed_fwd + plane * 2, g->cout, g->cin, (long long)g->cin * kk, kk, fwd_taps(g)))
+      PCUDA_FAIL(PCUDA_E_BADARG, "pack_jobs_fill: anti-phase image of a layer that is not 3x3");
+    job_blocks[nj] = pack_table_blocks(jobs[nj]); ++nj;
+  }
   if (packed_dgrad && dgrad_pair_ok(g)) {
     uint16_t* out = (uint16_t*)packed_dgrad;
     for (int ry = 0; ry < 2; ++ry) {
@@ -767,6 +840,12 @@ extern "C" int pcuda_conv2d_pack_jobs_fill(const pcuda_conv_geom* g, int prec, c
         job_blocks[nj] = pack_table_blocks(jobs[nj]); ++nj;
         out += plane;
       }
+    if (ap_layer_ok(g, g->cin, g->cout, prec)) {   // the anti-phase image behind the (single) data-gradient layout
+      if (nj >= max_jobs) PCUDA_FAIL(PCUDA_E_BADARG, "pack_jobs_fill: more layouts than job slots");
+      if (!ap_fill_pack(jobs[nj], w, (unsigned char*)out, g->cin, g->cout, kk, (long long)g->cin * kk, dgrad_taps(g, 0, 0)))
+        PCUDA_FAIL(PCUDA_E_BADARG, "pack_jobs_fill: anti-phase image of a layer that is not 3x3");
+      job_blocks[nj] = pack_table_blocks(jobs[nj]); ++nj;
+    }
   }
   return nj;
 }

@@ -55,9 +55,13 @@ for name in which:
     b = None if disc else torch.zeros(cout, device=dev)
     oh, ow = op.out_hw(h, w)
     gz = torch.randn(n, cout, oh, ow, device=dev)
+    # MICRO_DATA=zeros: all-zero operands, zerow: zero weights only -- the SAME instruction streams on operands that do not
+    # toggle the multipliers: what the kernels' clock is under (round 6: profiles/r06_experiment_power_cap.txt)
+    if os.environ.get("MICRO_DATA") == "zeros": x.zero_(); wt.zero_(); gz.zero_()
+    if os.environ.get("MICRO_DATA") == "zerow": wt.zero_()
     dw = torch.zeros_like(wt)
     fl = 2.0 * n * oh * ow * cout * cin * k * k
-    def t(fn, reps=10):
+    def t(fn, reps=int(os.environ.get("MICRO_REPS", 10))):
         fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(reps): fn()
         torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps

@@ -1,15 +1,10 @@
 #!/bin/bash
-# is the kernel power- (clock-) limited?  the same instruction stream on random data, on zero weights, on all-zero operands
+# what the epilogue's time is made of (DBG build, mode 1): dbg 16 = no output stores, 32 = no partial sums, 48 = neither
 B=scripts/micro/bin/conv3ap_micro
 mkdir -p gpurun_out
 O=gpurun_out/conv3ap_exp.txt
 : > $O
-for rep in 1 2; do
-for shape in "32 256 256 32 32" "32 64 64 128 128"; do
-  for dm in 0 2 1; do
-    echo "== $shape data $dm" | tee -a $O
-    AP_DATA=$dm $B $shape 200 0 0 2>&1 | grep "time" | tee -a $O
-    AP_DATA=$dm $B $shape 200 0 1 2>&1 | grep "time\|group A" | tee -a $O
-  done
-done
+for d in 0 16 32 48 2; do
+  echo "== dbg $d" | tee -a $O
+  $B 32 64 64 128 128 50 $d 1 2>&1 | grep "time\|group A" | tee -a $O
 done

@@ -63,7 +63,7 @@ int main(int argc, char** argv) {
   if (ntiles & 1) { printf("odd tile count\n"); return 1; }
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   const int grid = std::min(prop.multiProcessorCount, p.total);
-  auto kern = clkmode == 1 ? conv3ap_kernel<1, true, false> : (clkmode == 2 ? conv3ap_kernel<1, false, true> : conv3ap_kernel<1, false, false>);
+  auto kern = clkmode == 1 ? conv3ap_kernel<1, false, true, false> : (clkmode == 2 ? conv3ap_kernel<1, false, false, true> : conv3ap_kernel<1, false, false, false>);
   CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, AP_LDS_BYTES));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), AP_LDS_BYTES, 0, p);
   CK(hipDeviceSynchronize());

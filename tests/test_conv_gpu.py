@@ -408,7 +408,8 @@ def test_dgrad_with_the_2x2_fold_in_its_epilogue(dev, prec, n, cin, cout, h, w):
     (2, 64, 128, 113, 113, 4, 2, 2, True),      # the 224 x 224 input's second layer
     (2, 32, 48, 40, 36, 4, 2, 1, True),         # even maps, another padding
     (2, 40, 24, 21, 19, 3, 1, 1, True),         # stride 1 on rows that are no multiple of 4: plain epilogue
-    (2, 64, 64, 32, 32, 3, 1, 1, True),         # few tiles: the eight-wave kernel (plain epilogue)
+    (2, 64, 64, 32, 32, 3, 1, 1, True),         # few tiles: the eight-wave kernel (plain epilogue); in bf16x3 mode the
+                                                # anti-phase kernel takes this layer's data gradient (round 6): not fused there
     (88, 64, 64, 32, 32, 3, 1, 1, False),       # transposed-epilogue plan: not taken, the two-kernel form runs
 ])
 def test_dgrad_with_the_leaky_relu_backward_in_its_epilogue(dev, prec, n, cin, cout, h, w, k, stride, pad, fused):
@@ -418,6 +419,9 @@ def test_dgrad_with_the_leaky_relu_backward_in_its_epilogue(dev, prec, n, cin, c
     import ctypes as C
     from pointcloududa_amd import _lib as L, kernels as K
     K.set_precision(prec)
+    if (prec == "bf16x3" and k == 3 and stride == 1 and pad == 1 and cin % 64 == 0 and cout % 16 == 0 and h % 8 == 0 and
+            w % 32 == 0 and (n * (h // 8) * (w // 32)) % 2 == 0):
+        fused = False    # csrc/conv_ap.hip takes the plain data gradient of this layer: dgrad_lrelu reports UNSUPPORTED
     try:
         rng = np.random.default_rng(cin + h + k)
         oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
