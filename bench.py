@@ -377,7 +377,15 @@ def main():
 
     # PCUDA_GRAPH=1 (single process): replay the step from a captured hipGraph.  Off by default: measured 68.7 vs
     # 69.4 ms/step -- the ~4 ms between kernels is dependent-launch latency on the GPU, not host launch time.
-    use_graph = os.environ.get("PCUDA_GRAPH", "0") == "1"
+    # Default: eager where the rank has >= 4 host cores (22 ms of host issue time under a 44-ms GPU step), hipGraph replay
+    # (10 ms, the tested path of tests/test_step_gpu.py) where it has fewer -- eight ranks on a 16-core host.
+    try:
+        cores_here = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores_here = os.cpu_count() or 1
+    graph_env = os.environ.get("PCUDA_GRAPH")
+    use_graph = graph_env == "1" if graph_env is not None else cores_here < 4
+    graph_why = ("PCUDA_GRAPH=%s" % graph_env) if graph_env is not None else ("%d host cores for this rank" % cores_here)
     step = tr.step_graphed if use_graph else tr.step
     # settle phase (untimed setup, not part of --warmup): lazily created buffers, packed-weight caches, allocator pools
     # of the side streams and the GPU's clocks reach their steady state only after a second or two of work
@@ -476,15 +484,21 @@ def main():
                    # replayed from the adversarial pass, 7 of them execute for those two networks
                    "executed_gflop_per_pair": round(wl["gflop_per_pair"] - (2 * wl.get("d_gflop", 3.60 * (wl.get("hw", 256) / 256.0) ** 2)
                                                     * (int(wl["d1"]) + int(wl["d2"])) / 2.0 if tr.d_reuse else 0.0), 1),
-                   "box_to_box": "638-690 img/s measured for the default command across MI355X boxes in rounds 3-4 (boxes of the pool differ by up to 10 % on one binary)",
+                   "box_to_box": "693-741 img/s measured for the default command across the MI355X boxes of round 6 (probe clocks 2.08-2.35 GHz; profiles/r06_box_scatter.txt); compare lines by img_s_per_ghz",
                    "streams": "discriminators concurrent" if tr.d_streams else "single",
                    # d1 / d2 see the target batch twice per step with the same weights and the same input values
                    # (adversarial pass, then their own update): the second forward is replayed from the first's
                    # activations.  PCUDA_DREUSE=0 runs it again (same bits, ~1.5 ms per step more).
                    "d_target_forward": "replayed from the adversarial pass of the same step" if tr.d_reuse else "run twice",
-                   "launch": "hipGraph replay" if (use_graph and getattr(tr, "_graph", None) is not None) else "eager",
+                   "launch": ("hipGraph replay" if (use_graph and getattr(tr, "_graph", None) is not None) else "eager") + " (" + graph_why + ")",
                    "losses": {k: round(host[k], 5) for k in ("seg_loss", "adv_loss") if k in host}},
     }
+
+    # value / probe clock: what normalises lines from boxes of different clocks (the probe is an all-SIMD MFMA loop on trivial
+    # operands: the clock the box GRANTS, not the lower one the convolution kernels hold on real data --
+    # profiles/r06_experiment_power_cap.txt)
+    if result["clock_ghz_under_load"]:
+        result["img_s_per_ghz"] = round(result["value"] / world / result["clock_ghz_under_load"], 1)
 
     if not args.no_roofline:
         # every rank runs the profiled steps (they hold collectives when world > 1); rank 0 reports its own kernels

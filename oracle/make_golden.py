@@ -40,7 +40,16 @@ from networks.PointNetCls import PointNetCls                        # noqa: E402
 from networks.unet import Segmentation_model_Point                  # noqa: E402
 from utils.npy2point import graipher                                # noqa: E402
 
-GOLD = os.path.join(REPO, "tests", "golden")
+GOLD_COMMITTED = os.path.join(REPO, "tests", "golden")
+# --check: regenerate every fixture into a scratch directory and compare byte for byte with the committed ones (exit status 1
+# on any difference, a missing or an extra file): the pinning of the oracle against the reference, as a command
+CHECK = "--check" in sys.argv
+if CHECK:
+    import tempfile
+    sys.argv.remove("--check")
+    GOLD = tempfile.mkdtemp(prefix="golden_check_")
+else:
+    GOLD = GOLD_COMMITTED
 os.makedirs(GOLD, exist_ok=True)
 torch.set_num_threads(8)
 
@@ -973,3 +982,12 @@ if __name__ == "__main__":
         gold_seg("seg_full256", _full, b=2, hw=256, seed=500, full_tensors=False)
     else:
         main()
+    if CHECK:
+        import filecmp
+        import shutil
+        names = sorted(set(os.listdir(GOLD)) | {f for f in os.listdir(GOLD_COMMITTED) if f.endswith(".npz")})
+        bad = [f for f in names if not (os.path.exists(os.path.join(GOLD, f)) and os.path.exists(os.path.join(GOLD_COMMITTED, f))
+                                        and filecmp.cmp(os.path.join(GOLD, f), os.path.join(GOLD_COMMITTED, f), shallow=False))]
+        shutil.rmtree(GOLD, ignore_errors=True)
+        print("golden check: %d fixtures regenerated, %d differ%s" % (len(names), len(bad), (": " + ", ".join(bad)) if bad else ""))
+        sys.exit(1 if bad else 0)
