@@ -19,7 +19,9 @@ static int ap_enabled() {
 // whatever maps the layer later runs on.  rows / red: output rows and reduction channels of the launch (forward: cout, cin;
 // data gradient: cin, cout).
 bool ap_layer_ok(const pcuda_conv_geom* g, int rows, int red, int prec) {
-  return ap_enabled() && prec == PCUDA_PREC_BF16X3 && g->k == 3 && g->stride == 1 && g->pad == 1 && g->dil == 1 && !g->in_up &&
+  // (in_up layers, unet.py:111: the forward reads the stored half-resolution input through the fold, the data gradient folds
+  //  2x2 blocks in its epilogue)
+  return ap_enabled() && prec == PCUDA_PREC_BF16X3 && g->k == 3 && g->stride == 1 && g->pad == 1 && g->dil == 1 &&
          rows >= 64 && (rows & 63) == 0 && red >= 16 && (red & 15) == 0 && rows <= AP_MAX_C && red <= AP_MAX_C;
 }
 size_t ap_layer_packed_bytes(int rows, int red) { return ap_packed_bytes(rows, red); }
@@ -87,8 +89,11 @@ int ap_tiles(int n, int h, int w) { return n * (h / 8) * (w / 32); }
 static bool ap_launch_ok(const IgemmParams& p, const TapSet& taps) {
   signed char src9[9];
   if (!ap_enabled() || !ap_tap_order(taps, src9)) return false;
-  if (p.in_step != 1 || p.in_shift || p.pair || p.fold || p.mask_a || p.oy_mul != 1 || p.ox_mul != 1 || p.oy_off || p.ox_off) return false;
-  if (p.lh != p.in_h || p.lw != p.in_w || p.out_w != p.in_w || p.in_row != p.in_w) return false;
+  if (p.in_step != 1 || p.pair || p.mask_a || p.oy_mul != 1 || p.ox_mul != 1 || p.oy_off || p.ox_off) return false;
+  if (p.in_shift && (p.fold || p.in_row != (p.in_w >> 1))) return false;            // forward through the nearest-x2 fold
+  if (!p.in_shift && p.in_row != p.in_w) return false;
+  if (p.lh != p.in_h || p.lw != p.in_w || p.out_w != (p.fold ? p.in_w >> 1 : p.in_w)) return false;
+  if (p.fold && (p.accumulate || p.bias || (p.stats && !p.red_a))) return false;      // data gradient with the 2x2 fold
   if (!ap_geom_ok(p.cout, p.cin, p.in_h, p.in_w) || !ap_map_ok(p.n, p.in_h, p.in_w)) return false;
   if (!(p.slope >= 0.f && p.slope <= 1.f)) return false;
   // input: a 16-channel chunk lies in one source, rows of float4, 32-bit element offsets inside an image
@@ -97,24 +102,31 @@ static bool ap_launch_ok(const IgemmParams& p, const TapSet& taps) {
   if (c1 < p.cin && (c1 & 15)) return false;
   if (((uintptr_t)x.p1 & 15) || (x.sn1 & 3) || (x.sc1 & 3) || x.sc1 >= (1ll << 26)) return false;
   if (c1 < p.cin && (((uintptr_t)x.p2 & 15) || (x.sn2 & 3) || (x.sc2 & 3) || x.sc2 >= (1ll << 26))) return false;
-  // output: 16-byte row segments, four consecutive rows in one destination
-  if (!te_dst_ok(&p.y, p.cout, p.out_w, p.lw, 32, 1, 0)) return false;
+  // output: 16-byte row segments, four consecutive rows in one destination (fold: 8-byte pairs, eight rows)
   const int yc1 = p.y.c1 < p.cout ? p.y.c1 : p.cout;
+  if (p.fold) {
+    if (((uintptr_t)p.y.p1 & 7) || (p.y.sc1 & 1) || (p.y.sn1 & 1) || (p.out_w & 1)) return false;
+    if (yc1 < p.cout && (((uintptr_t)p.y.p2 & 7) || (p.y.sc2 & 1) || (p.y.sn2 & 1) || (yc1 & 7))) return false;
+    if (p.red_a && (((uintptr_t)p.red_a & 7) || (p.red_sn & 1) || (p.red_sc & 1))) return false;
+  } else {
+    if (!te_dst_ok(&p.y, p.cout, p.out_w, p.lw, 32, 1, 0)) return false;
+    if (p.red_a && (((uintptr_t)p.red_a & 15) || (p.red_sn & 3) || (p.red_sc & 3))) return false;
+  }
   if (yc1 < p.cout && (yc1 & 3)) return false;
   if (p.y.sc1 >= (1ll << 26) || (yc1 < p.cout && p.y.sc2 >= (1ll << 26))) return false;
-  if (p.red_a && (((uintptr_t)p.red_a & 15) || (p.red_sn & 3) || (p.red_sc & 3) || !p.stats)) return false;
+  if (p.red_a && !p.stats) return false;
   return true;
 }
 
-template <int STATS, bool ACC>
+template <int STATS, bool ACC, bool FOLD = false>
 static int ap_launch_t(const ApParams& ap, int grid, hipStream_t s) {
   static DeviceOnce once;
   if (const unsigned long long bit = once.pending()) {
-    if (hipFuncSetAttribute((const void*)conv3ap_kernel<STATS, ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, AP_LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)conv3ap_kernel<STATS, ACC, false, false, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, AP_LDS_BYTES) != hipSuccess)
       PCUDA_FAIL(PCUDA_E_LAUNCH, "conv3ap_kernel: cannot opt in to %d bytes of LDS", AP_LDS_BYTES);
     once.mark(bit);
   }
-  hipLaunchKernelGGL((conv3ap_kernel<STATS, ACC>), dim3(grid), dim3(512), AP_LDS_BYTES, s, ap);
+  hipLaunchKernelGGL((conv3ap_kernel<STATS, ACC, false, false, FOLD>), dim3(grid), dim3(512), AP_LDS_BYTES, s, ap);
   PCUDA_CHECK_LAUNCH("conv3ap_kernel");
   return PCUDA_OK;
 }
@@ -133,6 +145,7 @@ int ap_try_launch(const IgemmParams& p, const TapSet& taps, const unsigned char*
   ap.tiles_x = p.in_w / 32; ap.tiles_y = p.in_h / 8; ap.n = p.n;
   ap.n_co_tiles = p.cout / 64; ap.nchunks = p.cin / 16;
   ap.total = (p.n * ap.tiles_x * ap.tiles_y / 2) * ap.n_co_tiles;
+  ap.up = p.in_shift ? 1 : 0; ap.out_w = p.out_w;
   static int cus = 0;
   if (!cus) {
     int d = 0; hipDeviceProp_t prop;
@@ -142,16 +155,17 @@ int ap_try_launch(const IgemmParams& p, const TapSet& taps, const unsigned char*
   const int grid = ap.total < cus ? ap.total : cus;
   const double flops = 2.0 * p.n * (double)p.in_h * p.in_w * p.cout * (double)p.cin * 9;
   char tag[160];
-  snprintf(tag, sizeof(tag), "conv3ap n%d red%d rows%d %dx%d taps9 stats%d acc%d items%d", p.n, p.cin, p.cout, p.in_h, p.in_w,
-           p.red_a ? 2 : (p.stats ? 1 : 0), p.accumulate ? 1 : 0, ap.total);
+  snprintf(tag, sizeof(tag), "conv3ap n%d red%d rows%d %dx%d taps9 up%d fold%d stats%d acc%d items%d", p.n, p.cin, p.cout, p.in_h, p.in_w,
+           ap.up, p.fold ? 1 : 0, p.red_a ? 2 : (p.stats ? 1 : 0), p.accumulate ? 1 : 0, ap.total);
   ProfScope prof(PCUDA_FAM_CONV_FWD, flops, s, tag);
   const int st = p.red_a ? 2 : (p.stats ? 1 : 0);
-  if (st == 1 && !p.accumulate) *rc = ap_launch_t<1, false>(ap, grid, s);
+  if (p.fold) *rc = st == 2 ? ap_launch_t<2, false, true>(ap, grid, s) : ap_launch_t<0, false, true>(ap, grid, s);
+  else if (st == 1 && !p.accumulate) *rc = ap_launch_t<1, false>(ap, grid, s);
   else if (st == 1) *rc = ap_launch_t<1, true>(ap, grid, s);
   else if (st == 2 && !p.accumulate) *rc = ap_launch_t<2, false>(ap, grid, s);
   else if (st == 2) *rc = ap_launch_t<2, true>(ap, grid, s);
   else if (!p.accumulate) *rc = ap_launch_t<0, false>(ap, grid, s);
   else *rc = ap_launch_t<0, true>(ap, grid, s);
-  note_kernel(st == 2 ? "conv3ap+bnred" : "conv3ap");
+  note_kernel(p.fold ? "conv3ap+fold" : (st == 2 ? "conv3ap+bnred" : "conv3ap"));
   return 1;
 }

@@ -47,6 +47,9 @@ struct ApParams {
   int tiles_x, tiles_y, n;
   int n_co_tiles, nchunks;
   int total;               // (tile pairs) x (co tiles)
+  int up;                  // 1: the stored input is (H / 2) x (W / 2), read through the nearest x2 fold (unet.py:111): the LDS tile holds
+                           //    the STORED pixels (6 x 18 records), the fragment addresses map a logical pixel to its record
+  int out_w;               // FOLD: row length of the half-resolution output
   int dbg;                 // timing experiments: 1 no MFMA, 2 no epilogue, 4 no commit, 8 no weight DMA
   unsigned long long* dbg_clk;
 };
@@ -93,7 +96,7 @@ __device__ __forceinline__ void ap_split8(const float* v, ap_u32x4& hi4, ap_u32x
 #define AP_CUR_N(c) ((int)((c) >> 20))
 
 // STATS: 0 none, 1 BatchNorm partial sums of the stored values, 2 BatchNorm-backward reduce partials (dgrad)
-template <int STATS, bool ACC = false, bool DBG = false, bool EXP = false>
+template <int STATS, bool ACC = false, bool DBG = false, bool EXP = false, bool FOLD = false>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void conv3ap_kernel(const ApParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
   float* const ssh = ssc + AP_MAX_C;
   // the parameters of the prefetch, in registers once (selecting between FIELDS of the by-value argument inside the loop
   // compiled to vector loads from the kernel-argument segment with an s_waitcnt vmcnt(0) behind them)
-  const int H = p.H, W = p.W, nchunks = p.nchunks, xc1 = p.x.c1, dbg = (DBG || EXP) ? p.dbg : 0;
+  const int H = p.H, W = p.W, nchunks = p.nchunks, xc1 = p.x.c1, dbg = (DBG || EXP) ? p.dbg : 0, up = p.up;
   const float* const xp1 = p.x.p1; const float* const xp2 = p.x.p2 ? p.x.p2 : p.x.p1;
   const long long xsn1 = p.x.sn1, xsn2 = p.x.sn2;
   const int xsc1 = (int)p.x.sc1, xsc2 = (int)p.x.sc2;
@@ -147,7 +150,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
   for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const int pp = (2 * w + pb + t / 3) * AP_HW + r + (t % 3);
+      const int ly = 2 * w + pb + t / 3, lx = r + (t % 3);                      // haloed logical tile: 10 x 34
+      const int pp = up ? ((ly + 1) >> 1) * 18 + ((lx + 1) >> 1) : ly * AP_HW + lx;  // (stored tile: 6 x 18, origin ((y0 - 1) >> 1, (x0 - 1) >> 1))
       xa[pb][t] = xs_lds + pp * 64 + ((h ^ ((pp >> 2) & 3)) << 4);
     }
   const unsigned wa = lds0 + r * 64 + ((h ^ ((r >> 2) & 3)) << 4);
@@ -156,17 +160,20 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
   // (200 units): eight float4 loads (one per channel of the half) of the quad x0 + 4 q .. + 3; consecutive lanes read
   // consecutive quads (160-byte runs).  Quads 0..7 commit four pixels, quad -1 its last (tile column 0), quad 8 its first
   // (tile column 33).
+  // (nearest-x2 fold: the stored tile, 6 rows x 6 quads -1..4 x 2 halves = 72 units; quad -1 gives tile column 0, quad 4 column 17)
   const int u = w * 64 + lane;
-  const bool uact = u < 200;
-  const int uu = min(u, 199);
-  const int urow = uu / 20, uhalf = (uu % 20) / 10, uq = uu % 10 - 1;
-  const unsigned emask = !uact ? 0u : (uq < 0 ? 8u : (uq > 7 ? 1u : 15u));
+  const int nq = up ? 6 : 10, nun = up ? 72 : 200, tpitch = up ? 18 : AP_HW, lastcol = up ? 17 : 33;
+  const bool uact = u < nun;
+  const int uu = min(u, nun - 1);
+  const int urow = uu / (2 * nq), uhalf = (uu % (2 * nq)) / nq, uq = uu % nq - 1;
+  const unsigned emask = !uact ? 0u : (uq < 0 ? 8u : (uq > nq - 3 ? 1u : 15u));
   unsigned xw[4];                // LDS byte offset (in Xs) of pixel e's hi piece (lo = ^ 32)
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const int pix = urow * AP_HW + min(max(1 + 4 * uq + e, 0), 33);
+    const int pix = urow * tpitch + min(max(1 + 4 * uq + e, 0), lastcol);
     xw[e] = pix * 64 + ((uhalf ^ ((pix >> 2) & 3)) << 4);
   }
+  const int Hs = up ? H >> 1 : H, Ws = up ? W >> 1 : W;   // the stored plane
 
   // stage cursors (wave-uniform, one register each).  nw: the next stage to prefetch; pw: the stage whose input is in
   // flight; cw: the stage this group computes next (committed in the memory segment in front of it); dw: the tile whose
@@ -203,10 +210,10 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
     const float* base = first ? xp1 + (long long)n * xsn1 : xp2 + (long long)n * xsn2;
     const int sc = first ? xsc1 : xsc2;
     const int cl0 = first ? c0 : c0 - xc1;
-    const int gy = AP_CUR_Y0(cur) - 1 + urow, gxx = AP_CUR_X0(cur) + 4 * uq;
-    xin = ((unsigned)gy < (unsigned)H) & ((unsigned)gxx < (unsigned)W);
-    const int cy = min(max(gy, 0), H - 1), cx = min(max(gxx, 0), W - 4);
-    const unsigned voff = (unsigned)((uhalf * 8) * sc + cy * W + cx) * 4u;
+    const int gy = (up ? (AP_CUR_Y0(cur) >> 1) : AP_CUR_Y0(cur)) - 1 + urow, gxx = (up ? (AP_CUR_X0(cur) >> 1) : AP_CUR_X0(cur)) + 4 * uq;
+    xin = ((unsigned)gy < (unsigned)Hs) & ((unsigned)gxx < (unsigned)Ws);
+    const int cy = min(max(gy, 0), Hs - 1), cx = min(max(gxx, 0), Ws - 4);
+    const unsigned voff = (unsigned)((uhalf * 8) * sc + cy * Ws + cx) * 4u;
     const char* b0 = (const char*)(base + (long long)cl0 * sc) + voff;
     const long long cs4 = (long long)sc * 4;
     asm volatile("global_load_dwordx4 v[224:227], %0, off" ::"v"(b0) : "memory", "v224", "v225", "v226", "v227");
@@ -393,6 +400,65 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
         // scratch so that a lane holds 4 consecutive pixels of one channel: 16-byte stores of whole 128-byte row
         // segments, BatchNorm partial sums from one 16-lane DPP reduction per channel.
         const int co0 = AP_CUR_COT(dw) * 64, dn = AP_CUR_N(dw);
+        if constexpr (FOLD) {
+          // 2x2 fold (the data gradient of a layer whose input was read through nearest x2, unet.py:111-112: the gradient of the
+          // STORED half-resolution tensor is the sum over each 2x2 block of the logical one; as igemm_pipe_kernel's FOLD
+          // epilogue).  A wave's two pixel blocks are tile rows 2 w and 2 w + 1: the vertical pair is one add per accumulator
+          // register; the row of sums goes through the wave's scratch ([32 channels][32 pixels]) so that a lane holds 4
+          // consecutive pixels of one channel, whose two horizontal pairs it stores as 8 bytes.
+          const int q = lane & 7, cs = lane >> 3;
+          const int ly = AP_CUR_Y0(dw) + 2 * w, lx = AP_CUR_X0(dw) + 4 * q;
+          const unsigned pixq = (unsigned)((ly >> 1) * p.out_w + (lx >> 1)) * 4u;
+          const int c1 = min(p.y.c1, p.cout);
+          const char* const yb1 = (const char*)(p.y.p1 + (long long)dn * p.y.sn1);
+          const char* const yb2 = (const char*)(p.y.p2 + (long long)dn * p.y.sn2);
+          const unsigned pl1 = (unsigned)p.y.sc1 * 4u, pl2 = (unsigned)p.y.sc2 * 4u;
+          const unsigned voff1 = (unsigned)cs * pl1 + pixq, voff2 = (unsigned)cs * pl2 + pixq;
+          const char* const ab = STATS == 2 ? (const char*)(p.red_a + (long long)dn * p.red_sn) : nullptr;
+          const unsigned aoff = STATS == 2 ? (unsigned)cs * (unsigned)p.red_sc * 4u + pixq : 0u;
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tsc[((i & 3) + 8 * (i >> 2) + 4 * h) * 32 + r] = acc[cb][0][i] + acc[cb][1][i];
+            __builtin_amdgcn_wave_barrier();
+            f32x4 v[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) v[it] = *(const f32x4*)(tsc + (it * 8 + cs) * 32 + 4 * q);
+            float s1[4], s2[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+              const int cu = co0 + cb * 32 + it * 8;               // uniform; the 8 channels lie in one destination
+              const bool first = cu < c1;
+              const char* const sb = first ? yb1 : yb2;
+              const unsigned plane = first ? pl1 : pl2;
+              const unsigned rel = (unsigned)(first ? cu : cu - c1);
+              char* const dptr = (char*)sb + (unsigned long long)rel * plane + (first ? voff1 : voff2);
+              const float o0 = v[it][0] + v[it][1], o1 = v[it][2] + v[it][3];
+              float a0 = 0.f, a1 = 0.f;
+              if (STATS == 2) {
+                const float2 av = *(const float2*)(ab + (long long)cu * p.red_sc * 4 + aoff);
+                a0 = av.x; a1 = av.y;
+              }
+              *(float2*)dptr = make_float2(o0, o1);
+              if (STATS == 2) {
+                const float m = stab1[cu + cs], is = stab2[cu + cs];
+                s1[it] = o0 + o1;
+                s2[it] = o0 * ((a0 - m) * is) + o1 * ((a1 - m) * is);
+              }
+            }
+            if (STATS == 2) {
+#pragma unroll
+              for (int it = 0; it < 4; ++it) { s1[it] = row_sum<8>(s1[it]); s2[it] = row_sum<8>(s2[it]); }
+              if (q == 0) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+                  *(float2*)(sred + (w * 64 + cb * 32 + it * 8 + cs) * 2) = make_float2(s1[it], s2[it]);
+              }
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
+          stat_pending = STATS != 0;
+        } else {
         const int q = lane & 15, cs = lane >> 4;
         const int ly = AP_CUR_Y0(dw) + 2 * w + (q >> 3), lx = AP_CUR_X0(dw) + 4 * (q & 7);
         const unsigned pixq = (unsigned)(ly * W + lx) * 4u;
@@ -473,6 +539,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
           __builtin_amdgcn_wave_barrier();
         }
         stat_pending = STATS != 0;
+        }
       }
       epi_pending = false;
       AP_CLK(3)

@@ -796,7 +796,9 @@ extern "C" int pcuda_conv2d_dgrad_fold(const pcuda_conv_geom* g, int prec, const
     p.red_a = a; p.red_sn = a_sn; p.red_sc = a_sc; p.red_mean = mean; p.red_invstd = invstd;
   }
   p.n = g->n;
-  return launch_igemm(p, prec, t, (hipStream_t)s);
+  const unsigned char* ap_image = ap_layer_ok(g, g->cin, g->cout, prec)
+                                      ? (const unsigned char*)packed_w_dgrad + packed_elems(g->cin, g->cout, t.n, prec) * 2 : nullptr;
+  return launch_igemm(p, prec, t, (hipStream_t)s, ap_image);
 }
 
 // ------------------------------------------------------------------------------------------

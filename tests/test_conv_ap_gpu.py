@@ -154,3 +154,40 @@ def test_results_do_not_depend_on_the_launch_and_match_the_ordinary_kernel(dev, 
     assert not _is_ap(K)
     ref = F.leaky_relu(F.conv2d(x30.cpu(), w.cpu(), b.cpu(), padding=1), 0.01)
     assert rel_err(y30, ref) < 1e-4
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w_", [(4, 128, 64, 32, 64), (2, 256, 128, 16, 32), (6, 64, 64, 24, 96)])
+def test_forward_through_the_nearest_x2_fold_and_its_folded_data_gradient(dev, n, cin, cout, h, w_):
+    """up-convolution (unet.py:111-112): the forward reads the STORED half-resolution input through the nearest x2 fold -- the
+    kernel's LDS tile holds the stored pixels, its fragment addresses do the fold --; the data gradient is written at the
+    stored resolution (the 2x2 sum in the epilogue), with and without the BatchNorm-backward reduce of the layer in front"""
+    from pointcloududa_amd import kernels as K
+    rng = np.random.default_rng(cin + h)
+    x = torch.from_numpy(rng.normal(0, 1, (n, cin, h // 2, w_ // 2)).astype(np.float32))
+    wt = torch.from_numpy(rng.normal(0, 0.1, (cout, cin, 3, 3)).astype(np.float32))
+    b = torch.from_numpy(rng.normal(0, 0.1, (cout,)).astype(np.float32))
+    xr = x.clone().requires_grad_(True)
+    z = F.conv2d(F.interpolate(xr, scale_factor=2, mode="nearest"), wt, b, padding=1)
+    gz = torch.from_numpy(rng.normal(0, 1, z.shape).astype(np.float32))
+    z.backward(gz)
+    op = K.ConvOp(cin, cout, 3, pad=1, in_up=True)
+    y, part, nt = op.forward(x.to(dev), wt.to(dev), b.to(dev), 1.0, h, w_, want_stats=True)
+    assert _is_ap(K), K.last_kernel()
+    assert rel_err(y, z) < 1e-4
+    assert rel_err(part[:nt].double().sum(0).cpu()[:, 0], z.double().sum((0, 2, 3))) < 1e-3
+    got = op.dgrad_fold(gz.to(dev), wt.to(dev), h, w_)
+    want_k = "conv3ap+fold" if cin % 64 == 0 else "igemm"
+    assert want_k in K.last_kernel(), K.last_kernel()
+    assert rel_err(got, xr.grad) < 1e-4
+    a = torch.from_numpy(rng.normal(0, 1, (n, cin, h // 2, w_ // 2)).astype(np.float32)).to(dev)
+    st = K.BNState()
+    st.mean = torch.from_numpy(rng.normal(0, 0.3, (cin,)).astype(np.float32)).to(dev)
+    st.invstd = torch.from_numpy(rng.uniform(0.5, 2.0, (cin,)).astype(np.float32)).to(dev)
+    got2, red = op.dgrad_fold(gz.to(dev), wt.to(dev), h, w_, bnred=(a, st))
+    assert "conv3ap+fold" in K.last_kernel(), K.last_kernel()
+    assert torch.equal(got2, got) and red is not None
+    part, nt = red
+    gd = got.double()
+    tot = part[:nt].double().sum(0)
+    want2 = (gd * ((a.double() - st.mean.double()[None, :, None, None]) * st.invstd.double()[None, :, None, None])).sum((0, 2, 3))
+    assert rel_err(tot[:, 0], gd.sum((0, 2, 3))) < 1e-4 and rel_err(tot[:, 1], want2) < 1e-4
