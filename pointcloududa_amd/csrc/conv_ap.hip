@@ -78,9 +78,24 @@ int ap_launch_pack(const float* w, unsigned char* out, int rows, int red, long l
 // ap_layer_ok this decides the TILE COUNT the caller sizes its BatchNorm partial sums by (pcuda_conv2d_fwd_tiles /
 // _dgrad_tiles): such a launch either runs here or -- tensors the kernel cannot address -- on the ordinary kernel ONLY IF
 // that kernel's plan has the same tiles (launch_igemm checks; otherwise the call fails rather than overrun the partials).
-bool ap_map_ok(int n, int h, int w) {
-  return ap_enabled() && h >= 8 && (h & 7) == 0 && w >= 32 && (w & 31) == 0 && n < 4096 && (h / 8) < 64 && (w / 32) < 16 &&
-         (((long long)n * (h / 8) * (w / 32)) & 1) == 0;
+// (+ enough work items -- (tile pair, co tile) -- for the chip: below three quarters of the compute units, the 32x32 maps at a
+//  per-rank batch of 16, the ordinary kernels' 128-pixel tiles fill it better than one 2 x 256-pixel item per workgroup on
+//  half of it.  PCUDA_AP_MIN_ITEMS overrides the threshold: the kernel-level tests run small maps on the kernel.)
+static int ap_min_items() {
+  const char* e = getenv("PCUDA_AP_MIN_ITEMS");      // (read per call: tests flip it inside one process)
+  if (e) return atoi(e);
+  static int cus = 0;
+  if (!cus) {
+    int d = 0; hipDeviceProp_t prop;
+    cus = (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&prop, d) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  return cus * 3 / 4;
+}
+bool ap_map_ok(int n, int h, int w, int rows) {
+  if (!(ap_enabled() && h >= 8 && (h & 7) == 0 && w >= 32 && (w & 31) == 0 && n < 4096 && (h / 8) < 64 && (w / 32) < 16 &&
+        (((long long)n * (h / 8) * (w / 32)) & 1) == 0))
+    return false;
+  return (long long)n * (h / 8) * (w / 32) / 2 * (rows / 64) >= ap_min_items();
 }
 int ap_tiles(int n, int h, int w) { return n * (h / 8) * (w / 32); }
 
@@ -94,7 +109,7 @@ static bool ap_launch_ok(const IgemmParams& p, const TapSet& taps) {
   if (!p.in_shift && p.in_row != p.in_w) return false;
   if (p.lh != p.in_h || p.lw != p.in_w || p.out_w != (p.fold ? p.in_w >> 1 : p.in_w)) return false;
   if (p.fold && (p.accumulate || p.bias || (p.stats && !p.red_a))) return false;      // data gradient with the 2x2 fold
-  if (!ap_geom_ok(p.cout, p.cin, p.in_h, p.in_w) || !ap_map_ok(p.n, p.in_h, p.in_w)) return false;
+  if (!ap_geom_ok(p.cout, p.cin, p.in_h, p.in_w) || !ap_map_ok(p.n, p.in_h, p.in_w, p.cout)) return false;
   if (!(p.slope >= 0.f && p.slope <= 1.f)) return false;
   // input: a 16-channel chunk lies in one source, rows of float4, 32-bit element offsets inside an image
   const pcuda_src& x = p.x;

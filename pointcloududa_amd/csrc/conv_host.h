@@ -174,7 +174,7 @@ bool ap_fill_pack(PackParams& p, const float* w, unsigned char* out, int rows, i
                   const TapSet& taps);
 int ap_launch_pack(const float* w, unsigned char* out, int rows, int red, long long s_row, long long s_red, const TapSet& taps,
                    hipStream_t s);
-bool ap_map_ok(int n, int h, int w);
+bool ap_map_ok(int n, int h, int w, int rows);
 int ap_tiles(int n, int h, int w);
 int ap_try_launch(const IgemmParams& p, const TapSet& taps, const unsigned char* image, hipStream_t s, int* rc);
 

@@ -382,7 +382,7 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s, co
                p.in_step, taps.dy_max - taps.dy_min);
   // (a launch the anti-phase kernel was expected to take -- the caller sized its partial sums by THAT kernel's tiles -- but did
   //  not, e.g. misaligned tensors: only if this plan writes the same tiles)
-  if (ap_image && p.stats && ap_map_ok(p.n, p.in_h, p.in_w) && p.in_step == 1 && !p.fold &&
+  if (ap_image && p.stats && ap_map_ok(p.n, p.in_h, p.in_w, p.cout) && p.in_step == 1 && !p.fold &&
       (long long)pl.tiles_x * pl.tiles_y * p.n != ap_tiles(p.n, p.in_h, p.in_w))
     PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv: tensors the anti-phase kernel cannot address on a map whose ordinary plan has other tiles");
   p.n_co_tiles = cdiv(p.cout, co_tile);
@@ -575,7 +575,7 @@ extern "C" int pcuda_conv2d_pack_all(const pcuda_conv_geom* g, int prec, const f
 extern "C" int pcuda_conv2d_fwd_tiles(const pcuda_conv_geom* g, int prec) {
   if (!geom_ok(g)) return 0;
   if (const int d = direct_fwd_tiles(g)) return d;
-  if (ap_layer_ok(g, g->cout, g->cin, prec) && ap_map_ok(g->n, g->in_h, g->in_w)) return ap_tiles(g->n, g->in_h, g->in_w);
+  if (ap_layer_ok(g, g->cout, g->cin, prec) && ap_map_ok(g->n, g->in_h, g->in_w, g->cout)) return ap_tiles(g->n, g->in_h, g->in_w);
   TapSet t = fwd_taps(g);
   IgemmPlan pl;
   if (plan_igemm(g->cout, g->cin, g->n, g->out_h, g->out_w, g->in_h, g->in_w, g->stride, t, prec == PCUDA_PREC_BF16X3, &pl) < 0)
@@ -698,7 +698,7 @@ extern "C" int pcuda_conv2d_dgrad_lrelu(const pcuda_conv_geom* g, int prec, cons
   if (dx->c1 < g->cin || a_sc != dx->sc1 || g->in_up)
     PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv2d_dgrad_lrelu: one NCHW destination with the activation's plane stride");
   // (a data gradient the anti-phase kernel takes has no masked store: the caller runs that kernel + pcuda_lrelu_bwd)
-  if (ap_layer_ok(g, g->cin, g->cout, prec) && ap_map_ok(g->n, g->in_h, g->in_w))
+  if (ap_layer_ok(g, g->cin, g->cout, prec) && ap_map_ok(g->n, g->in_h, g->in_w, g->cin))
     PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv2d_dgrad_lrelu: this layer's data gradient runs on the anti-phase kernel");
   return dgrad_impl(g, prec, dy, packed_w_dgrad, dx, 0, a, a_sn, slope, s);
 }
@@ -721,7 +721,7 @@ extern "C" int pcuda_debug_read_clocks(unsigned long long* out8) {
 extern "C" int pcuda_conv2d_dgrad_tiles(const pcuda_conv_geom* g, int prec) {
   if (!geom_ok(g) || g->stride != 1) return 0;
   if (const int d = direct_dgrad_tiles(g)) return d;
-  if (ap_layer_ok(g, g->cin, g->cout, prec) && ap_map_ok(g->n, g->in_h, g->in_w)) return ap_tiles(g->n, g->in_h, g->in_w);
+  if (ap_layer_ok(g, g->cin, g->cout, prec) && ap_map_ok(g->n, g->in_h, g->in_w, g->cin)) return ap_tiles(g->n, g->in_h, g->in_w);
   TapSet t = dgrad_taps(g, 0, 0);
   IgemmPlan pl;
   if (plan_igemm(g->cin, g->cout, g->n, g->in_h, g->in_w, g->out_h, g->out_w, 1, t, prec == PCUDA_PREC_BF16X3, &pl) < 0) return 0;

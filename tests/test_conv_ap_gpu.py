@@ -11,6 +11,12 @@ from conftest import rel_err
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _small_maps_on_the_kernel(monkeypatch):
+    """the dispatcher gives the kernel only launches with enough (tile pair, co tile) items for the chip; these cases are small"""
+    monkeypatch.setenv("PCUDA_AP_MIN_ITEMS", "0")
+
 # (n, cin, cout, h, w, bias, slope): forward rows = cout (a multiple of 64), reduction = cin (a multiple of 16), whole
 # 32 x 8-pixel tiles, an even number of them; the data gradient of the same layer has rows = cin, reduction = cout
 CASES = [
