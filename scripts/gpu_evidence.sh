@@ -4,7 +4,7 @@
 # calibration.  Everything lands in gpurun_out/ (copy the summaries to profiles/).   usage: TAG=r03 bash scripts/gpu_evidence.sh
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-TAG=${TAG:-r05}
+TAG=${TAG:-r06}
 python3 -c "import sys; sys.path.insert(0, '.'); from pointcloududa_amd._lib import csrc_hash; print('csrc_sha256', csrc_hash())" | tee gpurun_out/${TAG}_build_hash.txt
 # (the whole-step traffic first: bench.py quotes roofline.traffic from profiles/rNN_pmc_traffic.csv of THIS build's hash)
 TAG=$TAG bash scripts/gpu_pmc_step.sh > gpurun_out/${TAG}_pmc_step.log 2>&1; rc=$?; echo "pmc_step rc=$rc"

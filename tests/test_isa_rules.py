@@ -55,3 +55,24 @@ def test_scanner_sees_the_pattern(tmp_path):
                                   "\tglobal_load_dword v2, v2, s[12:13]\n\tglobal_load_dword v68, v[68:69], off offset:16\n\ts_endpgm\n")
     rows = V.scan(str(tmp_path))
     assert len(rows) == 1 and rows[0][2] == 3
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc (cross-compiles without a GPU)")
+def test_anti_phase_kernel_landing_zone_is_never_allocated(tmp_path):
+    """csrc/conv_ap_impl.h keeps its input prefetch in flight across two barrier intervals in v[224:255], loaded and read back by
+    inline assembly; the kernel is compiled with amdgpu_num_vgpr(224) so that the compiler never allocates those registers.
+    A compiler that touched them (or spilled to AGPRs / scratch, which changes the register split) would corrupt the prefetch
+    silently: scan every instantiation's assembly (scripts/ap_isa_check.py)."""
+    r = subprocess.run(["make", "-C", CSRC, "isa", "ISA_SRCS=conv_ap.hip"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    s = os.path.join(CSRC, "build", "isa", "conv_ap.s")
+    txt = open(s).read()
+    assert txt.count("\n_Z14conv3ap_kernel") >= 8, "expected the kernel's eight instantiations in the assembly"
+    assert "global_load_dwordx4 v[224:227]" in txt and "v_mov_b32 " in txt
+    c = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "ap_isa_check.py"), s], capture_output=True, text=True)
+    assert c.returncode == 0, c.stdout[-2000:]
+    # and the checker does see a violation
+    bad = tmp_path / "bad.s"
+    bad.write_text("_Z14conv3ap_kernelILi1ELb0ELb0ELb0ELb0EEv8ApParams:\n\tv_add_f32 v230, v1, v2\n\ts_endpgm\n")
+    c = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "ap_isa_check.py"), str(bad)], capture_output=True, text=True)
+    assert c.returncode == 1
