@@ -486,6 +486,8 @@ def main():
                                                     * (int(wl["d1"]) + int(wl["d2"])) / 2.0 if tr.d_reuse else 0.0), 1),
                    "box_to_box": "693-741 img/s measured for the default command across the MI355X boxes of round 6 (probe clocks 2.08-2.35 GHz; profiles/r06_box_scatter.txt); compare lines by img_s_per_ghz",
                    "streams": "discriminators concurrent" if tr.d_streams else "single",
+                   **({"experiment": "PCUDA_EXP_SKIP_DUPDATE=1: discriminator update passes left out -- NOT a benchmark line"}
+                      if getattr(tr, "_exp_skip_dupdate", False) else {}),
                    # d1 / d2 see the target batch twice per step with the same weights and the same input values
                    # (adversarial pass, then their own update): the second forward is replayed from the first's
                    # activations.  PCUDA_DREUSE=0 runs it again (same bits, ~1.5 ms per step more).

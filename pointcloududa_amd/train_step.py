@@ -93,6 +93,9 @@ class AdversarialTrainer:
         self.d_joint = os.environ.get("PCUDA_DJOINT", "1") != "0"
         self._segment = None      # "compute": step() leaves out the collectives and the optimiser steps (step_graphed)
         self._timeline = os.environ.get("PCUDA_TIMELINE", "0") == "1"     # (read per trainer, not at import time)
+        # PCUDA_EXP_SKIP_DUPDATE=1: the discriminators' update passes (phases 3-4) are left out -- a timing experiment
+        # (profiles/r06_experiment_dstream_cost.txt); bench.py marks such a line "experiment"
+        self._exp_skip_dupdate = os.environ.get("PCUDA_EXP_SKIP_DUPDATE", "0") == "1"
 
     def _side_streams(self, names):
         """One side stream PER DISCRIMINATOR, keyed by its name: a network's frozen pass (phase 2), its input-gradient
@@ -331,6 +334,8 @@ class AdversarialTrainer:
                 passes.append(("d1", "dis1", lambda e, i1, v: self.dis1(i1)))
             if c.d4:
                 passes.append(("d4", "dis4", lambda e, i1, v: self.dis4(v.detach().transpose(2, 1), drop_mask)[0]))
+            if self._exp_skip_dupdate:     # MEASUREMENT ONLY (what the update passes cost the step): not the reference's step
+                passes = []
             main = torch.cuda.current_stream()
             side = (self._side_streams([nm for nm, _, _ in passes]) if (self.d_streams and len(passes) > 1)
                     else [None] * len(passes))
@@ -404,7 +409,7 @@ class AdversarialTrainer:
                 g_work = None
             for nm in ("d1", "d2", "d4"):
                 o = getattr(self, "opt_" + nm)
-                if o is not None and not compute_only:
+                if o is not None and not compute_only and nm in d_works:   # (absent only under PCUDA_EXP_SKIP_DUPDATE)
                     work, scale = d_works[nm]
                     o.finish_all_reduce(work)
                     o.step(scale)
