@@ -14,8 +14,11 @@
 //   * one workgroup = four waves (one per SIMD: 512 registers each) on the two 16-pixel halves x the two row halves of the
 //     same 32-pixel strips, their accumulators added in a fixed order through LDS at the end; slabs go through the
 //     common fixed-order reduce.
-// Eligible: k = 3, stride 1, pad 1, no dilation, no upsampling fold, rows of 32 k pixels, 16-byte aligned planes; two sources
-// and the lazy-BatchNorm affine are per-row constants (zero padding is applied AFTER the affine).
+// Eligible: k = 3, stride 1, pad 1, no dilation, rows of 32 k pixels, 16-byte aligned planes; two sources and the lazy-BatchNorm
+// affine are per-row constants (zero padding is applied AFTER the affine).  The up-convolutions (unet.py:85 nn.Upsample(x2) in
+// front of the 3x3 convolution; UP = true): the input is read at its STORED resolution -- a lane's eight pixels are four stored
+// ones (one float4 instead of two, row y of the convolution's input is stored row y >> 1), split once and doubled in the
+// packed-bf16 domain (v_perm_b32): X traffic is a quarter of the upsampled tensor's.
 #include <type_traits>
 
 #include "conv_device.h"
@@ -42,7 +45,7 @@ struct RowF {             // one input row of the strip as MFMA B fragments: [sh
   uint4 f[3][2];
 };
 struct RawX {
-  f32x4 v0, v1;
+  f32x4 v0, v1;           // (UP: v1 is never loaded)
   float halo;
 };
 struct RawZ {
@@ -66,7 +69,7 @@ __device__ __forceinline__ uint4 shift_minus(const uint4 a, unsigned edge) {    
   return o;
 }
 
-template <bool X3>
+template <bool X3, bool UP = false>
 __global__ __launch_bounds__(256, 1) void wgrad3r_kernel(const W3RParams p) {
   __shared__ float red[9 * 16 * 64];
   __shared__ float dbs[4][32];
@@ -111,11 +114,12 @@ __global__ __launch_bounds__(256, 1) void wgrad3r_kernel(const W3RParams p) {
     const int ya = y_lo + (y_hi - y_lo) * wy / 2, yb = y_lo + (y_hi - y_lo) * (wy + 1) / 2;
     const int nrows = yb - ya;
     const float* zrow = p.dz + (long long)img * p.dz_sn + (long long)co * p.dz_sc + x0 + 8 * h;
-    const float* xrow = xbase + (long long)img * x_sn + (long long)cl * x_sc + x0 + 8 * h;
+    const float* xrow = xbase + (long long)img * x_sn + (long long)cl * x_sc + ((x0 + 8 * h) >> (UP ? 1 : 0));
+    const int xpitch = p.W >> (UP ? 1 : 0);                             // stored row pitch
     // the pixel beside the strip: left of it for the lower half-wave, right of it for the upper one
     const int hx = h ? x0 + 16 : x0 - 1;
     const bool hvalid = (unsigned)hx < (unsigned)p.W;
-    const float* hrow = xbase + (long long)img * x_sn + (long long)cl * x_sc + min(max(hx, 0), p.W - 1);
+    const float* hrow = xbase + (long long)img * x_sn + (long long)cl * x_sc + (min(max(hx, 0), p.W - 1) >> (UP ? 1 : 0));
 
     // lanes whose halo pixel lies outside the image read zero: folded into that load's affine
     const float sch = hvalid ? sc : 0.f, shh = hvalid ? sh : 0.f;
@@ -134,11 +138,11 @@ __global__ __launch_bounds__(256, 1) void wgrad3r_kernel(const W3RParams p) {
 #ifdef PCUDA_W3R_DEBUG
       if ((p.dbg & 1) && j > 3) return;
 #endif
-      const int yy = min(max(ya - 1 + j, 0), p.H - 1);
-      const float* q = xrow + (long long)yy * p.W;
+      const int yy = min(max(ya - 1 + j, 0), p.H - 1) >> (UP ? 1 : 0);
+      const float* q = xrow + (long long)yy * xpitch;
       rx[S].v0 = *(const f32x4*)q;
-      rx[S].v1 = *(const f32x4*)(q + 4);
-      rx[S].halo = hrow[(long long)yy * p.W];
+      if (!UP) rx[S].v1 = *(const f32x4*)(q + 4);
+      rx[S].halo = hrow[(long long)yy * xpitch];
     };
     auto issue_z = [&](int i, auto SLOT) {
       constexpr int S = decltype(SLOT)::value;
@@ -154,13 +158,23 @@ __global__ __launch_bounds__(256, 1) void wgrad3r_kernel(const W3RParams p) {
       constexpr int S = decltype(SLOT)::value, R = decltype(ROW)::value;
       const bool rvalid = (unsigned)(ya - 1 + j) < (unsigned)p.H;      // (uniform)
       const float s1 = rvalid ? sc : 0.f, s0 = rvalid ? sh : 0.f, h1 = rvalid ? sch : 0.f, h0 = rvalid ? shh : 0.f;
-      f32x4 a = rx[S].v0, b = rx[S].v1;
+      f32x4 a = rx[S].v0, b = UP ? rx[S].v0 : rx[S].v1;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { a[e] = fmaf(a[e], s1, s0); b[e] = fmaf(b[e], s1, s0); }
+      for (int e = 0; e < 4; ++e) { a[e] = fmaf(a[e], s1, s0); if (!UP) b[e] = fmaf(b[e], s1, s0); }
       const float hv = fmaf(rx[S].halo, h1, h0);
       uint4 H, L = make_uint4(0, 0, 0, 0);
       unsigned hh, hl = 0;
-      if (X3) {
+      if (UP) {            // four stored pixels: split as two pairs, every half-word doubled
+        unsigned h01, l01 = 0, h23, l23 = 0;
+        if (X3) { split2(a[0], a[1], h01, l01); split2(a[2], a[3], h23, l23); split2(hv, 0.f, hh, hl); }
+        else { h01 = pack_bf16x2(a[0], a[1]); h23 = pack_bf16x2(a[2], a[3]); hh = pack_bf16x2(hv, 0.f); }
+        H.x = __builtin_amdgcn_perm(h01, h01, 0x01000100u); H.y = __builtin_amdgcn_perm(h01, h01, 0x03020302u);
+        H.z = __builtin_amdgcn_perm(h23, h23, 0x01000100u); H.w = __builtin_amdgcn_perm(h23, h23, 0x03020302u);
+        if (X3) {
+          L.x = __builtin_amdgcn_perm(l01, l01, 0x01000100u); L.y = __builtin_amdgcn_perm(l01, l01, 0x03020302u);
+          L.z = __builtin_amdgcn_perm(l23, l23, 0x01000100u); L.w = __builtin_amdgcn_perm(l23, l23, 0x03020302u);
+        }
+      } else if (X3) {
         split2(a[0], a[1], H.x, L.x); split2(a[2], a[3], H.y, L.y);
         split2(b[0], b[1], H.z, L.z); split2(b[2], b[3], H.w, L.w);
         split2(hv, 0.f, hh, hl);
@@ -323,9 +337,14 @@ bool w3r_geom(const pcuda_conv_geom* g) {
   if (!mode) return false;
   static int maxc = -1;
   if (maxc < 0) { const char* e = getenv("PCUDA_W3R_MAXC"); maxc = e ? atoi(e) : 128; }
-  const bool shape = g->k == 3 && g->stride == 1 && g->pad == 1 && g->dil == 1 && !g->in_up && (g->in_w & 31) == 0 && g->in_h >= 4 &&
-                     g->cin >= 16 && g->cin <= maxc && g->cout <= maxc && (long long)g->in_h * g->in_w < (1ll << 28);
+  static int upmaxc = -1;     // PCUDA_W3R_UPMAXC: the up-convolutions (input read at its stored resolution) it takes by default
+  if (upmaxc < 0) { const char* e = getenv("PCUDA_W3R_UPMAXC"); upmaxc = e ? atoi(e) : 512; }
+  const int mc = (g->in_up && upmaxc > maxc) ? upmaxc : maxc;
+  const bool shape = g->k == 3 && g->stride == 1 && g->pad == 1 && g->dil == 1 && (g->in_w & 31) == 0 && g->in_h >= 4 &&
+                     (!g->in_up || (g->in_h & 1) == 0) &&
+                     g->cin >= 16 && g->cin <= mc && g->cout <= mc && (long long)g->in_h * g->in_w < (1ll << 28);
   if (!shape || mode >= 2) return shape;
+  if (g->in_up) return g->cin <= upmaxc && g->cout <= upmaxc;
   // default: unequal channel counts up to 64 (one operand's rows are then re-read by fewer blocks than the pixel-record
   // kernel stages them for) on maps of at least 64 rows
   return g->cin != g->cout && g->cin <= 64 && g->cout <= 64 && g->in_h >= 64;
@@ -390,12 +409,17 @@ int wgrad3r_try(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const fl
   }
   {
     char tag[160];
-    snprintf(tag, sizeof(tag), "wgrad3r n%d cin%d cout%d %dx%d k3 s1 d1 slices%d pairs%d", g->n, g->cin, g->cout, g->in_h, g->in_w,
-             w.slices, w.pairs_per_slice);
+    snprintf(tag, sizeof(tag), "wgrad3r n%d cin%d cout%d %dx%d k3 s1 d1 up%d slices%d pairs%d", g->n, g->cin, g->cout, g->in_h, g->in_w,
+             g->in_up ? 1 : 0, w.slices, w.pairs_per_slice);
     ProfScope prof(PCUDA_FAM_CONV_WGRAD, 2.0 * g->n * (double)g->in_h * g->in_w * g->cout * (double)g->cin * 9, s, tag);
     const dim3 grid((unsigned)nwg);
-    if (x3) hipLaunchKernelGGL(wgrad3r_kernel<true>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(wgrad3r_kernel<false>, grid, dim3(256), 0, s, p);
+    if (g->in_up) {
+      if (x3) hipLaunchKernelGGL((wgrad3r_kernel<true, true>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((wgrad3r_kernel<false, true>), grid, dim3(256), 0, s, p);
+    } else {
+      if (x3) hipLaunchKernelGGL(wgrad3r_kernel<true>, grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL(wgrad3r_kernel<false>, grid, dim3(256), 0, s, p);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { pcuda_set_error("wgrad3r_kernel: %s", hipGetErrorString(e)); *rc = PCUDA_E_LAUNCH; return 1; }
   }

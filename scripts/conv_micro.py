@@ -39,6 +39,9 @@ CASES = {  # name: (n, cin, cout, h, w, k, s, p, d, up)
     "p384": (32, 384, 256, 32, 32, 1, 1, 0, 1, False), "pcls": (32, 32, 4, 256, 256, 1, 1, 0, 1, False),
     "mp96": (32, 96, 64, 112, 112, 1, 1, 0, 1, False), "mp192": (32, 192, 128, 56, 56, 1, 1, 0, 1, False),
     "mp384": (32, 384, 256, 28, 28, 1, 1, 0, 1, False),
+    # the decoder's up-convolutions (unet.py:85: Upsample(x2) -> 3x3; h, w = the upsampled size, the input is stored at half of it)
+    "u6432": (32, 64, 32, 256, 256, 3, 1, 1, 1, True), "u12864": (32, 128, 64, 128, 128, 3, 1, 1, 1, True),
+    "u256128": (32, 256, 128, 64, 64, 3, 1, 1, 1, True), "u512256": (32, 512, 256, 32, 32, 3, 1, 1, 1, True),
 }
 which = sys.argv[1:] or list(CASES)
 for name in which:
@@ -48,10 +51,10 @@ for name in which:
     # LeakyReLU(0.01) and BatchNorm partial sums -- the bottleneck (b*/mb*) no BatchNorm; the discriminators' stride-2 layers
     # (d*/md*) no bias, LeakyReLU(0.2), no statistics
     disc, bott = name.lstrip("m").startswith("d") or name.startswith("s2d"), name.lstrip("m").startswith("b")
-    stats, slope = not (disc or bott or name.lstrip("m").startswith("p")), (0.2 if disc else 0.01)
+    stats, slope = not (disc or bott or up or name.lstrip("m").startswith("p")), (0.2 if disc else 0.01)
     if os.environ.get("MICRO_NOSTATS") == "1": stats = False
     op = K.ConvOp(cin, cout, k, stride=s, pad=p, dil=d, in_up=up)
-    x = torch.randn(n, cin, h, w, device=dev); wt = torch.randn(cout, cin, k, k, device=dev) * 0.05
+    x = torch.randn(n, cin, h // 2 if up else h, w // 2 if up else w, device=dev); wt = torch.randn(cout, cin, k, k, device=dev) * 0.05
     b = None if disc else torch.zeros(cout, device=dev)
     oh, ow = op.out_hw(h, w)
     gz = torch.randn(n, cout, oh, ow, device=dev)

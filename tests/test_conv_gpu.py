@@ -505,6 +505,47 @@ def test_pointwise_layer_weight_gradient_from_global_rows(dev, prec, n, c1, c2, 
 
 
 @pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("n,cin,cout,h,w", [
+    (2, 64, 32, 64, 64),            # up-convolution of decoder block 1 (unet.py:85: Upsample(x2) -> 3x3): 64 -> 32, stored 32x32
+    (2, 128, 64, 32, 64),           # 128 -> 64: four input-channel blocks x two output-channel blocks, two strips
+    (3, 48, 40, 12, 96),            # ragged channel blocks, six stored rows (row counts that do not divide by the unroll), three strips
+])
+def test_register_window_weight_gradient_of_up_convolution(dev, prec, n, cin, cout, h, w):
+    """The up-convolutions' weight gradient on the LDS-free kernel (csrc/conv_wgrad3r.hip, UP): the input is read at its STORED
+    resolution (a quarter of the upsampled tensor) and doubled in registers: against the CPU reference (nearest x2 -> 3x3) with
+    the lazy-BatchNorm affine (zero padding AFTER the affine), bias gradient, accumulate semantics, bit-reproducibility"""
+    from pointcloududa_amd import kernels as K
+    from pointcloududa_amd.kernels import TA
+    K.set_precision(prec)
+    try:
+        rng = np.random.default_rng(cin + cout + h)
+        a = torch.from_numpy(rng.normal(0, 1, (n, cin, h // 2, w // 2)).astype(np.float32))
+        sc = torch.from_numpy(rng.normal(1, 0.2, (cin,)).astype(np.float32))
+        sf = torch.from_numpy(rng.normal(0.5, 0.2, (cin,)).astype(np.float32))
+        wt = torch.from_numpy(rng.normal(0, 0.1, (cout, cin, 3, 3)).astype(np.float32)).requires_grad_(True)
+        bias = torch.zeros(cout, requires_grad=True)
+        xa = a * sc[None, :, None, None] + sf[None, :, None, None]
+        z = F.conv2d(F.interpolate(xa, scale_factor=2, mode="nearest"), wt, bias, padding=1)
+        gz = torch.from_numpy(rng.normal(0, 1, z.shape).astype(np.float32))
+        z.backward(gz)
+        op = K.ConvOp(cin, cout, 3, pad=1, in_up=True)
+        dw, db = torch.zeros(cout, cin, 3, 3, device=dev), torch.zeros(cout, device=dev)
+        src = TA(a.to(dev), sc.to(dev), sf.to(dev))
+        fb = K.fallback_count()
+        op.wgrad(src, gz.to(dev), dw, db, h, w, accumulate=False)
+        assert K.last_kernel().startswith("wgrad3r ") and " up1 " in K.last_kernel() and K.fallback_count() == fb, K.last_kernel()
+        assert rel_err(dw, wt.grad) < TOL[prec] and rel_err(db, bias.grad) < 1e-4
+        op.wgrad(src, gz.to(dev), dw, db, h, w, accumulate=True)
+        assert rel_err(dw, 2 * wt.grad) < TOL[prec] and rel_err(db, 2 * bias.grad) < 1e-4
+        dw2, db2 = torch.zeros_like(dw), torch.zeros_like(db)
+        op.wgrad(src, gz.to(dev), dw2, db2, h, w, accumulate=False)
+        op.wgrad(src, gz.to(dev), dw2, db2, h, w, accumulate=True)
+        assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    finally:
+        K.set_precision("bf16x3")
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
 @pytest.mark.parametrize("n,c1,c2,cout,h,w", [
     (2, 32, 32, 32, 64, 64),        # decoder block 1: cat(skip, up) 64 -> 32 (unet.py:116), the shape the kernel runs by default
     (2, 32, 0, 64, 64, 32),         # encoder block 2: 32 -> 64; one 32-pixel strip
