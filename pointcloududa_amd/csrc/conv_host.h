@@ -178,6 +178,12 @@ bool ap_map_ok(int n, int h, int w, int rows);
 int ap_tiles(int n, int h, int w);
 int ap_try_launch(const IgemmParams& p, const TapSet& taps, const unsigned char* image, hipStream_t s, int* rc);
 
+// row-streaming 3x3 kernel of the 32 -> 32-channel layers (conv_rs.hip): reads the ORDINARY packed layout
+bool rs_layer_ok(const pcuda_conv_geom* g, int rows, int red, int prec);
+bool rs_map_ok(int n, int h, int w);
+int rs_tiles(int n, int h, int w);
+int rs_try_launch(const IgemmParams& p, int prec, const TapSet& taps, hipStream_t s, int* rc);
+
 // direct (vector-ALU) kernels of the degenerate layers (conv_direct.hip); each returns 1 when it took the launch
 int direct_fwd_tiles(const pcuda_conv_geom* g);
 int direct_forward(const pcuda_conv_geom* g, int prec, const pcuda_src* x, const void* packed_w, long long w_lo_off,

@@ -372,6 +372,7 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s, co
   {
     int rc;
     if (ap_image && prec == PCUDA_PREC_BF16X3 && ap_try_launch(p, taps, ap_image, s, &rc)) return rc;
+    if (p.cin == 32 && p.cout == 32 && rs_try_launch(p, prec, taps, s, &rc)) return rc;
   }
   const bool x3 = prec == PCUDA_PREC_BF16X3;
   const int co_blks = ig_co_blks(p.cout);
@@ -385,6 +386,11 @@ int launch_igemm(IgemmParams& p, int prec, const TapSet& taps, hipStream_t s, co
   if (ap_image && p.stats && ap_map_ok(p.n, p.in_h, p.in_w, p.cout) && p.in_step == 1 && !p.fold &&
       (long long)pl.tiles_x * pl.tiles_y * p.n != ap_tiles(p.n, p.in_h, p.in_w))
     PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv: tensors the anti-phase kernel cannot address on a map whose ordinary plan has other tiles");
+  // (the same for the row-streaming kernel of the 32 -> 32 layers: its tiles are its work items)
+  if (p.stats && p.cin == 32 && p.cout == 32 && prec == PCUDA_PREC_BF16X3 && taps.n == 9 && p.in_step == 1 && !p.in_shift && !p.fold &&
+      !p.pair && taps.dy_max - taps.dy_min == 2 && rs_map_ok(p.n, p.in_h, p.in_w) && p.lh == p.in_h && p.lw == p.in_w &&
+      (long long)pl.tiles_x * pl.tiles_y * p.n != rs_tiles(p.n, p.in_h, p.in_w))
+    PCUDA_FAIL(PCUDA_E_UNSUPPORTED, "conv: tensors the row-streaming kernel cannot address on a map whose ordinary plan has other tiles");
   p.n_co_tiles = cdiv(p.cout, co_tile);
   p.nchunks = cdiv(p.cin, 32);
   p.tw = pl.tw; p.th = pl.th; p.tmagic = 65536 / pl.tw + 1; p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y;
@@ -576,6 +582,7 @@ extern "C" int pcuda_conv2d_fwd_tiles(const pcuda_conv_geom* g, int prec) {
   if (!geom_ok(g)) return 0;
   if (const int d = direct_fwd_tiles(g)) return d;
   if (ap_layer_ok(g, g->cout, g->cin, prec) && ap_map_ok(g->n, g->in_h, g->in_w, g->cout)) return ap_tiles(g->n, g->in_h, g->in_w);
+  if (rs_layer_ok(g, g->cout, g->cin, prec) && rs_map_ok(g->n, g->in_h, g->in_w)) return rs_tiles(g->n, g->in_h, g->in_w);
   TapSet t = fwd_taps(g);
   IgemmPlan pl;
   if (plan_igemm(g->cout, g->cin, g->n, g->out_h, g->out_w, g->in_h, g->in_w, g->stride, t, prec == PCUDA_PREC_BF16X3, &pl) < 0)
@@ -722,6 +729,7 @@ extern "C" int pcuda_conv2d_dgrad_tiles(const pcuda_conv_geom* g, int prec) {
   if (!geom_ok(g) || g->stride != 1) return 0;
   if (const int d = direct_dgrad_tiles(g)) return d;
   if (ap_layer_ok(g, g->cin, g->cout, prec) && ap_map_ok(g->n, g->in_h, g->in_w, g->cin)) return ap_tiles(g->n, g->in_h, g->in_w);
+  if (rs_layer_ok(g, g->cin, g->cout, prec) && rs_map_ok(g->n, g->in_h, g->in_w)) return rs_tiles(g->n, g->in_h, g->in_w);
   TapSet t = dgrad_taps(g, 0, 0);
   IgemmPlan pl;
   if (plan_igemm(g->cin, g->cout, g->n, g->in_h, g->in_w, g->out_h, g->out_w, 1, t, prec == PCUDA_PREC_BF16X3, &pl) < 0) return 0;
