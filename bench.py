@@ -187,7 +187,7 @@ def pmc_traffic_per_launch():
                       % (os.path.basename(files[-1]), have, csrc_hash()))
     n = fetch = write = 0.0
     for r in csv.DictReader([l for l in lines if l and not l.startswith("#")]):
-        if r["kernel"].startswith(("igemm_pipe_kernel", "igemm8_kernel", "igemm_kernel", "conv3ap_kernel")):
+        if r["kernel"].startswith(("igemm_pipe_kernel", "igemm8_kernel", "igemm_kernel", "conv3ap_kernel", "conv3rs_kernel")):
             n += float(r["launches"]); fetch += float(r["FETCH_SIZE_KB_sum_raw"]); write += float(r["WRITE_SIZE_KB_sum"])
     if n == 0:
         return None, "no forward / dgrad launches in " + os.path.basename(files[-1])
@@ -528,7 +528,7 @@ def main():
         same_cmd = args.workload == "full_uda" and b == wl["batch"] and args.precision == "bf16x3" and world == 1
         traffic, traffic_src = pmc_traffic_per_launch() if same_cmd else (None, None)
         result["roofline"] = {
-            "kernel": "conv3ap_kernel / igemm_pipe_kernel / igemm8_kernel (implicit-GEMM MFMA conv: forward + dgrad launches)", "bound": "mfma",
+            "kernel": "conv3ap_kernel / conv3rs_kernel / igemm_pipe_kernel / igemm8_kernel (implicit-GEMM MFMA conv: forward + dgrad launches)", "bound": "mfma",
             "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
             "traffic": traffic, "traffic_unit": "bytes per launch (HBM, PMC)", "traffic_source": traffic_src,
             "launches_per_step": launches // nprof, "avg_launch_us": round(1000.0 * ms / max(launches, 1), 2),

@@ -30,7 +30,7 @@ for f in glob.glob("gpurun_out/pmcc/**/*counter_collection.csv", recursive=True)
 with open("gpurun_out/%s_pmc_conv.csv" % tag, "w") as o:
     o.write("kernel,counter,per_launch,launches\n")
     for k, d in sorted(agg.items()):
-        if not any(t in k for t in ("igemm", "conv3ap", "wgrad", "d1_fwd", "d1_dgrad", "d5_fwd", "c1_fwd", "pw_")): continue
+        if not any(t in k for t in ("igemm", "conv3ap", "conv3rs", "wgrad", "d1_fwd", "d1_dgrad", "d5_fwd", "c1_fwd", "pw_")): continue
         for c, (v, n) in sorted(d.items()):
             o.write('"%s",%s,%.1f,%d\n' % (k[:90], c, v / max(n, 1), n))
 print(open("gpurun_out/%s_pmc_conv.csv" % tag).read()[:6000])

@@ -76,3 +76,24 @@ def test_anti_phase_kernel_landing_zone_is_never_allocated(tmp_path):
     bad.write_text("_Z14conv3ap_kernelILi1ELb0ELb0ELb0ELb0EEv8ApParams:\n\tv_add_f32 v230, v1, v2\n\ts_endpgm\n")
     c = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "ap_isa_check.py"), str(bad)], capture_output=True, text=True)
     assert c.returncode == 1
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc (cross-compiles without a GPU)")
+def test_row_streaming_kernel_keeps_its_work_inside_the_mfma_sequence(tmp_path):
+    """csrc/conv_rs.hip runs ONE wave per SIMD: only its own instruction order overlaps the conversion, the epilogue and the
+    loads with the MFMAs (a scheduling fence pins one piece of that work behind every MFMA).  A compiler that clusters the MFMAs
+    again, or spills, costs the kernel its overlap without changing a result: scan every shipped instantiation's assembly
+    (scripts/rs_isa_check.py): no scratch in the variants the networks launch, 54 MFMAs per step copy, no long run of vector
+    instructions without an MFMA."""
+    r = subprocess.run(["make", "-C", CSRC, "isa", "ISA_SRCS=conv_rs.hip"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    s = os.path.join(CSRC, "build", "isa", "conv_rs.s")
+    c = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "rs_isa_check.py"), s], capture_output=True, text=True)
+    assert c.returncode == 0, c.stdout[-2000:]
+    # and the checker does see a clustered kernel
+    bad = tmp_path / "bad.s"
+    body = "\tv_mfma_f32_32x32x16_bf16 a[0:15], v[0:3], v[4:7], a[0:15]\n" * (54 * 8) + "\tv_add_f32 v1, v2, v3\n" * 60
+    bad.write_text("_ZN12_GLOBAL__N_114conv3rs_kernelILi1ELb0ELb1ELi0EEEvNS_8RsParamsE:\n" + body +
+                   "\t.amdhsa_kernel x\n\t\t.amdhsa_private_segment_fixed_size 0\n\t.end_amdhsa_kernel\n")
+    c = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "rs_isa_check.py"), str(bad)], capture_output=True, text=True)
+    assert c.returncode == 1
