@@ -33,6 +33,14 @@ namespace {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// cache policy of the streaming loads / stores (timing experiments: -DRS_LD_AUX=2 / -DRS_ST_AUX=2 = non-temporal)
+#ifndef RS_LD_AUX
+#define RS_LD_AUX 0
+#endif
+#ifndef RS_ST_AUX
+#define RS_ST_AUX 0
+#endif
+
 constexpr int RS_REC = 144;                        // record bytes: 32 bf16 hi | 32 bf16 lo | 16 pad (ig_rec_bytes(true))
 constexpr int RS_WTAP = 32 * RS_REC;               // one tap of weights
 constexpr int RS_WBYTES = 9 * RS_WTAP;             // 41472
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(256, 1) void conv3rs_kernel(const RsParams p) {
   auto load_x = [&](int e, int rw, auto SLOT) {   // load e of 5 of an input row: e < 4 channel e of this lane's four, 4 the halo
     constexpr int S = decltype(SLOT)::value;
     if (DBG & 4) { if (e < 4) raw[S][e] = f32x4{0.f, 0.f, 0.f, 0.f}; else rawh[S] = 0.f; return; }
-    if (e < 4) raw[S][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo, e * xpl + (unsigned)rw * 4u, 0));
+    if (e < 4) raw[S][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo, e * xpl + (unsigned)rw * 4u, RS_LD_AUX));
     else rawh[S] = hp[rw];
   };
   auto issue_x = [&](int j, auto SLOT) {           // unconditional, clamped: rows outside the image are zeroed at conversion
@@ -200,7 +208,7 @@ __global__ __launch_bounds__(256, 1) void conv3rs_kernel(const RsParams p) {
     ev[e] = a;
     if (STATS == 1) { s1 += a; s2 = fmaf(a, a, s2); }
     if (STATS == 2) { s1 += a; s2 = fmaf(a, (av[g][e] - mean_l) * is_l, s2); }
-    if (e == 3 && !(DBG & 2)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ev), yrs, yo, 32 * g + ro, 0);
+    if (e == 3 && !(DBG & 2)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ev), yrs, yo, 32 * g + ro, RS_ST_AUX);
   };
   // step i (phase PH = i % 4): the 54 MFMAs of row i, two chains alternating; behind MFMA q one piece of the other work, pinned
   // there by a scheduling fence (the solver of sched_group_barrier left all of it outside the MFMA sequence):
