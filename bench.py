@@ -517,6 +517,16 @@ def main():
         K.prof_enable(False)
         if os.environ.get("PCUDA_PROF_DUMP"):
             K.prof_dump(os.environ["PCUDA_PROF_DUMP"])
+        rs_rows = []
+        if rank == 0:   # the row-streaming kernel's launches (HBM-bound members of the family): by tag, from the per-launch dump
+            import csv, re, tempfile
+            with tempfile.TemporaryDirectory() as td:
+                K.prof_dump(os.path.join(td, "layers.csv"))
+                for r in csv.DictReader(open(os.path.join(td, "layers.csv"))):
+                    m = re.match(r"conv3rs n(\d+) red32 rows32 (\d+)x(\d+) taps9 stats(\d)", r["tag"])
+                    if m:   # algorithmic bytes: 32 fp32 planes in, 32 out, 32 more of the saved activation with the BatchNorm-backward reduce
+                        n_, h_, w_, st_ = (int(v) for v in m.groups())
+                        rs_rows.append((float(r["ms"]), (3 if st_ == 2 else 2) * 32.0 * n_ * h_ * w_ * 4))
         ms, flops, launches = K.prof_read(0)
         wms, wflops, wl_n = K.prof_read(1)
         pms, pbytes, pl_n = K.prof_read(2)
@@ -545,6 +555,10 @@ def main():
                 "conv1d_f32": {"what": "PointNetCls k=1 Conv1d layers, exact fp32 MFMA (peak 157 TFLOP/s)",
                                "achieved_tflops": round(dflops / (dms * 1e-3) / 1e12, 2) if dms > 0 else 0.0,
                                "ms_per_step": round(dms / nprof, 3), "launches_per_step": dl_n // nprof},
+                "conv3rs_kernel": {"what": "the 32 -> 32-channel 3x3 launches of the family above (row streaming): HBM-bound, algorithmic bytes = the fp32 planes read + written",
+                                   "bound": "hbm", "achieved_gbps": round(sum(b_ for _, b_ in rs_rows) / (sum(m_ for m_, _ in rs_rows) * 1e-3) / 1e9, 1) if rs_rows else 0.0,
+                                   "peak_gbps": 8000.0, "ms_per_step": round(sum(m_ for m_, _ in rs_rows) / nprof, 3),
+                                   "launches_per_step": len(rs_rows) // nprof},
                 "pointwise": {"achieved_gbps": round(pbytes / (pms * 1e-3) / 1e9, 1) if pms > 0 else 0.0,
                               "ms_per_step": round(pms / nprof, 3), "launches_per_step": pl_n // nprof,
                               "peak_gbps": 8000.0},
