@@ -347,6 +347,10 @@ bool w3r_geom(const pcuda_conv_geom* g) {
   if (g->in_up) return g->cin <= upmaxc && g->cout <= upmaxc;
   // default: unequal channel counts up to 64 (one operand's rows are then re-read by fewer blocks than the pixel-record
   // kernel stages them for) on maps of at least 64 rows
+  // (round 6, re-measured on the library without SLP vectorisation: every layer on maps of at least 128 x 128 -- 32->32 at 256x256
+  //  0.214 -> 0.197 ms, 64->64 at 128x128 0.165 -> 0.152, 128->64 at 128x128 0.290 -> 0.265; still at parity or behind on 64x64 and
+  //  32x32 maps: 128->128 0.137 / 0.140, 256->256 0.144 / 0.146)
+  if (g->in_h >= 128 && g->in_w >= 128) return true;
   return g->cin != g->cout && g->cin <= 64 && g->cout <= 64 && g->in_h >= 64;
 }
 
