@@ -364,7 +364,18 @@ bool rs_layer_ok(const pcuda_conv_geom* g, int rows, int red, int prec) {
 bool rs_map_ok(int n, int h, int w) {
   const char* e = getenv("PCUDA_RS_MIN_ROWS");       // (read per call: tests flip it inside one process)
   const int min_rows = e ? atoi(e) : 64;
-  return rs_enabled() && w >= 32 && (w & 31) == 0 && h >= min_rows && h >= 2 && n >= 1;
+  if (!(rs_enabled() && w >= 32 && (w & 31) == 0 && h >= min_rows && h >= 2 && n >= 1)) return false;
+  // enough items -- (image, strip, row segment), one per wave -- for the chip: below three quarters of its wave slots (small
+  // batches) the ordinary kernel's 256-pixel tiles fill it better.  PCUDA_RS_MIN_ITEMS overrides the threshold (the kernel-level
+  // tests run small maps on the kernel).
+  const char* m = getenv("PCUDA_RS_MIN_ITEMS");
+  static int cus = 0;
+  if (!cus) {
+    int d = 0; hipDeviceProp_t prop;
+    cus = (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&prop, d) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  const long long min_items = m ? atoi(m) : 3ll * cus;
+  return (long long)n * (w / 32) * rs_rsplit(n, h, w) >= min_items;
 }
 int rs_tiles(int n, int h, int w) { return n * (w / 32) * rs_rsplit(n, h, w); }
 

@@ -198,6 +198,7 @@ def test_conv_full_batch_properties(dev, cin, cout, hw, k, s, p, monkeypatch):
     # (round 6: the dispatcher gives the anti-phase kernel only launches with enough work items for the chip -- the batch of 32
     #  of 256 -> 256 at 32x32, not its single samples.  Sample independence is a property of EACH kernel: both sizes on that one.)
     monkeypatch.setenv("PCUDA_AP_MIN_ITEMS", "0")
+    monkeypatch.setenv("PCUDA_RS_MIN_ITEMS", "0")       # (the same for the row-streaming kernel of 32 -> 32 at 256x256)
     torch.manual_seed(5)
     n = 32
     op = K.ConvOp(cin, cout, k, stride=s, pad=p)

@@ -14,8 +14,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _small_maps_on_the_kernel(monkeypatch):
-    """the dispatcher gives the kernel maps of at least 64 rows; some of these cases are smaller"""
+    """the dispatcher gives the kernel maps of at least 64 rows and launches with enough (image, strip, row segment) items for
+    the chip; these cases are smaller"""
     monkeypatch.setenv("PCUDA_RS_MIN_ROWS", "2")
+    monkeypatch.setenv("PCUDA_RS_MIN_ITEMS", "0")
 
 
 # (n, h, w, bias, slope)
