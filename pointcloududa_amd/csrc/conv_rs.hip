@@ -5,22 +5,26 @@
 // output rows give a staged input tile only 9 x 32 x 32 MACs per pixel, and igemm_pipe_kernel spends its time staging 32 x 8-pixel
 // tiles with their halo rows (10 rows staged per 8 computed), behind workgroup barriers: 243 us per launch against an HBM floor of
 // ~105 us.  Here every WAVE is its own pipeline (the structure of conv_wgrad3r.hip turned to the forward problem):
-//   * a wave owns a 32-pixel-wide column strip of one image and walks DOWN it one output row per step; the three input rows of a
-//     step are the previous step's last two plus ONE new row: every input element is loaded, affine-transformed and split into
-//     bf16 hi / lo once (plus two halo pixels per row and channel, one dword per lane);
+//   * a wave owns a 32-pixel-wide column strip of one image (and a segment of its rows) and walks DOWN it one output row per step;
+//     the three input rows of a step are the previous step's last two plus ONE new row: every input element is loaded,
+//     affine-transformed and split into bf16 hi / lo once (plus two halo pixels per row and channel, one dword per lane);
 //   * the rows live in a wave-private LDS ring of four row slots ([34 pixel records][32 hi | 32 lo | pad], the records of the
 //     ordinary kernels): the nine taps are nine (slot, pixel offset) immediates on ds_read_b128 -- no barrier anywhere in the
 //     loop, LDS ordering of a single wave is program order;
 //   * the layer's whole weight tensor (9 taps x 32 rows x 144 B = 41 KB: the ORDINARY packed layout, no image of its own) is
-//     copied to LDS once per workgroup; A fragments are immediates as well;
-//   * D[row = output channel][col = pixel]: an accumulator register is 32 consecutive pixels of one output row = one 128-byte
-//     line per half-wave, stored straight from registers; bias, LeakyReLU, accumulate, BatchNorm partial sums (forward) and the
-//     BatchNorm-backward reduce (data gradient: pcuda_conv2d_dgrad_bnred) run on the previous row's accumulators while the
-//     matrix pipe works on the current one; the partial sums stay in registers for the whole strip (one cross-lane reduce per
-//     item);
-//   * loads run four rows ahead in a register ring; 54 MFMAs per step and wave against ~300 other instructions in their shadow.
+//     copied to LDS once per workgroup; weight fragments are immediates as well;
+//   * D[row = pixel][col = output channel] (A = the pixel records, B = the weights): an accumulator register is four consecutive
+//     pixels of ONE channel per lane, so the stores, the accumulate loads and the BatchNorm-backward reduce's loads of the saved
+//     activation are float4 (as are the input loads: a lane loads four channels x four pixels of a row); bias, mean, 1 / std are
+//     per-lane scalars and the BatchNorm partial sums two registers per lane for the whole strip (one cross-lane add per item).
+//     Bias, LeakyReLU, accumulate, partial sums (forward) and the BatchNorm-backward reduce (data gradient:
+//     pcuda_conv2d_dgrad_bnred) run on the previous row's accumulators while the matrix pipe works on the current one;
+//   * one wave per SIMD: the source order IS the schedule -- behind each of a step's 54 MFMAs one piece of that work, pinned by a
+//     scheduling fence (scripts/rs_isa_check.py checks the assembly); loads run four rows ahead in a register ring.
 // Work item = (image, strip, row segment); items = a multiple of the chip's wave slots where the map allows.  One workgroup =
 // four waves on four neighbouring strips (their halo pixels are each other's lines), one workgroup per CU (120 KB of LDS).
+// Bound (profiles/r06_experiment_row_streaming.txt): the mixed read / write stream at ~3.3 TB/s (loads alone 4.3, stores alone
+// 4.5 TB/s; the instruction stream alone 88 us of 173-178).
 #include <stdlib.h>
 #include <type_traits>
 
@@ -49,8 +53,8 @@ constexpr int RS_RING = 4 * RS_ROW;                // 19584
 constexpr int RS_LDS = RS_WBYTES + 4 * RS_RING;    // 119808
 
 struct RsParams {
-  pcuda_src x;               // 32 channels: all in source 1, or 16 + 16
-  pcuda_dst y;               // 32 rows: the boundary between the destinations at a multiple of 8
+  pcuda_src x;               // 32 channels, all in source 1
+  pcuda_dst y;               // 32 rows, all in destination 1
   int H, W, n;
   const unsigned char* wimg; // ordinary packed layout of the launch: [tap][32 rows][144 B]
   int tap_pos[9];            // LDS position (dy + 1) * 3 + dx + 1 of the image's tap i
