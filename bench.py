@@ -484,7 +484,7 @@ def main():
                    # replayed from the adversarial pass, 7 of them execute for those two networks
                    "executed_gflop_per_pair": round(wl["gflop_per_pair"] - (2 * wl.get("d_gflop", 3.60 * (wl.get("hw", 256) / 256.0) ** 2)
                                                     * (int(wl["d1"]) + int(wl["d2"])) / 2.0 if tr.d_reuse else 0.0), 1),
-                   "box_to_box": "733-779 img/s measured for the default command on the final kernels across the MI355X boxes of round 6 (probe clocks 2.06-2.37 GHz; profiles/r06_box_scatter.txt); compare lines by img_s_per_ghz",
+                   "box_to_box": "742-779 img/s measured for the default command on the final kernels across the MI355X boxes of round 6 (probe clocks 2.06-2.37 GHz; profiles/r06_box_scatter.txt); compare lines by img_s_per_ghz",
                    "streams": "discriminators concurrent" if tr.d_streams else "single",
                    **({"experiment": "PCUDA_EXP_SKIP_DUPDATE=1: discriminator update passes left out -- NOT a benchmark line"}
                       if getattr(tr, "_exp_skip_dupdate", False) else {}),

@@ -23,7 +23,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     fs = glob.glob("gpurun_out/pmcl/%s/**/*counter_collection.csv" % ctr, recursive=True)
     if not fs: continue
     recs = sorted(csv.DictReader(open(fs[0])), key=lambda r: int(r["Dispatch_Id"]))
-    recs = [r for r in recs if r["Counter_Name"] == ctr and ("igemm" in r["Kernel_Name"] or "conv3ap_kernel" in r["Kernel_Name"] or "conv3rs_kernel" in r["Kernel_Name"] or "wgrad_kernel" in r["Kernel_Name"] or "wgrad3_kernel" in r["Kernel_Name"])]
+    recs = [r for r in recs if r["Counter_Name"] == ctr and ("igemm" in r["Kernel_Name"] or "conv3ap_kernel" in r["Kernel_Name"] or "conv3rs_kernel" in r["Kernel_Name"] or "wgrad_kernel" in r["Kernel_Name"] or "wgrad3_kernel" in r["Kernel_Name"] or "wgrad3r_kernel" in r["Kernel_Name"])]
     # conv dispatches arrive in a fixed order: per case 11 forward launches, 11 x dgrad launches per call (stride 1: one;
     # k = 4 / stride 2 / pad 2: one per ROW parity, the column classes paired -- four with PCUDA_DGRAD_PAIR=0), 11
     # weight-gradient launches (their reduce kernels are filtered out above)
@@ -33,7 +33,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         st = GEOM[cs][6]
         for op, cnt in enumerate((11, 11 * (st * st if (st == 1 or not pair) else st), 11)):
             for r in recs[pos:pos + cnt]:
-                assert ("wgrad_kernel" in r["Kernel_Name"] or "wgrad3_kernel" in r["Kernel_Name"]) == (op == 2), (cs, op, r["Kernel_Name"])
+                assert ("wgrad_kernel" in r["Kernel_Name"] or "wgrad3_kernel" in r["Kernel_Name"] or "wgrad3r_kernel" in r["Kernel_Name"]) == (op == 2), (cs, op, r["Kernel_Name"])
                 rows[(ci, op)][ctr].append(float(r["Counter_Value"]))
             pos += cnt
     assert pos == len(recs), (pos, len(recs))
