@@ -54,10 +54,17 @@ for name in which:
     stats, slope = not (disc or bott or up or name.lstrip("m").startswith("p")), (0.2 if disc else 0.01)
     if os.environ.get("MICRO_NOSTATS") == "1": stats = False
     op = K.ConvOp(cin, cout, k, stride=s, pad=p, dil=d, in_up=up)
-    x = torch.randn(n, cin, h // 2 if up else h, w // 2 if up else w, device=dev); wt = torch.randn(cout, cin, k, k, device=dev) * 0.05
+    # MICRO_PAD=<floats>: plane pitch of every activation tensor padded by that many floats (are power-of-two plane strides -- all
+    # channel planes of a pixel on one memory channel -- what the mixed read / write streams of the full-resolution level pay for?)
+    PAD = int(os.environ.get("MICRO_PAD", "0"))
+    def padded(nn, cc, hh, ww, fill="randn"):
+        big = (torch.randn if fill == "randn" else torch.zeros)(nn, cc, hh * ww + PAD, device=dev)
+        return big[:, :, :hh * ww].view(nn, cc, hh, ww) if PAD else big.view(nn, cc, hh, ww)
+    x = padded(n, cin, h // 2 if up else h, w // 2 if up else w); wt = torch.randn(cout, cin, k, k, device=dev) * 0.05
     b = None if disc else torch.zeros(cout, device=dev)
     oh, ow = op.out_hw(h, w)
-    gz = torch.randn(n, cout, oh, ow, device=dev)
+    gz = padded(n, cout, oh, ow)
+    yout, dxout = padded(n, cout, oh, ow, 'zeros'), padded(n, cin, h // 2 if up else h, w // 2 if up else w, 'zeros')
     # MICRO_DATA=zeros: all-zero operands, zerow: zero weights only -- the SAME instruction streams on operands that do not
     # toggle the multipliers: what the kernels' clock is under (round 6: profiles/r06_experiment_power_cap.txt)
     if os.environ.get("MICRO_DATA") == "zeros": x.zero_(); wt.zero_(); gz.zero_()
@@ -68,7 +75,7 @@ for name in which:
         fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(reps): fn()
         torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps
-    tf = t(lambda: op.forward(x, wt, b, slope, h, w, want_stats=stats))
-    td = t(lambda: op.dgrad(gz, wt, h, w))
+    tf = t(lambda: op.forward(x, wt, b, slope, h, w, want_stats=stats, out=yout if PAD else None))
+    td = t(lambda: op.dgrad(gz, wt, h, w, dx=dxout if (PAD and not up) else None))
     tw = t(lambda: op.wgrad(x, gz, dw, b, h, w))
     print("%-5s fwd %7.3f ms %6.1f TF | dgrad %7.3f ms %6.1f TF | wgrad %7.3f ms %6.1f TF" % (name, tf*1e3, fl/tf/1e12, td*1e3, fl/td/1e12, tw*1e3, fl/tw/1e12), flush=True)
