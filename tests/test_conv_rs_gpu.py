@@ -160,3 +160,38 @@ def test_reproducible_and_no_fallback(dev):
     # every sample is computed independently of its neighbours in the batch
     y3, _, _ = op.forward(x[1:3].contiguous(), w, b, 0.01, h, w_)
     assert _is_rs(K) and torch.equal(y3, y1[1:3])
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_geometries(dev, seed):
+    """random (batch, rows, strips): every row-segment split the plan can produce (segments of 16 .. 2 x 16 - 1 rows, remainders of
+    the unroll), forward with the affine + statistics and the accumulating data gradient with the BatchNorm-backward reduce"""
+    from pointcloududa_amd import kernels as K
+    from pointcloududa_amd.kernels import TA
+    rng = np.random.default_rng(100 + seed)
+    n, h, w_ = int(rng.integers(1, 7)), int(rng.integers(2, 150)), 32 * int(rng.integers(1, 5))
+    x = torch.from_numpy(rng.normal(0, 1, (n, 32, h, w_)).astype(np.float32))
+    w = torch.from_numpy(rng.normal(0, 0.1, (32, 32, 3, 3)).astype(np.float32))
+    b = torch.from_numpy(rng.normal(0, 0.1, (32,)).astype(np.float32))
+    sc = torch.from_numpy(rng.normal(1, 0.3, (32,)).astype(np.float32))
+    sf = torch.from_numpy(rng.normal(0.4, 0.3, (32,)).astype(np.float32))
+    y_ref = F.leaky_relu(F.conv2d(x * sc[None, :, None, None] + sf[None, :, None, None], w, b, padding=1), 0.01)
+    op = K.ConvOp(32, 32, 3, pad=1)
+    y, part, nt = op.forward(TA(x.to(dev), sc.to(dev), sf.to(dev)), w.to(dev), b.to(dev), 0.01, h, w_, want_stats=True)
+    assert _is_rs(K), K.last_kernel()
+    assert rel_err(y, y_ref) < 1e-4, (n, h, w_)
+    s = part[:nt].double().sum(0).cpu()
+    assert rel_err(s[:, 0], y_ref.double().sum((0, 2, 3))) < 1e-3 and rel_err(s[:, 1], (y_ref.double() ** 2).sum((0, 2, 3))) < 1e-3
+    gz = torch.from_numpy(rng.normal(0, 1, (n, 32, h, w_)).astype(np.float32))
+    a = torch.from_numpy(rng.normal(0, 1, (n, 32, h, w_)).astype(np.float32))
+    mean, invstd = a.mean((0, 2, 3)), 1.0 / torch.sqrt(a.var((0, 2, 3), unbiased=False) + 1e-5)
+    base = torch.from_numpy(rng.normal(0, 1, (n, 32, h, w_)).astype(np.float32))
+    g_ref = F.conv_transpose2d(gz, w, padding=1).double() + base.double()
+    ahat = (a.double() - mean.double()[None, :, None, None]) * invstd.double()[None, :, None, None]
+    st = K.BNState()
+    st.mean, st.invstd = mean.to(dev), invstd.to(dev)
+    dx, red = op.dgrad(gz.to(dev), w.to(dev), h, w_, dx=base.to(dev).clone(), accumulate=True, bnred=(a.to(dev), st))
+    assert "conv3rs+bnred" in K.last_kernel(), K.last_kernel()
+    assert rel_err(dx, g_ref.float()) < 1e-4, (n, h, w_)
+    got = red[0][:red[1]].double().sum(0).cpu()
+    assert rel_err(got[:, 0], g_ref.sum((0, 2, 3))) < 1e-3 and rel_err(got[:, 1], (g_ref * ahat).sum((0, 2, 3))) < 1e-3
