@@ -199,9 +199,25 @@ class _PointNetFn(torch.autograd.Function):
         if tape.trace is not None:
             module._last_trace = tape.trace
         if module.training:
-            for k, b in module.named_buffers():
-                if k.endswith("num_batches_tracked") and ".in" not in k and not k.startswith("in"):
-                    b.add_(1)
+            flat = getattr(module, "_flat_tracked", None)
+            if flat is not None:   # (still the buffers' storage?  module.to() / a re-registered buffer leaves the flat tensor behind)
+                first = next((b for k, b in module.named_buffers() if k.endswith("num_batches_tracked")), None)
+                if first is None or first.data_ptr() != flat.data_ptr():
+                    flat = None
+            if flat is not None:
+                # (optim.flatten_module re-seated every num_batches_tracked buffer as a view of ONE int64 tensor, in
+                #  named_buffers() order: one launch with a 0 / 1 mask instead of one per BatchNorm layer -- 32 per step)
+                mask = getattr(module, "_tracked_mask", None)
+                if mask is None or mask.device != flat.device or mask.numel() != flat.numel():
+                    names = [k for k, _ in module.named_buffers() if k.endswith("num_batches_tracked")]
+                    mask = torch.tensor([1 if (".in" not in k and not k.startswith("in")) else 0 for k in names],
+                                        dtype=torch.long, device=flat.device)
+                    module._tracked_mask = mask
+                flat.add_(mask)
+            else:
+                for k, b in module.named_buffers():
+                    if k.endswith("num_batches_tracked") and ".in" not in k and not k.startswith("in"):
+                        b.add_(1)
         ctx.tape, ctx.vars = tape, (xin, y, trans, trans_feat)
         ctx.set_materialize_grads(False)
         outs = (y.t, trans.t if trans is not None else x.new_zeros(()),
